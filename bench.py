@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- instance-disparity hot path on MI355X.
+
+One "step" = one pass of the hot path (a1 cost volume -> a3-a6 3D regressor -> a7 soft-argmin) over one batch of
+synthetic ROI feature pairs per GPU.  Headline workload = BASELINE.json's metric shape, Config A:
+112x112 ROI, 48 disparities -> cost volume [64,12,28,28] per ROI, entered at the feature boundary.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  ROIs are independent units: they are sharded across ranks with no data-path
+collective (weak scaling: fixed ROIs per GPU); a barrier + max-over-ranks brackets the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOPS_PER_VOXEL_3D = 644544          # conv FLOPs (2*MAC) of dres0..classif3 per cost-volume voxel
+PEAK_F32_TFLOPS = 157.3              # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md)
+
+
+def build_model(dev, maxdisp, mindisp, bn_case):
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    from disprcnn_amd.utils import synth
+    model = PSMNet(maxdisp, mindisp)
+    sd = synth.synth_state_dict(model.state_dict())
+    bn = os.path.join(ROOT, "tests", "golden", f"bn_stats_{bn_case}.npz")
+    if os.path.exists(bn):
+        synth.load_bn_stats(sd, bn)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev).eval(), sd
+
+
+def cpu_baseline_config_a(sd, budget_s=12.0):
+    """The CPU oracle (torch-CPU restatement, verified against the reference's outputs) on a bounded sample."""
+    from oracle import psmnet_oracle as O
+    from disprcnn_amd.utils import synth
+    threads = torch.get_num_threads()
+    fl, fr = synth.synth_features(4, 32, 28, 28, tag="cpu")
+    with torch.no_grad():
+        O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)          # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)
+            n += 4
+            el = time.perf_counter() - t0
+            if el >= budget_s:
+                break
+    return {"value": n / el, "unit": "ROI cost-volumes/s", "cores": threads, "kind": "port",
+            "sample": f"{n} ROI pairs (batches of 4) of the same Config-A workload, {el:.1f} s wall, torch-CPU fp32 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rois", type=int, default=64, help="ROI pairs per step per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Config-B extra measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used only for the barrier / max-reduce
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+
+    from disprcnn_amd import engine as E
+    from disprcnn_amd.utils import synth
+
+    model, sd = build_model(dev, 48, 0, "A")
+    N = args.rois
+    fl, fr = synth.synth_features(N, 32, 28, 28, tag=f"bench{rank}")
+    fl, fr = fl.to(dev), fr.to(dev)
+
+    def step():
+        return model.forward_from_features(fl, fr, (112, 112))
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, same K steps, same inputs
+    roofline = None
+    extra = {}
+    if rank == 0:
+        E.TIMING = []
+        with torch.no_grad():
+            for _ in range(args.steps):
+                step()
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in E.TIMING:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += flops
+        E.TIMING = None
+        dom = max(agg, key=lambda k: agg[k][1])
+        calls, secs, flops = agg[dom]
+        achieved = flops / secs / 1e12
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "calls_per_step": calls // args.steps, "avg_launch_us": round(secs / calls * 1e6, 2),
+                    "algorithmic_flops_per_launch": flops / calls}
+        extra["kernels"] = {k: {"calls_per_step": v[0] // args.steps, "avg_us": round(v[1] / v[0] * 1e6, 2),
+                                "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in agg.items()}
+        step_flops = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * N
+        extra["regressor_tflops_whole_step"] = round(step_flops * args.steps * world / elapsed / 1e12 / world, 2)
+
+        # ---- extra: Config B (224x224, D=96, full PSMNet incl. the 2D feature CNN), 16 ROI pairs per step
+        if not args.no_extra:
+            try:
+                mB, _ = build_model(dev, 48, -48, "B")
+                l, r = synth.synth_images(16, 224, 224, tag="benchB")
+                l, r = l.to(dev), r.to(dev)
+                with torch.no_grad():
+                    for _ in range(2):
+                        mB((l, r))
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter()
+                    for _ in range(5):
+                        mB((l, r))
+                    torch.cuda.synchronize()
+                    tb = (time.perf_counter() - tb) / 5
+                extra["config_b_full_psmnet"] = {"roi_pairs_per_s": round(16 / tb, 1), "ms_per_16_roi_image": round(tb * 1e3, 2),
+                                                 "stereo_pairs_per_s_16roi": round(1 / tb, 2),
+                                                 "workload": "16 ROI crops 224x224, D=96 (-48..48): 2D CNN + cost volume + 3D + soft-argmin"}
+                del mB
+            except Exception as ex:  # report, never hide
+                extra["config_b_full_psmnet"] = {"error": repr(ex)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline_config_a(sd)
+
+    if rank == 0:
+        total_rois = N * args.steps * world
+        line = {
+            "metric": "ROI cost-volumes/sec (112x112x48)", "value": round(total_rois / elapsed, 1), "unit": "ROI cost-volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Config A: per ROI pair, features [32,28,28]x2 -> concat cost volume [64,12,28,28] -> "
+                                   "3D stacked-hourglass regressor -> trilinear x4 + softmax + soft-argmin -> disparity [112,112]",
+                       "rois_per_step_per_gpu": N, "maxdisp": 48, "mindisp": 0, "parallelism": f"roi-shard x{world} (no collective)",
+                       "weights": "closed-form synthetic (disprcnn_amd.utils.synth), BN stats calibrated fixture"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

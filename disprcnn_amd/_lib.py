@@ -1,0 +1,87 @@
+"""ctypes binding of libdisprcnn_hip.so (the C ABI declared in include/disprcnn_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, ``lib()`` raises.  Status codes are turned into ``RuntimeError`` the way the
+reference turns ``AT_ASSERTM``/``THCudaCheck`` failures into Python errors
+(reference: csrc/ROIAlign.h:21,44; csrc/cuda/ROIAlign_cuda.cu:297).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdisprcnn_hip.so")
+
+DRC_MAX_TAPS = 64
+DRC_MAX_CLASSES = 8
+
+
+class DrcTap(C.Structure):
+    _fields_ = [("dd", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("widx", C.c_int32)]
+
+
+class DrcTapClass(C.Structure):
+    _fields_ = [("tap_begin", C.c_int32), ("tap_end", C.c_int32), ("n_phase", C.c_int32),
+                ("phase_tap_begin", C.c_int32 * 4),
+                ("min_dh", C.c_int32), ("max_dh", C.c_int32), ("min_dw", C.c_int32), ("max_dw", C.c_int32),
+                ("out_off_d", C.c_int32), ("out_off_h", C.c_int32), ("out_off_w", C.c_int32)]
+
+
+class DrcTapconvParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("res", C.c_void_p), ("y", C.c_void_p),
+                ("x_n_stride", C.c_int64), ("x_cb_stride", C.c_int64), ("x_d_stride", C.c_int64), ("x_h_stride", C.c_int64),
+                ("y_n_stride", C.c_int64), ("y_cb_stride", C.c_int64), ("y_d_stride", C.c_int64), ("y_h_stride", C.c_int64),
+                ("y_off0", C.c_int64),
+                ("r_n_stride", C.c_int64), ("r_cb_stride", C.c_int64), ("r_d_stride", C.c_int64), ("r_h_stride", C.c_int64),
+                ("r_off0", C.c_int64),
+                ("N", C.c_int32), ("OD", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+                ("in_mul", C.c_int32), ("out_mul", C.c_int32), ("cb_in", C.c_int32), ("cout_pad", C.c_int32),
+                ("R", C.c_int32), ("WT", C.c_int32), ("relu", C.c_int32), ("n_classes", C.c_int32),
+                ("lds_bytes_per_wave", C.c_int32), ("reserved", C.c_int32),
+                ("cls", DrcTapClass * DRC_MAX_CLASSES), ("taps", DrcTap * DRC_MAX_TAPS)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_SIGS = {
+    "drc_version": (C.c_char_p, []),
+    "drc_cost_volume_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_cost_volume_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_cost_volume_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_dense_to_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_blocked_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_tapconv_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_conv3d_cout1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "drc_upsample_softargmin_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_avgpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_bilinear_up_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_copy_blocks": (_I, [_P, _P, _I, _I, C.c_int64, _I, _I, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or python -m disprcnn_amd.csrc.build). "
+                "There is no CPU/torch fallback for this path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        kind = "bad argument / unsupported shape" if status < 0 else "hipError_t"
+        raise RuntimeError(f"{what} failed: status {status} ({kind})")

@@ -1,0 +1,52 @@
+"""Build libdisprcnn_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m disprcnn_amd.csrc.build [--force]
+
+The .so stays in-tree (git-ignored, but it travels to the GPU box with the snapshot).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["tapconv.hip", "volume_ops.hip", "roi_ops.hip", "train_ops.hip"]
+LIB = os.path.join(HERE, "libdisprcnn_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _sources():
+    return [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = _sources() + [os.path.join(HERE, "..", "..", "include", "disprcnn_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    for src in _sources():
+        obj = src[:-4] + ".o"
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "..", "include", "disprcnn_hip.h"))):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

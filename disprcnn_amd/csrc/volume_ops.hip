@@ -1,0 +1,429 @@
+// volume_ops.hip -- HBM-bound kernels of the instance-disparity path (gfx950):
+//   cost-volume build (dense NCDHW, blocked), its adjoint, layout converters, the 32->1 classifier conv,
+//   and the fused trilinear-upsample + softmax + soft-argmin epilogue.
+// All are pure data movement / short reductions: coalesced 16-byte accesses, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned grid_for(long work, int cap = 256 * 16) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1: dense cost volume.  Reference: stackhourglass.py:115-128 (zeros + 2*(D/4) slice copies).
+// Thread = 4 consecutive x of one (n, c2, j, y) row; L as aligned float4, R as shifted scalars.
+template <bool VEC4>
+__global__ __launch_bounds__(kThreads) void cost_volume_dense_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                                     float* __restrict__ cost, int N, int C, int Dp, int Hp, int Wp,
+                                                                     int lo4, int hi4) {
+    const int XV = VEC4 ? 4 : 1;
+    const int wq = Wp / XV;
+    const long total = (long)N * 2 * C * Dp * Hp * wq;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int xq = (int)(t % wq); t /= wq;
+        const int y = (int)(t % Hp); t /= Hp;
+        const int j = (int)(t % Dp); t /= Dp;
+        const int c2 = (int)(t % (2 * C));
+        const int n = (int)(t / (2 * C));
+        const int i = lo4 + j;
+        const bool live = i < hi4;
+        const int x0 = xq * XV;
+        float v[4];
+        const bool right = c2 >= C;
+        const int c = right ? c2 - C : c2;
+        const float* src = (right ? R : L) + (((long)n * C + c) * Hp + y) * Wp;
+#pragma unroll
+        for (int e = 0; e < XV; ++e) {
+            const int x = x0 + e, xs = x - i;
+            const bool ok = live && xs >= 0 && xs < Wp;
+            v[e] = ok ? src[right ? xs : x] : 0.0f;
+        }
+        float* dst = cost + ((((long)n * 2 * C + c2) * Dp + j) * Hp + y) * Wp + x0;
+        if (VEC4) *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+        else dst[0] = v[0];
+    }
+}
+
+// adjoint of the copy.  Thread per (half, n, c, y, x): sums the D' slices that copied this element.
+__global__ __launch_bounds__(kThreads) void cost_volume_bwd_kernel(const float* __restrict__ g, float* __restrict__ gL,
+                                                                   float* __restrict__ gR, int N, int C, int Dp, int Hp, int Wp,
+                                                                   int lo4, int hi4) {
+    const long per = (long)N * C * Hp * Wp;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < 2 * per; idx += (long)gridDim.x * kThreads) {
+        const bool right = idx >= per;
+        long t = right ? idx - per : idx;
+        const int x = (int)(t % Wp); t /= Wp;
+        const int y = (int)(t % Hp); t /= Hp;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        float s = 0.f;
+        for (int j = 0; j < Dp; ++j) {
+            const int i = lo4 + j;
+            if (i >= hi4) break;
+            const int xo = right ? x + i : x;      // output column that copied this input element
+            const int xs = xo - i;                  // == x for right, x - i for left validity test
+            const bool ok = right ? (xo >= 0 && xo < Wp) : (xs >= 0 && xs < Wp);
+            if (ok) s += g[((((long)n * 2 * C + (right ? C + c : c)) * Dp + j) * Hp + y) * Wp + xo];
+        }
+        (right ? gR : gL)[(((long)n * C + c) * Hp + y) * Wp + x] = s;
+    }
+}
+
+// a1, blocked output [N][2C/16][Dp+2][Hp+2][Wp+2][16] (pads 1).  Thread = one float4 (4 channels of a voxel).
+__global__ __launch_bounds__(kThreads) void cost_volume_blocked_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                                       float* __restrict__ out, int N, int C, int Dp, int Hp, int Wp,
+                                                                       int lo4, int hi4, int fp) {
+    const int CBo = 2 * C / 16, CBi = C / 16;
+    const long total = (long)N * CBo * Dp * Hp * Wp * 4;
+    const long oH = Wp + 2, oD = (long)(Hp + 2) * oH, oC = (long)(Dp + 2) * oD;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int x = (int)(t % Wp); t /= Wp;
+        const int y = (int)(t % Hp); t /= Hp;
+        const int j = (int)(t % Dp); t /= Dp;
+        const int cbo = (int)(t % CBo);
+        const int n = (int)(t / CBo);
+        const int i = lo4 + j;
+        const int xs = x - i;
+        const bool ok = (i < hi4) && xs >= 0 && xs < Wp;
+        const bool right = cbo >= CBi;
+        const int cbi = right ? cbo - CBi : cbo;
+        const int xr = right ? xs : x;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const float* src = right ? R : L;
+            if (fp > 0) {
+                const long iW = Wp + 2 * fp, iH = Hp + 2 * fp;
+                v = *(const f32x4*)(src + ((((long)n * CBi + cbi) * iH + (y + fp)) * iW + (xr + fp)) * 16 + q * 4);
+            } else {
+                const long plane = (long)Hp * Wp;
+                const float* s0 = src + ((long)n * C + cbi * 16 + q * 4) * plane + (long)y * Wp + xr;
+                v = (f32x4){s0[0], s0[plane], s0[2 * plane], s0[3 * plane]};
+            }
+        }
+        *(f32x4*)(out + (((long)n * CBo + cbo) * oC + (long)(j + 1) * oD + (long)(y + 1) * oH + (x + 1)) * 16 + q * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void dense_to_blocked_kernel(const float* __restrict__ dense, float* __restrict__ blk, int N, int C,
+                                                                    int D, int H, int W, int pd, int ph, int pw) {
+    const int CB = (C + 15) / 16;
+    const long total = (long)N * CB * D * H * W * 4;
+    const long bW = W + 2 * pw, bH = H + 2 * ph, bD = D + 2 * pd;
+    const long plane = (long)D * H * W;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H); t /= H;
+        const int d = (int)(t % D); t /= D;
+        const int cb = (int)(t % CB);
+        const int n = (int)(t / CB);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cb * 16 + q * 4 + e;
+            v[e] = c < C ? dense[((long)n * C + c) * plane + ((long)d * H + y) * W + x] : 0.f;
+        }
+        *(f32x4*)(blk + ((((long)n * CB + cb) * bD + (d + pd)) * bH * bW + (long)(y + ph) * bW + (x + pw)) * 16 + q * 4) =
+            (f32x4){v[0], v[1], v[2], v[3]};
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void blocked_to_dense_kernel(const float* __restrict__ blk, float* __restrict__ dense, int N, int C,
+                                                                    int D, int H, int W, int pd, int ph, int pw) {
+    const int CB = (C + 15) / 16;
+    const long total = (long)N * C * D * H * W;
+    const long bW = W + 2 * pw, bH = H + 2 * ph, bD = D + 2 * pd;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H); t /= H;
+        const int d = (int)(t % D); t /= D;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        dense[idx] = blk[((((long)n * CB + (c >> 4)) * bD + (d + pd)) * bH * bW + (long)(y + ph) * bW + (x + pw)) * 16 + (c & 15)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// classifN[2]: Conv3d(32->1,k3,p1).  4 lanes per voxel (channel quads), 27*cb_in float4 loads, quad-reduce by shuffle.
+__global__ __launch_bounds__(kThreads) void conv3d_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ res, float* __restrict__ out, int N, int cb_in,
+                                                                int D, int H, int W) {
+    const long nvox = (long)N * D * H * W;
+    const long total = nvox * 4;
+    const long bW = W + 2, bH = H + 2, bD = D + 2;
+    const long sH = bW * 16, sD = bH * sH, sC = bD * sD, sN = sC * cb_in;
+    const long work = ((total + kThreads - 1) / kThreads) * kThreads;  // keep whole waves alive for the shuffles
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < work; idx += (long)gridDim.x * kThreads) {
+        const bool live = idx < total;
+        long t = live ? idx : 0;
+        const int q = (int)(t & 3); t >>= 2;
+        const long vox = t;
+        const int xw = (int)(t % W); t /= W;
+        const int y = (int)(t % H); t /= H;
+        const int d = (int)(t % D);
+        const int n = (int)(t / D);
+        const float* xb = x + n * sN + d * sD + y * sH + (long)xw * 16 + q * 4;  // tap (0,0,0) in padded coords
+        float s = 0.f;
+        for (int cb = 0; cb < cb_in; ++cb) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const f32x4 xv = *(const f32x4*)(xb + cb * sC + kd * sD + kh * sH + kw * 16);
+                        const f32x4 wv = *(const f32x4*)(w + ((kd * 3 + kh) * 3 + kw) * cb_in * 16 + cb * 16 + q * 4);
+                        s = fmaf(xv.x, wv.x, s); s = fmaf(xv.y, wv.y, s); s = fmaf(xv.z, wv.z, s); s = fmaf(xv.w, wv.w, s);
+                    }
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (live && q == 0) out[vox] = res ? s + res[vox] : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7: trilinear(align_corners=True) x softmax over D x soft-argmin, one thread per output pixel.
+// Bilinear (y,x) resample of every coarse slice into LDS (column per thread), then one pass over the D fine
+// disparities with a linear blend between neighbouring coarse slices.  Never materialises [N,D,H,W].
+constexpr int kSAThreads = 128;
+__global__ __launch_bounds__(kSAThreads) void upsample_softargmin_kernel(const float* __restrict__ cost, float* __restrict__ disp, int N,
+                                                                         int Dp, int Hp, int Wp, int D, int H, int W, int mindisp) {
+    extern __shared__ float cz[];  // [Dp][kSAThreads]
+    const long total = (long)N * H * W;
+    const long idx = (long)blockIdx.x * kSAThreads + threadIdx.x;
+    if (idx >= total) return;
+    long t = idx;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const float sd = D > 1 ? (float)(Dp - 1) / (float)(D - 1) : 0.f;
+    const float fy = sy * y, fx = sx * x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
+    const float ty = fy - y0, tx = fx - x0;
+    const float* c = cost + (long)n * Dp * Hp * Wp;
+    float m = -INFINITY;
+    for (int k = 0; k < Dp; ++k) {
+        const float* s = c + (long)k * Hp * Wp;
+        const float a = s[y0 * Wp + x0] * (1.f - tx) + s[y0 * Wp + x1] * tx;
+        const float b = s[y1 * Wp + x0] * (1.f - tx) + s[y1 * Wp + x1] * tx;
+        const float v = a * (1.f - ty) + b * ty;
+        cz[k * kSAThreads + threadIdx.x] = v;
+        m = fmaxf(m, v);
+    }
+    float se = 0.f, sde = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float fd = sd * d;
+        const int k0 = (int)fd;
+        const int k1 = k0 + (k0 < Dp - 1);
+        const float td = fd - k0;
+        const float v = cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td;
+        const float e = expf(v - m);
+        se += e;
+        sde = fmaf(e, (float)(mindisp + d), sde);
+    }
+    disp[idx] = sde / se;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPP helpers on blocked 2D tensors (submodule.py:76-90, :120-135).
+// One wave per pooled output voxel: 16 window positions x 4 channel quads per step, shuffle-reduce.
+__global__ __launch_bounds__(64) void avgpool2d_blocked_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int CB, int H,
+                                                               int W, int px, int k, int OH, int OW, int py) {
+    long t = blockIdx.x;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH); t /= OH;
+    const int cb = (int)(t % CB);
+    const int n = (int)(t / CB);
+    const int lane = threadIdx.x, q = lane & 3, p0 = lane >> 2;
+    const long iW = W + 2 * px, iH = H + 2 * px;
+    const float* xb = x + (((long)n * CB + cb) * iH + (oh * k + px)) * iW * 16 + (long)(ow * k + px) * 16 + q * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0; p < k * k; p += 16) {
+        const int r = p / k, c = p - r * k;
+        s += *(const f32x4*)(xb + ((long)r * iW + c) * 16);
+    }
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+        s.x += __shfl_xor(s.x, m); s.y += __shfl_xor(s.y, m); s.z += __shfl_xor(s.z, m); s.w += __shfl_xor(s.w, m);
+    }
+    if (p0 == 0) {
+        const float inv = 1.0f / (float)(k * k);
+        const long oW = OW + 2 * py, oH = OH + 2 * py;
+        *(f32x4*)(y + ((((long)n * CB + cb) * oH + (oh + py)) * oW + (ow + py)) * 16 + q * 4) = s * inv;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bilinear_up_blocked_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int CB,
+                                                                       int IH, int IW, int px, int OH, int OW, int py, int y_cb_total,
+                                                                       int y_cb_off) {
+    const long total = (long)N * CB * OH * OW * 4;
+    const long iW = IW + 2 * px, iH = IH + 2 * px, oW = OW + 2 * py, oH = OH + 2 * py;
+    const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+    const float sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH); t /= OH;
+        const int cb = (int)(t % CB);
+        const int n = (int)(t / CB);
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < IH - 1), x1 = x0 + (x0 < IW - 1);
+        const float ty = fy - y0, tx = fx - x0;
+        const float* xb = x + (((long)n * CB + cb) * iH) * iW * 16 + q * 4;
+        const f32x4 v00 = *(const f32x4*)(xb + ((long)(y0 + px) * iW + (x0 + px)) * 16);
+        const f32x4 v01 = *(const f32x4*)(xb + ((long)(y0 + px) * iW + (x1 + px)) * 16);
+        const f32x4 v10 = *(const f32x4*)(xb + ((long)(y1 + px) * iW + (x0 + px)) * 16);
+        const f32x4 v11 = *(const f32x4*)(xb + ((long)(y1 + px) * iW + (x1 + px)) * 16);
+        // same association as ATen's upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+        const f32x4 v = (1.f - ty) * ((1.f - tx) * v00 + tx * v01) + ty * ((1.f - tx) * v10 + tx * v11);
+        *(f32x4*)(y + ((((long)n * y_cb_total + y_cb_off + cb) * oH + (oy + py)) * oW + (ox + py)) * 16 + q * 4) = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void copy_blocks_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int CB,
+                                                               long vox_per_cb, int y_cb_total, int y_cb_off) {
+    const long per = vox_per_cb * 4;
+    const long total = (long)N * CB * per;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        const long e = idx % per;
+        long t = idx / per;
+        const int cb = (int)(t % CB);
+        const int n = (int)(t / CB);
+        *(f32x4*)(y + (((long)n * y_cb_total + y_cb_off + cb) * per + e) * 4) = *(const f32x4*)(x + idx * 4);
+    }
+}
+
+inline int done() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+const char* drc_version(void) { return "disprcnn_hip gfx950 abi1"; }
+
+int drc_cost_volume_fwd(const float* left, const float* right, float* cost, int N, int C, int Dp, int Hp, int Wp, int lo4, int hi4,
+                        void* stream) {
+    if (N < 0 || C <= 0 || Dp < 0 || Hp <= 0 || Wp <= 0) return -2;
+    const long total = (long)N * 2 * C * Dp * Hp * Wp;
+    if (total == 0) return 0;
+    if (!left || !right || !cost) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (Wp % 4 == 0 && ((uintptr_t)cost & 15) == 0)
+        hipLaunchKernelGGL(cost_volume_dense_kernel<true>, dim3(grid_for(total / 4)), dim3(kThreads), 0, s, left, right, cost, N, C, Dp, Hp, Wp, lo4, hi4);
+    else
+        hipLaunchKernelGGL(cost_volume_dense_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0, s, left, right, cost, N, C, Dp, Hp, Wp, lo4, hi4);
+    return done();
+}
+
+int drc_cost_volume_bwd(const float* gcost, float* gleft, float* gright, int N, int C, int Dp, int Hp, int Wp, int lo4, int hi4,
+                        void* stream) {
+    if (N < 0 || C <= 0 || Dp < 0 || Hp <= 0 || Wp <= 0) return -2;
+    const long total = 2L * N * C * Hp * Wp;
+    if (total == 0) return 0;
+    if (!gcost || !gleft || !gright) return -1;
+    hipLaunchKernelGGL(cost_volume_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, gcost, gleft, gright, N, C, Dp, Hp, Wp, lo4, hi4);
+    return done();
+}
+
+int drc_cost_volume_blocked_fwd(const float* left, const float* right, float* cost_blk, int N, int C, int Dp, int Hp, int Wp, int lo4,
+                                int hi4, int in_blocked_pad, void* stream) {
+    if (N < 0 || C <= 0 || (C & 15) || Dp < 0 || Hp <= 0 || Wp <= 0 || in_blocked_pad < 0) return -2;
+    const long total = (long)N * (2 * C / 16) * Dp * Hp * Wp * 4;
+    if (total == 0) return 0;
+    if (!left || !right || !cost_blk) return -1;
+    hipLaunchKernelGGL(cost_volume_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, left, right, cost_blk, N, C, Dp, Hp, Wp, lo4, hi4, in_blocked_pad);
+    return done();
+}
+
+int drc_dense_to_blocked(const float* dense, float* blk, int N, int C, int D, int H, int W, int pd, int ph, int pw, void* stream) {
+    if (N < 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || pd < 0 || ph < 0 || pw < 0) return -2;
+    const long total = (long)N * ((C + 15) / 16) * D * H * W * 4;
+    if (total == 0) return 0;
+    if (!dense || !blk) return -1;
+    hipLaunchKernelGGL(dense_to_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, dense, blk, N, C, D, H, W, pd, ph, pw);
+    return done();
+}
+
+int drc_blocked_to_dense(const float* blk, float* dense, int N, int C, int D, int H, int W, int pd, int ph, int pw, void* stream) {
+    if (N < 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || pd < 0 || ph < 0 || pw < 0) return -2;
+    const long total = (long)N * C * D * H * W;
+    if (total == 0) return 0;
+    if (!dense || !blk) return -1;
+    hipLaunchKernelGGL(blocked_to_dense_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, blk, dense, N, C, D, H, W, pd, ph, pw);
+    return done();
+}
+
+int drc_conv3d_cout1_fwd(const float* x, const float* w, const float* res, float* out, int N, int cb_in, int D, int H, int W,
+                         void* stream) {
+    if (N < 0 || cb_in <= 0 || D <= 0 || H <= 0 || W <= 0) return -2;
+    const long total = (long)N * D * H * W * 4;
+    if (total == 0) return 0;
+    if (!x || !w || !out) return -1;
+    hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(grid_for(total, 256 * 32)), dim3(kThreads), 0, (hipStream_t)stream, x, w, res, out, N, cb_in, D, H, W);
+    return done();
+}
+
+int drc_upsample_softargmin_fwd(const float* cost, float* disp, int N, int Dp, int Hp, int Wp, int D, int H, int W, int mindisp,
+                                void* stream) {
+    if (N < 0 || Dp <= 0 || Hp <= 0 || Wp <= 0 || D <= 0 || H <= 0 || W <= 0) return -2;
+    if (Dp > 96) return -3;  // LDS column per thread: Dp * 128 * 4 B
+    const long total = (long)N * H * W;
+    if (total == 0) return 0;
+    if (!cost || !disp) return -1;
+    const unsigned blocks = (unsigned)((total + kSAThreads - 1) / kSAThreads);
+    hipLaunchKernelGGL(upsample_softargmin_kernel, dim3(blocks), dim3(kSAThreads), (size_t)Dp * kSAThreads * 4, (hipStream_t)stream, cost, disp, N, Dp, Hp, Wp, D, H, W, mindisp);
+    return done();
+}
+
+int drc_avgpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W, int px, int k, int OH, int OW, int py, void* stream) {
+    if (N < 0 || CB <= 0 || H <= 0 || W <= 0 || k <= 0 || OH <= 0 || OW <= 0 || OH * k > H || OW * k > W) return -2;
+    const long blocks = (long)N * CB * OH * OW;
+    if (blocks == 0) return 0;
+    if (!x || !y) return -1;
+    hipLaunchKernelGGL(avgpool2d_blocked_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, x, y, N, CB, H, W, px, k, OH, OW, py);
+    return done();
+}
+
+int drc_bilinear_up_blocked(const float* x, float* y, int N, int CB, int IH, int IW, int px, int OH, int OW, int py, int y_cb_total,
+                            int y_cb_off, void* stream) {
+    if (N < 0 || CB <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || y_cb_off < 0 || y_cb_off + CB > y_cb_total) return -2;
+    const long total = (long)N * CB * OH * OW * 4;
+    if (total == 0) return 0;
+    if (!x || !y) return -1;
+    hipLaunchKernelGGL(bilinear_up_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, N, CB, IH, IW, px, OH, OW, py, y_cb_total, y_cb_off);
+    return done();
+}
+
+int drc_copy_blocks(const float* x, float* y, int N, int CB, int64_t vox_per_cb, int y_cb_total, int y_cb_off, void* stream) {
+    if (N < 0 || CB <= 0 || vox_per_cb <= 0 || y_cb_off < 0 || y_cb_off + CB > y_cb_total) return -2;
+    const long total = (long)N * CB * vox_per_cb * 4;
+    if (total == 0) return 0;
+    if (!x || !y) return -1;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, N, CB, (long)vox_per_cb, y_cb_total, y_cb_off);
+    return done();
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+"""Host side of the HIP engine: blocked tensors, weight packing, tap lists, launch plans.
+
+PyTorch is used for device memory, streams and parameter storage only; all arithmetic of
+the hot path runs in libdisprcnn_hip.so through the C ABI (include/disprcnn_hip.h).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import DrcTapconvParams
+
+CB = 16
+SLACK_FLOATS = 1 << 16          # over-read room behind every blocked tensor (ragged last row groups)
+LDS_PER_WAVE_MAX = 38 * 1024    # 4 waves/block -> 152 KiB of the 160 KiB LDS
+MAX_SLOTS = 112                 # 7 voxel tiles of 16
+TIMING = None                   # bench.py sets this to a list to collect (kernel name, flops, start_evt, end_evt)
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected a CUDA/HIP tensor on an MI355X; the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what}: fp32 only (reference: config/defaults.py:22 DTYPE float32), got {t.dtype}")
+
+
+class Blocked:
+    """Channel-blocked, zero-haloed tensor float[N][CB][D+2pd][H+2ph][W+2pw][16]."""
+
+    def __init__(self, N, C_, D, H, W, pd, ph, pw, device):
+        self.N, self.C, self.D, self.H, self.W = N, C_, D, H, W
+        self.pd, self.ph, self.pw = pd, ph, pw
+        self.cb = (C_ + CB - 1) // CB
+        self.Dp, self.Hp, self.Wp = D + 2 * pd, H + 2 * ph, W + 2 * pw
+        self.h_stride = self.Wp * CB
+        self.d_stride = self.Hp * self.h_stride
+        self.cb_stride = self.Dp * self.d_stride
+        self.n_stride = self.cb * self.cb_stride
+        self.numel = N * self.n_stride
+        self.storage = torch.zeros(self.numel + SLACK_FLOATS, dtype=torch.float32, device=device)
+        self.device = device
+
+    @property
+    def interior_off(self):
+        return self.pd * self.d_stride + self.ph * self.h_stride + self.pw * CB
+
+    def view6(self):
+        return self.storage[: self.numel].view(self.N, self.cb, self.Dp, self.Hp, self.Wp, CB)
+
+    def from_dense(self, dense):
+        """dense [N,C,D,H,W] or [N,C,H,W] -> interior of this blocked tensor (HIP kernel)."""
+        require_gpu(dense, "from_dense")
+        dense = dense.contiguous()
+        if self.N == 0:
+            return self
+        st = _lib.lib().drc_dense_to_blocked(_ptr(dense), _ptr(self.storage), self.N, self.C, self.D, self.H, self.W,
+                                             self.pd, self.ph, self.pw, _stream_ptr(self.device))
+        _lib.check(st, "drc_dense_to_blocked")
+        return self
+
+    def to_dense(self):
+        shape = (self.N, self.C, self.D, self.H, self.W)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if self.N:
+            st = _lib.lib().drc_blocked_to_dense(_ptr(self.storage), _ptr(out), self.N, self.C, self.D, self.H, self.W,
+                                                 self.pd, self.ph, self.pw, _stream_ptr(self.device))
+            _lib.check(st, "drc_blocked_to_dense")
+        return out
+
+
+class BlockedSlice:
+    """A channel-block slice [cb_off, cb_off+cb) of a Blocked tensor (concat without copies)."""
+
+    def __init__(self, base, cb_off, channels):
+        self.base, self.cb_off, self.C = base, cb_off, channels
+        self.cb = (channels + CB - 1) // CB
+        for k in ("N", "D", "H", "W", "pd", "ph", "pw", "Dp", "Hp", "Wp", "h_stride", "d_stride", "cb_stride", "n_stride",
+                  "device", "storage", "interior_off"):
+            setattr(self, k, getattr(base, k))
+
+    @property
+    def ptr_off(self):
+        return self.cb_off * self.cb_stride
+
+
+def _base_ptr(t):
+    off = getattr(t, "ptr_off", 0)
+    return t.storage.data_ptr() + 4 * off
+
+
+# ------------------------------------------------------------------------------------------- weights
+def pack_weight(w, transposed=False):
+    """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) -> [K][cb_in][cout_pad][16] fp32 contiguous."""
+    if transposed:
+        w = w.transpose(0, 1)
+    cout, cin = w.shape[:2]
+    K = int(math.prod(w.shape[2:]))
+    cb = (cin + CB - 1) // CB
+    cout_pad = (cout + CB - 1) // CB * CB
+    wp = torch.zeros(K, cb * CB, cout_pad, dtype=torch.float32, device=w.device)
+    wp[:, :cin, :cout] = w.reshape(cout, cin, K).permute(2, 1, 0)
+    return wp.view(K, cb, CB, cout_pad).permute(0, 1, 3, 2).contiguous()
+
+
+def pack_weight_cout1(w):
+    """Conv3d(Cin->1,k3) weight [1,Cin,3,3,3] -> [27][cb*16]."""
+    cin = w.shape[1]
+    cb = (cin + CB - 1) // CB
+    wp = torch.zeros(27, cb * CB, dtype=torch.float32, device=w.device)
+    wp[:, :cin] = w.reshape(cin, 27).t()
+    return wp.contiguous()
+
+
+def fold_bn(gamma, beta, mean, var, eps=1e-5, cout_pad=None):
+    """Eval-mode BatchNorm folded to y = scale*conv + shift (reference: submodule.py:19-22 conv->BN)."""
+    scale = gamma / torch.sqrt(var + eps)
+    shift = beta - mean * scale
+    if cout_pad is not None and cout_pad != scale.numel():
+        s = torch.ones(cout_pad, dtype=torch.float32, device=scale.device)
+        b = torch.zeros(cout_pad, dtype=torch.float32, device=scale.device)
+        s[: scale.numel()] = scale
+        b[: shift.numel()] = shift
+        scale, shift = s, b
+    return scale.contiguous().float(), shift.contiguous().float()
+
+
+# ------------------------------------------------------------------------------------------- tap lists
+def taps_conv(kdims, dilation, pad_conv, pad_in):
+    """Cross-correlation taps for a (kd,kh,kw) kernel: offset = k*dil - pad_conv + pad_in (padded input coords)."""
+    kd, kh, kw = kdims
+    taps = []
+    for a in range(kd):
+        for b in range(kh):
+            for c in range(kw):
+                dd = a * dilation[0] - pad_conv[0] + pad_in[0]
+                dh = b * dilation[1] - pad_conv[1] + pad_in[1]
+                dw = c * dilation[2] - pad_conv[2] + pad_in[2]
+                if min(dd, dh, dw) < 0:
+                    raise ValueError("input halo too small for this convolution")
+                taps.append((dd, dh, dw, (a * kh + b) * kw + c))
+    return [dict(taps=taps, off=(0, 0, 0))]
+
+
+def taps_deconv3d_k3s2(pad_in=(1, 1, 1)):
+    """ConvTranspose3d(k3,s2,p1,op1) as 8 output-parity classes (stackhourglass.py:22-30).
+    o = 2i - 1 + k  =>  even o=2j: (i=j,k=1);  odd o=2j+1: (i=j,k=2), (i=j+1,k=0)."""
+    per = {0: [(0, 1)], 1: [(0, 2), (1, 0)]}
+    classes = []
+    for pd_ in (0, 1):
+        for ph_ in (0, 1):
+            for pw_ in (0, 1):
+                taps = []
+                for (od_, kd) in per[pd_]:
+                    for (oh_, kh) in per[ph_]:
+                        for (ow_, kw) in per[pw_]:
+                            taps.append((od_ + pad_in[0], oh_ + pad_in[1], ow_ + pad_in[2], (kd * 3 + kh) * 3 + kw))
+                classes.append(dict(taps=taps, off=(pd_, ph_, pw_)))
+    return classes
+
+
+def choose_tile(OH, OW, in_mul, span_h, span_w):
+    """Pick (R, WT): rows x cols of output per wave.  Maximise useful MFMA slots under the LDS budget."""
+    best = None
+    wts = {-(-OW // parts) for parts in range(1, OW + 1) if -(-OW // parts) <= MAX_SLOTS}
+    for wt in sorted(wts):
+        for r in range(1, min(OH, MAX_SLOTS // wt) + 1):
+            rows_in = in_mul * (r - 1) + span_h + 1
+            seg = in_mul * (wt - 1) + span_w + 1
+            lds = 2 * rows_in * seg * 64
+            if lds > LDS_PER_WAVE_MAX:
+                continue
+            n_rt, n_wt = -(-OH // r), -(-OW // wt)
+            nvt = -(-(r * wt) // 16)
+            vt_cap = 4 if nvt <= 4 else 7   # instantiations <4,*> and <7,*>: MFMAs issued per group = nvt*16 slots
+            useful = OH * OW
+            issued = n_rt * n_wt * nvt * 16
+            eff = useful / issued
+            key = (round(eff, 4), r * wt, -lds)
+            if best is None or key > best[0]:
+                best = (key, r, wt, lds, vt_cap)
+    if best is None:
+        raise ValueError("no tile fits the LDS budget")
+    return best[1], best[2], best[3]
+
+
+class ConvPlan:
+    """A fully resolved tapconv launch: geometry, tap classes, tile choice.  Pointers are patched per call."""
+
+    def __init__(self, x, y, classes, in_mul, out_mul, grid_dhw, cout, relu):
+        p = DrcTapconvParams()
+        OD, OH, OW = grid_dhw
+        p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
+        p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
+        p.y_off0 = y.interior_off
+        p.N, p.OD, p.OH, p.OW = x.N, OD, OH, OW
+        p.in_mul, p.out_mul = in_mul, out_mul
+        p.cb_in = x.cb
+        p.cout_pad = (cout + CB - 1) // CB * CB
+        p.relu = int(relu)
+        p.n_classes = len(classes)
+        span_h = max(max(t[1] for t in c["taps"]) - min(t[1] for t in c["taps"]) for c in classes)
+        span_w = max(max(t[2] for t in c["taps"]) - min(t[2] for t in c["taps"]) for c in classes)
+        R, WT, lds = choose_tile(OH, OW, in_mul, span_h, span_w)
+        p.R, p.WT = R, WT
+        p.lds_bytes_per_wave = (lds + 1023) // 1024 * 1024
+        ti = 0
+        for ci, c in enumerate(classes):
+            taps = sorted(c["taps"], key=lambda t: (t[0], t[1], t[2]))
+            k = p.cls[ci]
+            k.tap_begin = ti
+            dds = []
+            for t in taps:
+                if t[0] not in dds:
+                    dds.append(t[0])
+                    k.phase_tap_begin[len(dds) - 1] = ti
+                p.taps[ti].dd, p.taps[ti].dh, p.taps[ti].dw, p.taps[ti].widx = t
+                ti += 1
+            k.tap_end = ti
+            k.n_phase = len(dds)
+            k.phase_tap_begin[len(dds)] = ti
+            k.min_dh, k.max_dh = min(t[1] for t in taps), max(t[1] for t in taps)
+            k.min_dw, k.max_dw = min(t[2] for t in taps), max(t[2] for t in taps)
+            k.out_off_d, k.out_off_h, k.out_off_w = c["off"]
+        if ti > _lib.DRC_MAX_TAPS:
+            raise ValueError("too many taps")
+        self.p = p
+        self.device = x.device
+        self.flops = 2 * x.N * OD * OH * OW * sum(len(c["taps"]) for c in classes) * x.C * cout
+        nvt = -(-(R * WT) // 16)
+        ct = p.cout_pad // 16
+        self.kname = "tapconv_kernel<%d,%d>" % (4 if nvt <= 4 else 7, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1))
+
+    def run(self, x, w, scale, shift, y, res=None):
+        p = self.p
+        p.x, p.y = _base_ptr(x), _base_ptr(y)
+        p.w, p.scale, p.shift = w.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        if res is not None:
+            p.res = _base_ptr(res)
+            p.r_n_stride, p.r_cb_stride, p.r_d_stride, p.r_h_stride = res.n_stride, res.cb_stride, res.d_stride, res.h_stride
+            p.r_off0 = res.interior_off
+        else:
+            p.res = None
+        if TIMING is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        st = _lib.lib().drc_tapconv_fwd(C.byref(p), _stream_ptr(self.device))
+        _lib.check(st, "drc_tapconv_fwd")
+        if TIMING is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            TIMING.append((self.kname, self.flops, e0, e1))
+
+
+def plan_conv3d(x, y, stride, cout, relu):
+    """Conv3d(k3,pad1,stride) on a blocked tensor with halo 1."""
+    assert (x.pd, x.ph, x.pw) == (1, 1, 1)
+    classes = taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
+    return ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu)
+
+
+def plan_deconv3d(x, y, cout, relu):
+    assert (x.pd, x.ph, x.pw) == (1, 1, 1) and (y.D, y.H, y.W) == (2 * x.D, 2 * x.H, 2 * x.W)
+    return ConvPlan(x, y, taps_deconv3d_k3s2(), 1, 2, (x.D, x.H, x.W), cout, relu)
+
+
+def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
+    """Conv2d(k,stride,pad,dilation) on blocked 2D tensors (D=1, pd=0)."""
+    assert x.pd == 0 and x.D == 1
+    classes = taps_conv((1, k, k), (1, dilation, dilation), (0, pad, pad), (0, x.ph, x.pw))
+    return ConvPlan(x, y, classes, stride, 1, (1, y.H, y.W), cout, relu)
+
+
+# ------------------------------------------------------------------------------------------- other ops
+def cost_volume_blocked(left, right, out, lo4, hi4, in_blocked_pad=0):
+    """left/right NCHW (or blocked 2D) -> out: Blocked [N,2C,Dp,Hp,Wp] halo 1."""
+    st = _lib.lib().drc_cost_volume_blocked_fwd(_ptr(left), _ptr(right), _ptr(out.storage), out.N, out.C // 2, out.D, out.H, out.W,
+                                                lo4, hi4, in_blocked_pad, _stream_ptr(out.device))
+    _lib.check(st, "drc_cost_volume_blocked_fwd")
+
+
+def conv3d_cout1(x, w27, res, out):
+    """x Blocked (halo 1) -> out dense [N,D,H,W] (+res)."""
+    st = _lib.lib().drc_conv3d_cout1_fwd(_ptr(x.storage), _ptr(w27), _ptr(res), _ptr(out), x.N, x.cb, x.D, x.H, x.W,
+                                         _stream_ptr(x.device))
+    _lib.check(st, "drc_conv3d_cout1_fwd")
+
+
+def upsample_softargmin(cost, disp, maxdisp, mindisp):
+    N, Dp, Hp, Wp = cost.shape
+    _, H, W = disp.shape
+    st = _lib.lib().drc_upsample_softargmin_fwd(_ptr(cost), _ptr(disp), N, Dp, Hp, Wp, maxdisp - mindisp, H, W, mindisp,
+                                                _stream_ptr(cost.device))
+    _lib.check(st, "drc_upsample_softargmin_fwd")

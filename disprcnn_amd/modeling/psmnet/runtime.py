@@ -1,0 +1,303 @@
+"""Execution of PSMNet on the HIP engine (eval mode: BatchNorm folded into the conv epilogues).
+
+Graph restated from the reference (stackhourglass.py:106-174, submodule.py:106-139) as a flat
+schedule of launches over blocked, zero-haloed tensors.  Workspaces and launch plans are cached
+per input shape; halos are zeroed once at allocation and never written again.
+"""
+import torch
+
+from ... import engine as E
+from .submodule import SPP_BRANCHES, TRUNK_STAGES
+
+
+class _Conv:
+    """Packed weights + folded BN of one conv(+bn) site."""
+
+    def __init__(self, conv, bn, device, transposed=False):
+        w = conv.weight.detach().to(device=device, dtype=torch.float32)
+        self.cout = w.shape[1] if transposed else w.shape[0]
+        self.w = E.pack_weight(w, transposed)
+        cout_pad = self.w.shape[2]
+        if bn is not None:
+            self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
+                                               bn.running_mean.detach().to(device).float(),
+                                               bn.running_var.detach().to(device).float(), bn.eps, cout_pad)
+        else:
+            self.scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
+            self.shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+
+
+class PSMNetRuntime:
+    def __init__(self, model, device):
+        self.model = model
+        self.device = device
+        self._weights_version = None
+        self._w = None
+        self._ws = {}      # workspaces: key -> dict of tensors/plans
+
+    def invalidate(self):
+        self._weights_version = None
+
+    # ------------------------------------------------------------------ weights
+    def _version(self):
+        return tuple(t._version for t in list(self.model.parameters()) + list(self.model.buffers())) + \
+            tuple(t.data_ptr() for t in self.model.parameters())
+
+    def _compile(self):
+        v = self._version()
+        if self._w is not None and v == self._weights_version:
+            return self._w
+        m, dev = self.model, self.device
+        W = {}
+
+        def cb3(name, seq, transposed=False):
+            W[name] = _Conv(seq[0], seq[1], dev, transposed)
+
+        cb3("dres0.0", m.dres0[0]); cb3("dres0.2", m.dres0[2])
+        cb3("dres1.0", m.dres1[0]); cb3("dres1.2", m.dres1[2])
+        for hg in ("dres2", "dres3", "dres4"):
+            h = getattr(m, hg)
+            cb3(hg + ".conv1", h.conv1[0]); cb3(hg + ".conv2", h.conv2); cb3(hg + ".conv3", h.conv3[0])
+            cb3(hg + ".conv4", h.conv4[0]); cb3(hg + ".conv5", h.conv5, True); cb3(hg + ".conv6", h.conv6, True)
+        for c in ("classif1", "classif2", "classif3"):
+            seq = getattr(m, c)
+            cb3(c + ".0", seq[0])
+            W[c + ".2"] = E.pack_weight_cout1(seq[2].weight.detach().to(device=dev, dtype=torch.float32))
+        fe = m.feature_extraction
+        for i in (0, 2, 4):
+            cb3(f"fe.firstconv.{i}", fe.firstconv[i])
+        for name, planes, nblk, stride, dil in TRUNK_STAGES:
+            for b, unit in enumerate(getattr(fe, name)):
+                cb3(f"fe.{name}.{b}.conv1", unit.conv1[0]); cb3(f"fe.{name}.{b}.conv2", unit.conv2)
+                if unit.downsample is not None:
+                    cb3(f"fe.{name}.{b}.down", unit.downsample)
+        for name, _ in SPP_BRANCHES:
+            cb3(f"fe.{name}", getattr(fe, name)[1])
+        cb3("fe.lastconv.0", fe.lastconv[0])
+        W["fe.lastconv.2"] = _Conv(fe.lastconv[2], None, dev)
+        self._w, self._weights_version = W, v
+        return W
+
+    # ------------------------------------------------------------------ 3D regressor
+    def _ws3d(self, N, Dp, Hp, Wp):
+        key = ("3d", N, Dp, Hp, Wp)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev = self.device
+        B = lambda c, d, h, w: E.Blocked(N, c, d, h, w, 1, 1, 1, dev)
+        full = (Dp, Hp, Wp)
+        half = tuple(-(-s // 2) for s in full)
+        quart = tuple(-(-s // 2) for s in half)
+        if tuple(2 * s for s in half) != full or tuple(2 * s for s in quart) != half:
+            raise ValueError(f"cost-volume dims {full} must be divisible by 4 (D,H,W multiples of 16; SURVEY 8)")
+        t = {}
+        t["cost"] = B(64, *full)
+        for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t"):
+            t[n] = B(32, *full)
+        for k in (1, 2, 3):
+            t[f"hg{k}.c1"] = B(64, *half); t[f"hg{k}.pre"] = B(64, *half); t[f"hg{k}.post"] = B(64, *half)
+            t[f"hg{k}.c3"] = B(64, *quart); t[f"hg{k}.c4"] = B(64, *quart)
+        for k in (1, 2, 3):
+            t[f"costk{k}"] = torch.empty(N, *full, dtype=torch.float32, device=dev)
+        p = {}
+        p["dres0.0"] = E.plan_conv3d(t["cost"], t["d0a"], 1, 32, True)
+        p["dres0.2"] = E.plan_conv3d(t["d0a"], t["cost0a"], 1, 32, True)
+        p["dres1.0"] = E.plan_conv3d(t["cost0a"], t["d1a"], 1, 32, True)
+        p["dres1.2"] = E.plan_conv3d(t["d1a"], t["cost0"], 1, 32, False)
+        for k in (1, 2, 3):
+            src = t["cost0"] if k == 1 else t[f"out{k - 1}"]
+            p[f"hg{k}.conv1"] = E.plan_conv3d(src, t[f"hg{k}.c1"], 2, 64, True)
+            p[f"hg{k}.conv2"] = E.plan_conv3d(t[f"hg{k}.c1"], t[f"hg{k}.pre"], 1, 64, True)
+            p[f"hg{k}.conv3"] = E.plan_conv3d(t[f"hg{k}.pre"], t[f"hg{k}.c3"], 2, 64, True)
+            p[f"hg{k}.conv4"] = E.plan_conv3d(t[f"hg{k}.c3"], t[f"hg{k}.c4"], 1, 64, True)
+            p[f"hg{k}.conv5"] = E.plan_deconv3d(t[f"hg{k}.c4"], t[f"hg{k}.post"], 64, True)
+            p[f"hg{k}.conv6"] = E.plan_deconv3d(t[f"hg{k}.post"], t[f"out{k}"], 32, False)
+            p[f"classif{k}.0"] = E.plan_conv3d(t[f"out{k}"], t["cls_t"], 1, 32, True)
+        ws = dict(t=t, p=p, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
+        self._ws[key] = ws
+        return ws
+
+    def _regress(self, ws, W):
+        """dres0..dres4 + classif heads on ws['t']['cost'] -> dense cost3 [N,D',H',W'] (reference :130-144)."""
+        t, p = ws["t"], ws["p"]
+
+        def run(plan, wname, x, y, res=None):
+            c = W[wname]
+            p[plan].run(t[x], c.w, c.scale, c.shift, t[y], t[res] if res else None)
+
+        run("dres0.0", "dres0.0", "cost", "d0a")
+        run("dres0.2", "dres0.2", "d0a", "cost0a")
+        run("dres1.0", "dres1.0", "cost0a", "d1a")
+        run("dres1.2", "dres1.2", "d1a", "cost0", res="cost0a")           # dres1(cost0)+cost0, no relu
+        for k, hg in ((1, "dres2"), (2, "dres3"), (3, "dres4")):
+            src = "cost0" if k == 1 else f"out{k - 1}"
+            postsqu = None if k == 1 else f"hg{k - 1}.post"                 # dres3(.., post1), dres4(.., post2)
+            presqu = f"hg{k}.pre" if k == 1 else "hg1.pre"                  # pre1 reused by dres3 AND dres4 (:136,:139)
+            run(f"hg{k}.conv1", hg + ".conv1", src, f"hg{k}.c1")
+            run(f"hg{k}.conv2", hg + ".conv2", f"hg{k}.c1", f"hg{k}.pre", res=postsqu)   # relu(conv2 + postsqu)
+            run(f"hg{k}.conv3", hg + ".conv3", f"hg{k}.pre", f"hg{k}.c3")
+            run(f"hg{k}.conv4", hg + ".conv4", f"hg{k}.c3", f"hg{k}.c4")
+            run(f"hg{k}.conv5", hg + ".conv5", f"hg{k}.c4", f"hg{k}.post", res=presqu)   # relu(conv5 + presqu|pre)
+            run(f"hg{k}.conv6", hg + ".conv6", f"hg{k}.post", f"out{k}", res="cost0")    # out_k = conv6 + cost0
+        prev = None
+        for k in (1, 2, 3):
+            run(f"classif{k}.0", f"classif{k}.0", f"out{k}", "cls_t")
+            E.conv3d_cout1(t["cls_t"], W[f"classif{k}.2"], prev, t[f"costk{k}"])             # cumulative heads
+            prev = t[f"costk{k}"]
+        return t["costk1"], t["costk2"], t["costk3"]
+
+    def _check_disp(self):
+        mx, mn = self.model.maxdisp, self.model.mindisp
+        if (mx - mn) % 16 != 0 or mx % 4 != 0 or mn % 4 != 0:
+            raise ValueError("maxdisp/mindisp must be multiples of 4 with a range divisible by 16 (SURVEY 8, a1)")
+        return mx, mn
+
+    def forward_features(self, fl, fr, out_hw, training=False):
+        if training:
+            raise NotImplementedError("training-mode (batch-statistics BN + backward) is not built yet on the HIP engine")
+        E.require_gpu(fl, "PSMNet features"); E.require_gpu(fr, "PSMNet features")
+        mx, mn = self._check_disp()
+        N, C, Hp, Wp = fl.shape
+        H, W = out_hw
+        if C != 32:
+            raise ValueError("feature maps must have 32 channels")
+        disp = torch.empty(N, H, W, dtype=torch.float32, device=self.device)
+        if N == 0:
+            return disp            # empty ROI batch (reference: disprcnn3d.py:272-275)
+        Wt = self._compile()
+        ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
+        E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
+        _, _, cost3 = self._regress(ws, Wt)
+        E.upsample_softargmin(cost3, disp, mx, mn)
+        return disp
+
+    # ------------------------------------------------------------------ 2D feature CNN
+    def _ws2d(self, N, H, W):
+        key = ("2d", N, H, W)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        if H % 4 or W % 4 or H // 4 < 56 or W // 4 < 56:
+            raise ValueError("PSMNet needs H,W multiples of 4 and >= 224 (fixed AvgPool2d(56), reference submodule.py:76)")
+        dev = self.device
+        B2 = lambda c, h, w, pad=1: E.Blocked(N, c, 1, h, w, 0, pad, pad, dev)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        t, p = {}, {}
+        t["img"] = B2(3, H, W)
+        t["f0"], t["f1"], t["f2"] = B2(32, H2, W2), B2(32, H2, W2), B2(32, H2, W2)
+        p["fe.firstconv.0"] = E.plan_conv2d(t["img"], t["f0"], 3, 2, 1, 1, 32, True)
+        p["fe.firstconv.2"] = E.plan_conv2d(t["f0"], t["f1"], 3, 1, 1, 1, 32, True)
+        p["fe.firstconv.4"] = E.plan_conv2d(t["f1"], t["f2"], 3, 1, 1, 1, 32, True)
+        t["cat"] = B2(320, H4, W4)
+        sched = []   # (plan key, weight key, x, y, res)
+        cur, cur_c, cur_hw = "f2", 32, (H2, W2)
+        for name, planes, nblk, stride, dil in TRUNK_STAGES:
+            pad = 2 if name in ("layer3", "layer4") else 1      # tensors read by the dilated layer4 carry halo 2
+            for b in range(nblk):
+                s = stride if b == 0 else 1
+                hw = (cur_hw[0] // s, cur_hw[1] // s)
+                u = f"fe.{name}.{b}"
+                mid = u + ".mid"
+                t[mid] = B2(planes, hw[0], hw[1], pad)
+                p[u + ".conv1"] = E.plan_conv2d(t[cur], t[mid], 3, s, 1 if dil == 1 else dil, dil, planes, True)
+                sched.append((u + ".conv1", u + ".conv1", cur, mid, None))
+                res = cur
+                if (u + ".down") in self._w:
+                    t[u + ".sc"] = B2(planes, hw[0], hw[1], pad)
+                    p[u + ".down"] = E.plan_conv2d(t[cur], t[u + ".sc"], 1, s, 0, 1, planes, False)
+                    sched.append((u + ".down", u + ".down", cur, u + ".sc", None))
+                    res = u + ".sc"
+                last = b == nblk - 1
+                if name == "layer2" and last:
+                    t[u + ".out"] = E.BlockedSlice(t["cat"], 0, 64)        # output_raw -> channels 0..63 of the concat
+                elif name == "layer4" and last:
+                    t[u + ".out"] = E.BlockedSlice(t["cat"], 4, 128)       # output_skip -> channels 64..191
+                else:
+                    t[u + ".out"] = B2(planes, hw[0], hw[1], pad)
+                p[u + ".conv2"] = E.plan_conv2d(t[mid], t[u + ".out"], 3, 1, 1 if dil == 1 else dil, dil, planes, False)
+                sched.append((u + ".conv2", u + ".conv2", mid, u + ".out", res))   # out += x, no trailing relu
+                cur, cur_c, cur_hw = u + ".out", planes, hw
+        skip = cur
+        # SPP: concat order (raw, skip, b4, b3, b2, b1) -> channel blocks 0-3, 4-11, 12-13, 14-15, 16-17, 18-19
+        slot = {"branch4": 12, "branch3": 14, "branch2": 16, "branch1": 18}
+        spp = []
+        for name, k in SPP_BRANCHES:
+            oh, ow = H4 // k, W4 // k
+            t[name + ".pool"] = B2(128, oh, ow, 0)
+            t[name + ".conv"] = B2(32, oh, ow, 0)
+            p["fe." + name] = E.plan_conv2d(t[name + ".pool"], t[name + ".conv"], 1, 1, 0, 1, 32, True)
+            spp.append((name, k, oh, ow, slot[name]))
+        t["last0"] = B2(128, H4, W4, 0)
+        t["feat"] = B2(32, H4, W4, 1)
+        p["fe.lastconv.0"] = E.plan_conv2d(t["cat"], t["last0"], 3, 1, 1, 1, 128, True)
+        p["fe.lastconv.2"] = E.plan_conv2d(t["last0"], t["feat"], 1, 1, 0, 1, 32, False)
+        ws = dict(t=t, p=p, sched=sched, spp=spp, skip=skip, dims=(H4, W4),
+                  flops=sum(pl.flops for pl in p.values()))
+        self._ws[key] = ws
+        return ws
+
+    def _features(self, ws, W, images):
+        """feature_extraction on a batch of images (left and right stacked) -> blocked [N,32,H/4,W/4] (halo 1)."""
+        from ... import _lib
+        t, p = ws["t"], ws["p"]
+        lib = _lib.lib()
+        sp = E._stream_ptr(self.device)
+        t["img"].from_dense(images)
+
+        def run(plan, wname, x, y, res=None):
+            c = W[wname]
+            p[plan].run(t[x], c.w, c.scale, c.shift, t[y], t[res] if res else None)
+
+        run("fe.firstconv.0", "fe.firstconv.0", "img", "f0")
+        run("fe.firstconv.2", "fe.firstconv.2", "f0", "f1")
+        run("fe.firstconv.4", "fe.firstconv.4", "f1", "f2")
+        for plan, wname, x, y, res in ws["sched"]:
+            run(plan, wname, x, y, res)
+        skip = t[ws["skip"]]
+        H4, W4 = ws["dims"]
+        cat = t["cat"]
+        for name, k, oh, ow, cb_off in ws["spp"]:
+            pool, conv = t[name + ".pool"], t[name + ".conv"]
+            st = self._avgpool_slice(lib, skip, pool, k, oh, ow, sp)
+            _lib.check(st, "drc_avgpool2d_blocked")
+            run("fe." + name, "fe." + name, name + ".pool", name + ".conv")
+            st = lib.drc_bilinear_up_blocked(E._ptr(conv.storage), E._ptr(cat.storage), cat.N, 2, oh, ow, 0, H4, W4, cat.ph,
+                                             cat.cb, cb_off, sp)
+            _lib.check(st, "drc_bilinear_up_blocked")
+        run("fe.lastconv.0", "fe.lastconv.0", "cat", "last0")
+        run("fe.lastconv.2", "fe.lastconv.2", "last0", "feat")
+        return t["feat"]
+
+    def _avgpool_slice(self, lib, skip, pool, k, oh, ow, sp):
+        """AvgPool2d(k,k) of output_skip, which lives in channel blocks 4..11 of the 20-block concat tensor:
+        pool each image's slice separately (the kernel assumes dense [N][CB] packing of its input)."""
+        base = skip.base
+        st = 0
+        for n in range(base.N):
+            xin = base.storage.data_ptr() + 4 * (n * base.n_stride + skip.cb_off * base.cb_stride)
+            yout = pool.storage.data_ptr() + 4 * (n * pool.n_stride)
+            st = lib.drc_avgpool2d_blocked(xin, yout, 1, skip.cb, base.H, base.W, base.ph, k, oh, ow, 0, sp)
+            if st:
+                return st
+        return st
+
+    def forward_images(self, left, right, training=False):
+        if training:
+            raise NotImplementedError("training-mode (batch-statistics BN + backward) is not built yet on the HIP engine")
+        E.require_gpu(left, "PSMNet input"); E.require_gpu(right, "PSMNet input")
+        mx, mn = self._check_disp()
+        N, _, H, W = left.shape
+        disp = torch.empty(N, H, W, dtype=torch.float32, device=self.device)
+        if N == 0:
+            return disp
+        Wt = self._compile()
+        ws2 = self._ws2d(2 * N, H, W)
+        feat = self._features(ws2, Wt, torch.cat((left, right), 0))
+        ws3 = self._ws3d(N, (mx - mn) // 4, H // 4, W // 4)
+        fv = feat.storage
+        right_view = fv[N * feat.n_stride:]
+        E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
+        _, _, cost3 = self._regress(ws3, Wt)
+        E.upsample_softargmin(cost3, disp, mx, mn)
+        return disp

@@ -1,0 +1,149 @@
+/*
+ * disprcnn_hip.h -- C ABI of libdisprcnn_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the instance-disparity hot path of zju3dv/disprcnn.  The
+ * reference has no FFI of its own for this path on the GPU: its arithmetic is
+ * torch.nn -> cuDNN, plus the pybind11 module disprcnn._C (csrc/vision.cpp:7-15) for
+ * ROIAlign.  Each entry point below names the reference code it replaces.
+ *
+ * Conventions (SURVEY.md 8b "Ownership"/"Errors"):
+ *   - the CALLER allocates every buffer; the library never allocates, frees or syncs;
+ *   - all pointers are device pointers (HBM) unless stated otherwise, fp32;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it;
+ *   - return 0 on success, <0 for a bad argument / unsupported shape,
+ *     >0 = hipError_t from hipGetLastError() after the launch;
+ *   - re-entrant: no global mutable state (callable from autograd worker threads).
+ *
+ * "Blocked" tensors: channel-blocked, zero-haloed layout
+ *     float[N][CB][D+2pd][H+2ph][W+2pw][16],  CB = ceil(C/16)
+ * The halo is written once (zero) by the allocator and never touched by a kernel,
+ * so 3x3x3 taps need no bounds checks and every staged tile row is contiguous.
+ */
+#ifndef DISPRCNN_HIP_H
+#define DISPRCNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRC_MAX_TAPS 64
+#define DRC_MAX_CLASSES 8
+#define DRC_CB 16 /* channels per block */
+
+/* library / build info: returns a static string "disprcnn_hip gfx950 <abi-version>" */
+const char* drc_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * a1. Cost volume, reference layout (NCDHW), bit-exact copy semantics.
+ * Replaces the Python slice-assign loop PSMNet.forward, stackhourglass.py:115-128.
+ *   left,right : [N,C,Hp,Wp]      cost : [N,2C,Dp,Hp,Wp],  Dp = (maxdisp-mindisp)//4 computed by caller
+ *   lo4 = mindisp//4 (floor), hi4 = maxdisp//4 (floor): slices j with lo4+j >= hi4 stay zero.
+ */
+int drc_cost_volume_fwd(const float* left, const float* right, float* cost,
+                        int N, int C, int Dp, int Hp, int Wp, int lo4, int hi4, void* stream);
+
+/* a1 backward: gL[n,c,y,x] = sum_j gcost[n,c,j,y,x]*valid, gR[n,c,y,x'] = sum_j gcost[n,C+c,j,y,x'+i]*valid
+ * (adjoint of the copy; the reference gets it from autograd of stackhourglass.py:118-127). */
+int drc_cost_volume_bwd(const float* gcost, float* gleft, float* gright,
+                        int N, int C, int Dp, int Hp, int Wp, int lo4, int hi4, void* stream);
+
+/* a1, blocked output: same values written as a blocked tensor [N][2C/16][Dp+2][Hp+2][Wp+2][16]
+ * (pads 1,1,1), the input layout of the 3D regressor.  C must be a multiple of 16.
+ * left/right are NCHW (in_blocked=0) or blocked 2D [N][C/16][Hp+2*fp][Wp+2*fp][16] (in_blocked=fp>0). */
+int drc_cost_volume_blocked_fwd(const float* left, const float* right, float* cost_blk,
+                                int N, int C, int Dp, int Hp, int Wp, int lo4, int hi4,
+                                int in_blocked_pad, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Layout converters between the reference layouts and blocked tensors.
+ *   dense  : [N,C,D,H,W] (D=1 for 2D)      blocked : [N][CB][D+2pd][H+2ph][W+2pw][16]
+ * to_blocked writes the interior only (channels C..16*CB-1 are written as zero). */
+int drc_dense_to_blocked(const float* dense, float* blk, int N, int C, int D, int H, int W,
+                         int pd, int ph, int pw, void* stream);
+int drc_blocked_to_dense(const float* blk, float* dense, int N, int C, int D, int H, int W,
+                         int pd, int ph, int pw, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a2-a6, a8, a12.  Tap-list convolution on blocked tensors: one engine for
+ * Conv3d k3 s1/s2 (submodule.py:19-22), ConvTranspose3d k3 s2 p1 op1 as 8 parity classes
+ * (stackhourglass.py:22-30), and Conv2d (submodule.py:13-16; D=1), with the folded-BN scale/shift,
+ * residual add and ReLU of the surrounding nn.Sequential fused into the epilogue.
+ *
+ *   y[n,co,O(o)] = act( scale[co] * sum_t sum_ci w[t][ci][co] * x[n,ci, in_mul*o + tap_t] + shift[co] (+ res[n,co,O(o)]) )
+ *   O(o) = out_mul*o + class offset  (out_mul=2 for the transposed conv's parity classes)
+ *
+ * fp32 in, fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+ */
+typedef struct drc_tap {
+    int32_t dd, dh, dw; /* input offset (in padded-input coordinates) relative to in_mul*o */
+    int32_t widx;       /* index of the [cb_in][Cout][16] weight slab for this tap */
+} drc_tap;
+
+typedef struct drc_tap_class {
+    int32_t tap_begin, tap_end;      /* taps sorted by dd inside a class */
+    int32_t n_phase;                 /* number of distinct dd */
+    int32_t phase_tap_begin[4];      /* tap ranges per distinct dd (phase_tap_begin[n_phase] = tap_end) */
+    int32_t min_dh, max_dh, min_dw, max_dw;
+    int32_t out_off_d, out_off_h, out_off_w; /* parity offsets (0/1) */
+} drc_tap_class;
+
+typedef struct drc_tapconv_params {
+    const float* x;      /* blocked input  */
+    const float* w;      /* packed weights [n_w_slabs][cb_in][cout_pad][16] */
+    const float* scale;  /* [cout_pad] folded BN scale (1 if none) */
+    const float* shift;  /* [cout_pad] folded BN shift (0 if none) */
+    const float* res;    /* optional residual: blocked, same logical shape as y, own strides (may be NULL) */
+    float* y;            /* blocked output */
+    int64_t x_n_stride, x_cb_stride, x_d_stride, x_h_stride; /* floats; voxel stride is 16 */
+    int64_t y_n_stride, y_cb_stride, y_d_stride, y_h_stride; /* floats */
+    int64_t y_off0;      /* float offset of logical output voxel (0,0,0) (skips the halo) */
+    int64_t r_n_stride, r_cb_stride, r_d_stride, r_h_stride; /* residual geometry (floats), used when res != NULL */
+    int64_t r_off0;
+    int32_t N, OD, OH, OW;   /* logical grid iterated by one class */
+    int32_t in_mul, out_mul; /* 1 or 2 */
+    int32_t cb_in;           /* input channel blocks */
+    int32_t cout_pad;        /* multiple of 16 */
+    int32_t R, WT;           /* rows x cols of output handled by one wave (R*WT <= 112) */
+    int32_t relu;
+    int32_t n_classes;
+    int32_t lds_bytes_per_wave; /* >= 2 * staged tile bytes of the largest class */
+    int32_t reserved;
+    drc_tap_class cls[DRC_MAX_CLASSES];
+    drc_tap taps[DRC_MAX_TAPS];
+} drc_tapconv_params;
+
+/* Validates, picks the (voxel-tiles, cout-tiles) instantiation and launches. */
+int drc_tapconv_fwd(const drc_tapconv_params* p, void* stream);
+
+/* Final classifier conv Conv3d(32->1,k3,p1,bias=False) (stackhourglass.py:78-88 `classifN[2]`)
+ * with the cumulative head add (`+ cost_{k-1}`, :142-144) fused.
+ *   x : blocked [N][cb_in][D+2][H+2][W+2][16];  w : [27][cb_in*16];  out,res : dense [N,D,H,W] */
+int drc_conv3d_cout1_fwd(const float* x, const float* w, const float* res, float* out,
+                         int N, int cb_in, int D, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a7. Fused trilinear(align_corners=True) upsample -> softmax over D -> soft-argmin.
+ * Replaces F.interpolate + F.softmax + disparityregression (stackhourglass.py:169-173,
+ * submodule.py:51-57) without materialising the [N,D,H,W] volume.
+ *   cost : dense [N,Dp,Hp,Wp]   disp : [N,H,W]   D = maxdisp-mindisp, d = mindisp..maxdisp-1 */
+int drc_upsample_softargmin_fwd(const float* cost, float* disp, int N, int Dp, int Hp, int Wp,
+                                int D, int H, int W, int mindisp, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Small helpers for the 2D feature CNN (submodule.py:76-139): average pool and bilinear
+ * (align_corners=True) upsample on blocked 2D tensors, channel-offset aware (writes into a
+ * slice of the concatenated 320-channel tensor). */
+int drc_avgpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W, int px,
+                          int k, int OH, int OW, int py, void* stream);
+int drc_bilinear_up_blocked(const float* x, float* y, int N, int CB, int IH, int IW, int px,
+                            int OH, int OW, int py, int y_cb_total, int y_cb_off, void* stream);
+/* copy channel blocks of a blocked tensor into a channel slice of another (same spatial geometry) */
+int drc_copy_blocks(const float* x, float* y, int N, int CB, int64_t vox_per_cb,
+                    int y_cb_total, int y_cb_off, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISPRCNN_HIP_H */

@@ -1,0 +1,206 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the committed golden fixtures.
+
+Tolerances (stated): cost volume bit-exact; single conv layers |err| <= 2e-5*max|ref| + 1e-5
+(fp32 FMA chains in a different summation order); disparities mean <= 1e-3 px, max <= 2e-2 px vs the
+reference fp32 outputs (measured fp32-vs-fp64 floor of the reference itself: mean 9.4e-5 / max 2.0e-3).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import psmnet_oracle as O
+from disprcnn_amd.utils import synth
+from tests.helpers import golden_npz, state_for
+from tests.test_oracle_golden import CV_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _sha(t):
+    return hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def _close(got, ref, rel=2e-5, abs_=1e-5):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    tol = rel * ref.abs().max().item() + abs_
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"max err {err:.3e} > tol {tol:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ a1
+@pytest.mark.parametrize("mx,mn,shp", CV_CASES)
+def test_cost_volume_bit_exact(dev, mx, mn, shp):
+    from disprcnn_amd import ops
+    z = golden_npz("cost_volume.npz")
+    fl, fr = synth.synth_features(*shp, tag=f"cv{mx}_{mn}")
+    c = ops.cost_volume(fl.to(dev), fr.to(dev), mx, mn)
+    assert _sha(c) == str(z[f"cv_{mx}_{mn}_{'x'.join(map(str, shp))}_sha"])
+    assert torch.equal(c.cpu(), O.cost_volume(fl, fr, mx, mn))
+
+
+def test_cost_volume_odd_width_and_empty(dev):
+    from disprcnn_amd import ops
+    fl, fr = synth.synth_features(2, 3, 5, 13, tag="odd")
+    c = ops.cost_volume(fl.to(dev), fr.to(dev), 8, -8)
+    assert torch.equal(c.cpu(), O.cost_volume(fl, fr, 8, -8))
+    e = ops.cost_volume(torch.zeros(0, 32, 28, 28, device=dev), torch.zeros(0, 32, 28, 28, device=dev), 48, 0)
+    assert tuple(e.shape) == (0, 64, 12, 28, 28)
+
+
+def test_cost_volume_blocked_matches_dense(dev):
+    from disprcnn_amd import engine as E
+    fl, fr = synth.synth_features(2, 32, 28, 28, tag="blk")
+    out = E.Blocked(2, 64, 12, 28, 28, 1, 1, 1, dev)
+    E.cost_volume_blocked(fl.to(dev), fr.to(dev), out, -24 // 4, 24 // 4, 0)
+    assert torch.equal(out.to_dense().cpu(), O.cost_volume(fl, fr, 24, -24))
+    v = out.view6()
+    assert v[:, :, 0].abs().sum() == 0 and v[:, :, :, 0].abs().sum() == 0 and v[:, :, :, :, -1].abs().sum() == 0   # halo intact
+
+
+def test_cost_volume_backward_is_adjoint(dev):
+    from disprcnn_amd import ops
+    fl, fr = synth.synth_features(2, 4, 6, 20, tag="adj")
+    g = synth.hash_uniform("adj:g", (2, 8, 6, 6, 20))
+    fl.requires_grad_(True); fr.requires_grad_(True)
+    c = O.cost_volume(fl * 1.0, fr * 1.0, 12, -12)
+    # the oracle's slice assignment is differentiable in torch: autograd gives the reference adjoint
+    (c * g).sum().backward()
+    gl, gr = ops.cost_volume_backward(g.to(dev), 12, -12)
+    _close(gl, fl.grad, 1e-6, 1e-6); _close(gr, fr.grad, 1e-6, 1e-6)
+
+
+def test_layout_roundtrip_full_size(dev):
+    """Size-independent property at BASELINE config-B size: dense -> blocked -> dense is the identity, halo stays 0."""
+    from disprcnn_amd import engine as E
+    x = synth.hash_uniform("rt", (2, 64, 24, 56, 56)).to(dev)
+    b = E.Blocked(2, 64, 24, 56, 56, 1, 1, 1, dev).from_dense(x)
+    assert torch.equal(b.to_dense(), x)
+    assert abs(b.storage.double().sum().item() - x.double().sum().item()) < 1e-6 * x.numel()
+
+
+# ------------------------------------------------------------------------------------------------ a2-a6 layers
+LAYERS = [  # cin, cout, stride, transposed, dims
+    (64, 32, 1, False, (4, 12, 28)), (32, 32, 1, False, (3, 28, 28)), (32, 64, 2, False, (12, 28, 28)),
+    (64, 64, 2, False, (6, 14, 14)), (64, 64, 1, False, (3, 7, 7)), (64, 64, 1, True, (3, 7, 7)),
+    (64, 32, 1, True, (6, 14, 14)), (32, 32, 1, False, (2, 56, 56)), (16, 48, 1, False, (2, 5, 9)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims", LAYERS)
+def test_conv3d_layer_vs_oracle(dev, cin, cout, stride, transposed, dims):
+    from disprcnn_amd import ops
+    n = 2
+    x = synth.hash_uniform(f"L{cin}{cout}{stride}{transposed}:x", (n, cin) + dims)
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = synth.hash_uniform(f"L{cin}{cout}:w", wshape, -0.1, 0.1)
+    scale = synth.hash_uniform("L:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("L:b", (cout,), -0.5, 0.5)
+    if transposed:
+        ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    else:
+        ref = F.conv3d(x, w, None, stride, 1)
+    res = synth.hash_uniform("L:r", tuple(ref.shape))
+    ref = F.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) + res)
+    got = ops.conv3d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, True, res.to(dev), transposed)
+    assert got.shape == ref.shape
+    _close(got, ref)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [(3, 32, 3, 2, 1, 1, (64, 80)), (32, 32, 3, 1, 1, 1, (40, 56)),
+                                                         (32, 64, 1, 2, 0, 1, (40, 56)), (128, 128, 3, 1, 2, 2, (28, 28)),
+                                                         (320, 128, 3, 1, 1, 1, (12, 20)), (128, 32, 1, 1, 0, 1, (3, 3))])
+def test_conv2d_layer_vs_oracle(dev, cin, cout, k, stride, pad, dil, hw):
+    from disprcnn_amd import ops
+    x = synth.hash_uniform(f"C{cin}{cout}{k}:x", (2, cin) + hw)
+    w = synth.hash_uniform(f"C{cin}{cout}{k}:w", (cout, cin, k, k), -0.1, 0.1)
+    scale = synth.hash_uniform("C:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("C:b", (cout,), -0.5, 0.5)
+    ref = F.conv2d(x, w, None, stride, pad, dil) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    got = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, pad, dil, False, None, in_halo=max(pad, 1))
+    assert got.shape == ref.shape
+    _close(got, ref)
+
+
+def test_upsample_softargmin_vs_oracle(dev):
+    from disprcnn_amd import ops
+    for (dp, hp, wp, mx, mn) in [(12, 28, 28, 48, 0), (24, 56, 56, 48, -48), (12, 28, 28, 24, -24)]:
+        cost = synth.hash_uniform(f"sa{dp}{mn}", (2, 1, dp, hp, wp), -3.0, 3.0)
+        ref = O.upsample_softargmin(cost, mx, mn, 4 * hp, 4 * wp)
+        got = ops.upsample_softargmin(cost.to(dev), mx, mn, 4 * hp, 4 * wp).cpu()
+        err = (got - ref).abs()
+        assert err.mean().item() < 1e-4 and err.max().item() < 2e-3, (err.mean().item(), err.max().item())
+
+
+# ------------------------------------------------------------------------------------------------ whole path
+def _model(dev, case, mx, mn):
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    m = PSMNet(mx, mn)
+    m.load_state_dict(state_for(case), strict=True)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("case,mx,mn", [("A", 48, 0), ("At", 48, 0), ("A2", 24, -24)])
+def test_config_a_vs_golden(dev, case, mx, mn):
+    z = golden_npz()
+    m = _model(dev, "At" if case == "At" else "A", mx, mn)
+    fl, fr = synth.synth_features(2, 32, 28, 28, tag="caseA")
+    with torch.no_grad():
+        pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
+    ref = torch.from_numpy(z[f"{case}_pred"])
+    err = (pred - ref).abs()
+    print(case, "mean/max err px", err.mean().item(), err.max().item())
+    assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
+    # intermediates: cost3 of the HIP path vs the oracle (sampled by the golden file too)
+    rt = m._rt
+    ws = rt._ws[("3d", 2, (mx - mn) // 4, 28, 28)]
+    cost3 = ws["t"]["costk3"].cpu().reshape(-1)
+    idx = torch.from_numpy(z[f"{case}_cost3_idx"]); val = torch.from_numpy(z[f"{case}_cost3_val"])
+    assert (cost3[idx] - val).abs().max().item() < 1e-3 * max(1.0, val.abs().max().item())
+    out3 = ws["t"]["out3"].to_dense().cpu().reshape(-1)
+    idx = torch.from_numpy(z[f"{case}_out3_idx"]); val = torch.from_numpy(z[f"{case}_out3_val"])
+    assert (out3[idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4
+
+
+def test_config_b_vs_golden(dev):
+    z = golden_npz()
+    m = _model(dev, "B", 48, -48)
+    left, right = synth.synth_images(2, 224, 224, tag="caseB")
+    with torch.no_grad():
+        pred = m((left.to(dev), right.to(dev))).cpu()
+        pred2 = m({"left": left.to(dev), "right": right.to(dev)}).cpu()
+    assert torch.equal(pred, pred2)                    # dict and tuple inputs, deterministic
+    ref = torch.from_numpy(z["B_pred"])
+    err = (pred - ref).abs()
+    print("B mean/max err px", err.mean().item(), err.max().item())
+    assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
+    feat = m._rt._ws[("2d", 4, 224, 224)]["t"]["feat"].to_dense().cpu()[:, :, 0]
+    flat = feat[:2].reshape(-1)
+    idx = torch.from_numpy(z["B_featL_idx"]); val = torch.from_numpy(z["B_featL_val"])
+    assert (flat[idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4
+
+
+def test_empty_roi_batch(dev):
+    m = _model(dev, "A", 48, 0)
+    out = m.forward_from_features(torch.zeros(0, 32, 28, 28, device=dev), torch.zeros(0, 32, 28, 28, device=dev), (112, 112))
+    assert tuple(out.shape) == (0, 112, 112)
+
+
+def test_batch_independence_large(dev):
+    """Size-independent property at bench batch size: ROI k of a 16-ROI batch equals the same ROI run alone (bitwise:
+    waves never mix ROIs and the FMA order does not depend on N)."""
+    m = _model(dev, "A", 48, 0)
+    fl, fr = synth.synth_features(16, 32, 28, 28, tag="big")
+    with torch.no_grad():
+        full = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
+        one = m.forward_from_features(fl[5:6].to(dev), fr[5:6].to(dev), (112, 112)).cpu()
+    assert torch.equal(full[5:6], one)
+    assert torch.isfinite(full).all() and full.min() >= 0 and full.max() <= 47

@@ -1,0 +1,93 @@
+"""CPU-only checks: C-ABI library loads and exports every declared symbol, state-dict layout, host-side planning."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    from disprcnn_amd import _lib
+    from disprcnn_amd.csrc import build
+    build.build(verbose=False)
+    header = open(os.path.join(ROOT, "include", "disprcnn_hip.h")).read()
+    declared = set(re.findall(r"\b(drc_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/disprcnn_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert b"gfx950" in _lib.lib().drc_version()
+
+
+def test_params_struct_matches_header_size():
+    """sizeof(drc_tapconv_params) computed by gcc must equal the ctypes mirror."""
+    import subprocess, tempfile
+    from disprcnn_amd import _lib
+    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(drc_tap));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        a, b, t = map(int, subprocess.check_output([exe]).split())
+    assert a == ctypes.sizeof(_lib.DrcTapconvParams)
+    assert b == ctypes.sizeof(_lib.DrcTapClass) and t == ctypes.sizeof(_lib.DrcTap)
+
+
+def test_state_dict_layout():
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    sd = PSMNet(48, -48).state_dict()
+    assert len(sd) == 514
+    assert sum(v.numel() for v in sd.values()) == 5236053
+    assert tuple(sd["dres0.0.0.weight"].shape) == (32, 64, 3, 3, 3)
+    assert tuple(sd["dres2.conv5.0.weight"].shape) == (64, 64, 3, 3, 3)
+    assert tuple(sd["dres2.conv6.0.weight"].shape) == (64, 32, 3, 3, 3)
+    assert tuple(sd["classif1.2.weight"].shape) == (1, 32, 3, 3, 3)
+    assert sum(1 for k in sd if k.startswith("feature_extraction")) == 361
+    n_params = sum(p.numel() for p in PSMNet(48, -48).parameters())
+    assert n_params == 5224768
+
+
+def test_no_cpu_fallback():
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    m = PSMNet(48, 0).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.forward_from_features(torch.zeros(1, 32, 28, 28), torch.zeros(1, 32, 28, 28), (112, 112))
+
+
+def test_pack_weight_layout():
+    from disprcnn_amd import engine as E
+    w = torch.arange(2 * 3 * 27, dtype=torch.float32).view(2, 3, 3, 3, 3)
+    p = E.pack_weight(w)
+    assert tuple(p.shape) == (27, 1, 16, 16)
+    for t in (0, 13, 26):
+        for co in range(2):
+            for ci in range(3):
+                assert p[t, 0, co, ci] == w[co, ci].reshape(-1)[t]
+    assert p[:, :, 2:, :].abs().sum() == 0 and p[:, :, :, 3:].abs().sum() == 0
+    wt = torch.arange(3 * 2 * 27, dtype=torch.float32).view(3, 2, 3, 3, 3)     # ConvTranspose: [Cin,Cout,...]
+    pt = E.pack_weight(wt, transposed=True)
+    assert pt[5, 0, 1, 2] == wt[2, 1].reshape(-1)[5]
+
+
+def test_deconv_parity_classes_cover_all_taps():
+    from disprcnn_amd import engine as E
+    cls = E.taps_deconv3d_k3s2()
+    assert len(cls) == 8
+    widx = sorted(t[3] for c in cls for t in c["taps"])
+    assert widx == list(range(27))
+    assert sorted(len(c["taps"]) for c in cls) == [1, 2, 2, 2, 4, 4, 4, 8]
+
+
+@pytest.mark.parametrize("shape", [(28, 28, 1, 2, 2), (56, 56, 1, 2, 2), (14, 14, 2, 2, 2), (7, 7, 1, 1, 1), (112, 112, 2, 2, 2),
+                                   (112, 112, 1, 2, 2), (56, 56, 1, 4, 4), (375, 1242, 2, 6, 6)])
+def test_tile_choice_fits_lds(shape):
+    from disprcnn_amd import engine as E
+    OH, OW, im, sh, sw = shape
+    R, WT, lds = E.choose_tile(OH, OW, im, sh, sw)
+    assert R * WT <= 112 and lds <= E.LDS_PER_WAVE_MAX
+    assert lds == 2 * (im * (R - 1) + sh + 1) * (im * (WT - 1) + sw + 1) * 64
