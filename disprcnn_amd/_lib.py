@@ -8,21 +8,19 @@ reference turns ``AT_ASSERTM``/``THCudaCheck`` failures into Python errors
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE the .so: both must share torch's libamdhip64 runtime
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdisprcnn_hip.so")
 
-DRC_MAX_TAPS = 64
 DRC_MAX_CLASSES = 8
 
 
-class DrcTap(C.Structure):
-    _fields_ = [("dd", C.c_int32), ("dh", C.c_int32), ("dw", C.c_int32), ("widx", C.c_int32)]
-
-
 class DrcTapClass(C.Structure):
-    _fields_ = [("tap_begin", C.c_int32), ("tap_end", C.c_int32), ("n_phase", C.c_int32),
-                ("phase_tap_begin", C.c_int32 * 4),
-                ("min_dh", C.c_int32), ("max_dh", C.c_int32), ("min_dw", C.c_int32), ("max_dw", C.c_int32),
+    _fields_ = [("nd", C.c_int32), ("nh", C.c_int32), ("nw", C.c_int32),
+                ("dd0", C.c_int32), ("dh0", C.c_int32), ("dw0", C.c_int32),
+                ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+                ("wbase", C.c_int32), ("wsd", C.c_int32), ("wsh", C.c_int32), ("wsw", C.c_int32),
                 ("out_off_d", C.c_int32), ("out_off_h", C.c_int32), ("out_off_w", C.c_int32)]
 
 
@@ -38,7 +36,7 @@ class DrcTapconvParams(C.Structure):
                 ("in_mul", C.c_int32), ("out_mul", C.c_int32), ("cb_in", C.c_int32), ("cout_pad", C.c_int32),
                 ("R", C.c_int32), ("WT", C.c_int32), ("relu", C.c_int32), ("n_classes", C.c_int32),
                 ("lds_bytes_per_wave", C.c_int32), ("reserved", C.c_int32),
-                ("cls", DrcTapClass * DRC_MAX_CLASSES), ("taps", DrcTap * DRC_MAX_TAPS)]
+                ("cls", DrcTapClass * DRC_MAX_CLASSES)]
 
 
 _P = C.c_void_p

@@ -1,4 +1,4 @@
-// tapconv.hip -- tap-list convolution on channel-blocked, zero-haloed tensors (gfx950 / CDNA4).
+// tapconv.hip -- tap-grid convolution on channel-blocked, zero-haloed tensors (gfx950 / CDNA4).
 //
 // One engine for every dense convolution of the instance-disparity path:
 //   Conv3d k3 s1/s2 + BN3d (+ReLU, +residual)         reference: submodule.py:19-22, stackhourglass.py:63-88
@@ -10,13 +10,13 @@
 //       A = weights  [16 cout  x 4 cin]   lane l: cout = l&15, cin quad member k = l>>4
 //       B = voxels   [4 cin    x 16 vox]  lane l: voxel slot = l&15, k = l>>4
 //       D[cout][voxel]: lane l holds couts 4*(l>>4)..+3 of voxel l&15  -> one float4 store per tile
-//   * a WAVE owns a group of R output rows x WT columns (<= VT*16 voxel slots) of one (n, od) slice and
-//     ALL (CT*16) output channels of its cout chunk: VT*CT accumulators of 4 VGPRs.
-//   * per phase (one depth offset dd, one 16-channel input block) the wave stages the input rows it needs
-//     into ITS OWN LDS region with global_load_lds_dwordx4 (no VGPR round trip, no block barrier: waves are
-//     independent), double-buffered; the 3x3 (kh,kw) taps of the phase are LDS address offsets.
-//   * weights stream from L2/L1 straight into VGPRs (shared by the 4 waves of a block through L1),
-//     prefetched one tap ahead.
+//   * a WAVE owns a group of R output rows x WT columns (VT*16 voxel slots) of one (n, od) slice and
+//     CT*16 output channels: VT*CT accumulators of 4 registers.
+//   * per phase (one depth offset, one 16-channel input block) the wave stages the input rows it needs into
+//     ITS OWN LDS region with global_load_lds_dwordx4 (no VGPR round trip, no block barrier: waves are
+//     independent), double-buffered; the (kh,kw) taps of the phase are LDS address offsets.
+//   * weights stream from L2/L1 straight into VGPRs (the 4 waves of a block share them through L1);
+//     weights and B fragments are register double-buffered one tap ahead (A/B sets, no runtime indexing).
 //   * epilogue: folded-BN scale/shift, residual add, ReLU, coalesced float4 stores (16 voxels x 64 B).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,10 +35,10 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int j = lane & 15;  // voxel slot within a tile / cout within a tile (A operand)
+    const int j = lane & 15;  // voxel slot within a tile (B operand) / cout within a tile (A operand)
     const int g = lane >> 4;  // k member
 
-    const drc_tap_class& cls = p.cls[blockIdx.z];
+    const drc_tap_class cls = p.cls[blockIdx.z];
     const int n_wt = (p.OW + p.WT - 1) / p.WT;
     const int n_rt = (p.OH + p.R - 1) / p.R;
     const int groups = p.N * p.OD * n_rt * n_wt;
@@ -51,44 +51,32 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
     const int oh0 = rt * p.R, ow0 = wt * p.WT;
     const int ct0 = blockIdx.y * CT;
 
-    const int rows_in = p.in_mul * (p.R - 1) + (cls.max_dh - cls.min_dh) + 1;
-    const int seg_vox = p.in_mul * (p.WT - 1) + (cls.max_dw - cls.min_dw) + 1;
+    const int rows_in = p.in_mul * (p.R - 1) + (cls.nh - 1) * cls.sh + 1;
+    const int seg_vox = p.in_mul * (p.WT - 1) + (cls.nw - 1) * cls.sw + 1;
     const int seg_floats = seg_vox * 16;
     const int buf_floats = rows_in * seg_floats;
     float* lds = lds_all + wave * (p.lds_bytes_per_wave >> 2);
-
-    // per-lane B-operand offsets (floats, inside a staged tile) and output offsets
     const int nslots = p.R * p.WT;
-    const int nvt = (nslots + 15) >> 4;
+
+    // per-lane B-operand offsets (floats) inside a staged tile
     int lane_off[VT];
-    int64_t yoff[VT], roff[VT];
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) {
         const int s = vt * 16 + j;
         int r = s / p.WT, c = s - r * p.WT;
-        const bool valid = (s < nslots) && (oh0 + r < p.OH) && (ow0 + c < p.OW);
-        if (!valid) { r = 0; c = 0; }
+        if (s >= nslots) { r = 0; c = 0; }
         lane_off[vt] = (p.in_mul * r * seg_vox + p.in_mul * c) * 16 + g * 4;
-        yoff[vt] = valid ? (p.y_off0 + (int64_t)n * p.y_n_stride +
-                            (int64_t)(od * p.out_mul + cls.out_off_d) * p.y_d_stride +
-                            (int64_t)((oh0 + r) * p.out_mul + cls.out_off_h) * p.y_h_stride +
-                            (int64_t)((ow0 + c) * p.out_mul + cls.out_off_w) * 16 + g * 4)
-                         : (int64_t)-1;
-        roff[vt] = p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)(od * p.out_mul + cls.out_off_d) * p.r_d_stride +
-                   (int64_t)((oh0 + r) * p.out_mul + cls.out_off_h) * p.r_h_stride +
-                   (int64_t)((ow0 + c) * p.out_mul + cls.out_off_w) * 16 + g * 4;
     }
 
-    const float* xbase = p.x + (int64_t)n * p.x_n_stride + (int64_t)(p.in_mul * oh0 + cls.min_dh) * p.x_h_stride +
-                         (int64_t)(p.in_mul * ow0 + cls.min_dw) * 16;
-    const int n_ph = cls.n_phase * p.cb_in;
+    const float* xbase = p.x + (int64_t)n * p.x_n_stride + (int64_t)(p.in_mul * oh0 + cls.dh0) * p.x_h_stride +
+                         (int64_t)(p.in_mul * ow0 + cls.dw0) * 16;
+    const int nt = cls.nh * cls.nw;        // taps per phase
+    const int n_ph = cls.nd * p.cb_in;     // phases: depth tap (outer) x input channel block (inner)
 
-    // stage phase `ph` (depth offset index ph / cb_in, channel block ph % cb_in) into LDS buffer `b`
-    auto stage = [&](int ph, int b) {
+    auto stage = [&](int ph) {
         const int di = ph / p.cb_in, cb = ph - di * p.cb_in;
-        const int dd = p.taps[cls.phase_tap_begin[di]].dd;
-        const float* src = xbase + (int64_t)cb * p.x_cb_stride + (int64_t)(p.in_mul * od + dd) * p.x_d_stride;
-        float* dst = lds + b * buf_floats;
+        const float* src = xbase + (int64_t)cb * p.x_cb_stride + (int64_t)(p.in_mul * od + cls.dd0 + di * cls.sd) * p.x_d_stride;
+        float* dst = lds + (ph & 1) * buf_floats;
         for (int r = 0; r < rows_in; ++r) {
             const float* srow = src + (int64_t)r * p.x_h_stride;
             float* drow = dst + r * seg_floats;
@@ -106,77 +94,109 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weight pointer of (tap t, channel block cb): slab [cb_in][cout_pad][16]
+    // weight fragment address: slab [widx][cb][cout_pad][16]
     const float* wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 16 + g * 4;
     const int64_t w_cb_stride = (int64_t)p.cout_pad * 16;
     const int64_t w_tap_stride = w_cb_stride * p.cb_in;
 
-    stage(0, 0);
-    f32x4 wcur[CT], wnext[CT];
+    // "next step" cursor, advanced incrementally (no divisions in the loop): phase (di,cb), tap (tb,tc)
+    int n_di = 0, n_cb = 0, n_tb = 0, n_tc = 0;
+    auto next_wptr = [&]() -> const float* {
+        const int widx = cls.wbase + n_di * cls.wsd + n_tb * cls.wsh + n_tc * cls.wsw;
+        return wlane + (int64_t)widx * w_tap_stride + (int64_t)n_cb * w_cb_stride;
+    };
+    auto next_tap_off = [&]() -> int { return (n_tb * cls.sh * seg_vox + n_tc * cls.sw) * 16; };
+    auto advance = [&]() {   // move the cursor one tap step forward (wraps into the next phase; saturates at the end)
+        if (++n_tc == cls.nw) {
+            n_tc = 0;
+            if (++n_tb == cls.nh) {
+                n_tb = 0;
+                if (++n_cb == p.cb_in) { n_cb = 0; ++n_di; }
+            }
+        }
+    };
+
+    f32x4 wA[CT], wB[CT], bA[VT], bB[VT];
+    stage(0);
     {
-        const float* wp = wlane + (int64_t)p.taps[cls.tap_begin].widx * w_tap_stride;
+        const float* wp = next_wptr();
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) wcur[ct] = *(const f32x4*)(wp + ct * 256);
+        for (int ct = 0; ct < CT; ++ct) wA[ct] = *(const f32x4*)(wp + ct * 256);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    for (int ph = 0; ph < n_ph; ++ph) {
-        const int di = ph / p.cb_in, cb = ph - di * p.cb_in;
-        const int tb = cls.phase_tap_begin[di], te = cls.phase_tap_begin[di + 1];
-        const float* buf = lds + (ph & 1) * buf_floats;
-        const int t_stage = (te - 2 > tb) ? te - 2 : tb;
-        for (int t = tb; t < te; ++t) {
-            if (t == t_stage && ph + 1 < n_ph) stage(ph + 1, (ph + 1) & 1);
-            // prefetch the next step's weights (next tap of this phase, or first tap of the next phase)
-            {
-                int tn = t + 1, phn = ph;
-                if (tn == te) { phn = ph + 1; }
-                if (phn < n_ph) {
-                    const int din = phn / p.cb_in, cbn = phn - din * p.cb_in;
-                    if (tn == te) tn = cls.phase_tap_begin[din];
-                    const float* wp = wlane + (int64_t)p.taps[tn].widx * w_tap_stride + (int64_t)cbn * w_cb_stride;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) wnext[ct] = *(const f32x4*)(wp + ct * 256);
-                }
-            }
-            const drc_tap tp = p.taps[t];
-            const int tap_off = ((tp.dh - cls.min_dh) * seg_vox + (tp.dw - cls.min_dw)) * 16;
-            f32x4 bf[VT];
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt)
-                if (vt < nvt) bf[vt] = *(const f32x4*)(buf + lane_off[vt] + tap_off);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int vt = 0; vt < VT; ++vt)
-                    if (vt < nvt)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[ct][kk], bf[vt][kk], acc[vt][ct], 0, 0, 0);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wcur[ct] = wnext[ct];
-        }
-        // the next phase's tile (issued >= one tap ago) and the prefetched weights must have landed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        (void)cb;
+    const int t_stage = nt >= 2 ? nt - 2 : 0;
+
+#define DRC_MFMA_BLOCK(KK, W_USE, B_USE)                                                               \
+    _Pragma("unroll") for (int vt = 0; vt < VT; ++vt)                                                  \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
+            acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[ct][KK], B_USE[vt][KK], acc[vt][ct], 0, 0, 0);
+
+// One tap step.  Every prefetch (next LDS tile via LDS-DMA, next weights, next B fragments) is issued AFTER the first
+// MFMA block and is therefore >= 3/4 of a step old when the next step's first MFMA waits for it: the waits hipcc
+// places (conservatively vmcnt(0)/lgkmcnt(0)) never see a young load.
+#define DRC_STEP(T, W_USE, B_USE, W_LD, B_LD)                                                          \
+    {                                                                                                  \
+        DRC_MFMA_BLOCK(0, W_USE, B_USE)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if ((T) == t_stage && ph + 1 < n_ph) stage(ph + 1);                                            \
+        advance();                                                                                     \
+        const bool in_phase_ = (T) + 1 < nt;                                                           \
+        const float* wp_ = next_wptr();                                                                \
+        if (n_di < cls.nd) {                                                                           \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) W_LD[ct] = *(const f32x4*)(wp_ + ct * 256); \
+        }                                                                                              \
+        const int to_ = in_phase_ ? next_tap_off() : 0;                                                \
+        _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x4*)(buf + lane_off[vt] + to_); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        DRC_MFMA_BLOCK(1, W_USE, B_USE)                                                                \
+        DRC_MFMA_BLOCK(2, W_USE, B_USE)                                                                \
+        DRC_MFMA_BLOCK(3, W_USE, B_USE)                                                                \
     }
+
+    for (int ph = 0; ph < n_ph; ++ph) {
+        const float* buf = lds + (ph & 1) * buf_floats;
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x4*)(buf + lane_off[vt]);   // tap 0 of this phase
+        int t = 0;
+        for (; t + 1 < nt; t += 2) {
+            DRC_STEP(t, wA, bA, wB, bB);
+            DRC_STEP(t + 1, wB, bB, wA, bA);
+        }
+        if (t < nt) {
+            DRC_STEP(t, wA, bA, wB, bB);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wA[ct] = wB[ct];
+        }
+        // the next phase's tile (issued >= 3/4 of a tap step ago) must have landed before it is read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef DRC_STEP
+#undef DRC_MFMA_BLOCK
 
     // epilogue: folded BN, residual, ReLU, store
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const f32x4 sc = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
-        const f32x4 sh = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
+    for (int vt = 0; vt < VT; ++vt) {
+        const int s = vt * 16 + j;
+        const int r = s / p.WT, c = s - r * p.WT;
+        const bool valid = (s < nslots) && (oh0 + r < p.OH) && (ow0 + c < p.OW);
+        if (!valid) continue;
+        const int zd = od * p.out_mul + cls.out_off_d, zh = (oh0 + r) * p.out_mul + cls.out_off_h,
+                  zw = (ow0 + c) * p.out_mul + cls.out_off_w;
+        const int64_t yo = p.y_off0 + (int64_t)n * p.y_n_stride + (int64_t)zd * p.y_d_stride + (int64_t)zh * p.y_h_stride +
+                           (int64_t)zw * 16 + g * 4;
+        const int64_t ro = p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)zd * p.r_d_stride + (int64_t)zh * p.r_h_stride +
+                           (int64_t)zw * 16 + g * 4;
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt) {
-            if (vt < nvt && yoff[vt] >= 0) {
-                const int64_t o = yoff[vt] + (int64_t)(ct0 + ct) * p.y_cb_stride;
-                f32x4 v = acc[vt][ct] * sc + sh;
-                if (p.res) v += *(const f32x4*)(p.res + roff[vt] + (int64_t)(ct0 + ct) * p.r_cb_stride);
-                if (p.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *(f32x4*)(p.y + o) = v;
+        for (int ct = 0; ct < CT; ++ct) {
+            const f32x4 sc = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
+            const f32x4 sh = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
+            f32x4 v = acc[vt][ct] * sc + sh;
+            if (p.res) v += *(const f32x4*)(p.res + ro + (int64_t)(ct0 + ct) * p.r_cb_stride);
+            if (p.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
+            *(f32x4*)(p.y + yo + (int64_t)(ct0 + ct) * p.y_cb_stride) = v;
         }
     }
 }
@@ -188,7 +208,6 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     const long groups = (long)p.N * p.OD * n_rt * n_wt;
     dim3 grid((unsigned)((groups + 3) / 4), (unsigned)(p.cout_pad / 16 / CT), (unsigned)p.n_classes);
     const size_t lds = (size_t)p.lds_bytes_per_wave * 4;
-    if (lds > 160 * 1024) return -5;
     static bool attr_done = false;  // idempotent attribute set; benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)tapconv_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -196,6 +215,20 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     }
     hipLaunchKernelGGL((tapconv_kernel<VT, CT>), grid, dim3(256), lds, stream, p);
     return (int)hipGetLastError();
+}
+
+template <int CT>
+int launch_vt(int nvt, const drc_tapconv_params& p, hipStream_t s) {
+    switch (nvt) {
+        case 1: return launch<1, CT>(p, s);
+        case 2: return launch<2, CT>(p, s);
+        case 3: return launch<3, CT>(p, s);
+        case 4: return launch<4, CT>(p, s);
+        case 5: return launch<5, CT>(p, s);
+        case 6: return launch<6, CT>(p, s);
+        case 7: return launch<7, CT>(p, s);
+    }
+    return -3;
 }
 
 }  // namespace
@@ -213,19 +246,18 @@ extern "C" int drc_tapconv_fwd(const drc_tapconv_params* pp, void* stream) {
     int need = 0;
     for (int c = 0; c < p.n_classes; ++c) {
         const drc_tap_class& k = p.cls[c];
-        if (k.tap_begin < 0 || k.tap_end > DRC_MAX_TAPS || k.tap_end <= k.tap_begin) return -4;
-        if (k.n_phase < 1 || k.n_phase > 3) return -4;
-        const int rows_in = p.in_mul * (p.R - 1) + (k.max_dh - k.min_dh) + 1;
-        const int seg_vox = p.in_mul * (p.WT - 1) + (k.max_dw - k.min_dw) + 1;
+        if (k.nd < 1 || k.nh < 1 || k.nw < 1 || k.sd < 0 || k.sh < 0 || k.sw < 0) return -4;
+        if (k.dd0 < 0 || k.dh0 < 0 || k.dw0 < 0) return -4;
+        const int rows_in = p.in_mul * (p.R - 1) + (k.nh - 1) * k.sh + 1;
+        const int seg_vox = p.in_mul * (p.WT - 1) + (k.nw - 1) * k.sw + 1;
         const int bytes = rows_in * seg_vox * 64 * 2;
         if (bytes > need) need = bytes;
     }
-    if (p.lds_bytes_per_wave < need || (p.lds_bytes_per_wave & 15)) return -5;
+    if (p.lds_bytes_per_wave < need || (p.lds_bytes_per_wave & 15) || (size_t)p.lds_bytes_per_wave * 4 > 160 * 1024) return -5;
     hipStream_t s = (hipStream_t)stream;
     const int ct = p.cout_pad / 16;
     const int nvt = (p.R * p.WT + 15) / 16;
-    // instantiations: voxel tiles per wave {4,7} x cout tiles per wave {1,2,4}
-    if (ct % 4 == 0) return nvt <= 4 ? launch<4, 4>(p, s) : launch<7, 4>(p, s);
-    if (ct % 2 == 0) return nvt <= 4 ? launch<4, 2>(p, s) : launch<7, 2>(p, s);
-    return nvt <= 4 ? launch<4, 1>(p, s) : launch<7, 1>(p, s);
+    if (ct % 4 == 0) return launch_vt<4>(nvt, p, s);
+    if (ct % 2 == 0) return launch_vt<2>(nvt, p, s);
+    return launch_vt<1>(nvt, p, s);
 }

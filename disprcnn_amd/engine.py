@@ -133,38 +133,42 @@ def fold_bn(gamma, beta, mean, var, eps=1e-5, cout_pad=None):
     return scale.contiguous().float(), shift.contiguous().float()
 
 
-# ------------------------------------------------------------------------------------------- tap lists
+# ------------------------------------------------------------------------------------------- tap grids
 def taps_conv(kdims, dilation, pad_conv, pad_in):
-    """Cross-correlation taps for a (kd,kh,kw) kernel: offset = k*dil - pad_conv + pad_in (padded input coords)."""
+    """Cross-correlation tap grid of a (kd,kh,kw) kernel: offset = k*dil - pad_conv + pad_in (padded input coords)."""
     kd, kh, kw = kdims
-    taps = []
-    for a in range(kd):
-        for b in range(kh):
-            for c in range(kw):
-                dd = a * dilation[0] - pad_conv[0] + pad_in[0]
-                dh = b * dilation[1] - pad_conv[1] + pad_in[1]
-                dw = c * dilation[2] - pad_conv[2] + pad_in[2]
-                if min(dd, dh, dw) < 0:
-                    raise ValueError("input halo too small for this convolution")
-                taps.append((dd, dh, dw, (a * kh + b) * kw + c))
-    return [dict(taps=taps, off=(0, 0, 0))]
+    first = tuple(pad_in[i] - pad_conv[i] for i in range(3))
+    if min(first) < 0:
+        raise ValueError("input halo too small for this convolution")
+    return [dict(n=(kd, kh, kw), first=first, step=tuple(dilation), wbase=0, wstep=(kh * kw, kw, 1), off=(0, 0, 0))]
 
 
 def taps_deconv3d_k3s2(pad_in=(1, 1, 1)):
     """ConvTranspose3d(k3,s2,p1,op1) as 8 output-parity classes (stackhourglass.py:22-30).
-    o = 2i - 1 + k  =>  even o=2j: (i=j,k=1);  odd o=2j+1: (i=j,k=2), (i=j+1,k=0)."""
-    per = {0: [(0, 1)], 1: [(0, 2), (1, 0)]}
+    o = 2i - 1 + k  =>  even o=2j: (i=j,k=1);  odd o=2j+1: (i=j,k=2), (i=j+1,k=0):
+    per dim an even class has one tap (offset 0, k=1), an odd class two taps (offsets 0,1 with k=2,0)."""
     classes = []
+    kstride = (9, 3, 1)
     for pd_ in (0, 1):
         for ph_ in (0, 1):
             for pw_ in (0, 1):
-                taps = []
-                for (od_, kd) in per[pd_]:
-                    for (oh_, kh) in per[ph_]:
-                        for (ow_, kw) in per[pw_]:
-                            taps.append((od_ + pad_in[0], oh_ + pad_in[1], ow_ + pad_in[2], (kd * 3 + kh) * 3 + kw))
-                classes.append(dict(taps=taps, off=(pd_, ph_, pw_)))
+                par = (pd_, ph_, pw_)
+                n = tuple(2 if q else 1 for q in par)
+                wbase = sum((2 if q else 1) * ks for q, ks in zip(par, kstride))
+                wstep = tuple(-2 * ks if q else 0 for q, ks in zip(par, kstride))
+                classes.append(dict(n=n, first=tuple(pad_in), step=(1, 1, 1), wbase=wbase, wstep=wstep, off=par))
     return classes
+
+
+def class_taps(c):
+    """Enumerate (dd, dh, dw, widx) of a tap-grid class (host-side mirror of the kernel's arithmetic)."""
+    out = []
+    for a in range(c["n"][0]):
+        for b in range(c["n"][1]):
+            for d in range(c["n"][2]):
+                out.append((c["first"][0] + a * c["step"][0], c["first"][1] + b * c["step"][1], c["first"][2] + d * c["step"][2],
+                            c["wbase"] + a * c["wstep"][0] + b * c["wstep"][1] + d * c["wstep"][2]))
+    return out
 
 
 def choose_tile(OH, OW, in_mul, span_h, span_w):
@@ -180,13 +184,12 @@ def choose_tile(OH, OW, in_mul, span_h, span_w):
                 continue
             n_rt, n_wt = -(-OH // r), -(-OW // wt)
             nvt = -(-(r * wt) // 16)
-            vt_cap = 4 if nvt <= 4 else 7   # instantiations <4,*> and <7,*>: MFMAs issued per group = nvt*16 slots
             useful = OH * OW
             issued = n_rt * n_wt * nvt * 16
             eff = useful / issued
             key = (round(eff, 4), r * wt, -lds)
             if best is None or key > best[0]:
-                best = (key, r, wt, lds, vt_cap)
+                best = (key, r, wt, lds)
     if best is None:
         raise ValueError("no tile fits the LDS budget")
     return best[1], best[2], best[3]
@@ -207,37 +210,26 @@ class ConvPlan:
         p.cout_pad = (cout + CB - 1) // CB * CB
         p.relu = int(relu)
         p.n_classes = len(classes)
-        span_h = max(max(t[1] for t in c["taps"]) - min(t[1] for t in c["taps"]) for c in classes)
-        span_w = max(max(t[2] for t in c["taps"]) - min(t[2] for t in c["taps"]) for c in classes)
+        span_h = max((c["n"][1] - 1) * c["step"][1] for c in classes)
+        span_w = max((c["n"][2] - 1) * c["step"][2] for c in classes)
         R, WT, lds = choose_tile(OH, OW, in_mul, span_h, span_w)
         p.R, p.WT = R, WT
         p.lds_bytes_per_wave = (lds + 1023) // 1024 * 1024
-        ti = 0
         for ci, c in enumerate(classes):
-            taps = sorted(c["taps"], key=lambda t: (t[0], t[1], t[2]))
             k = p.cls[ci]
-            k.tap_begin = ti
-            dds = []
-            for t in taps:
-                if t[0] not in dds:
-                    dds.append(t[0])
-                    k.phase_tap_begin[len(dds) - 1] = ti
-                p.taps[ti].dd, p.taps[ti].dh, p.taps[ti].dw, p.taps[ti].widx = t
-                ti += 1
-            k.tap_end = ti
-            k.n_phase = len(dds)
-            k.phase_tap_begin[len(dds)] = ti
-            k.min_dh, k.max_dh = min(t[1] for t in taps), max(t[1] for t in taps)
-            k.min_dw, k.max_dw = min(t[2] for t in taps), max(t[2] for t in taps)
+            k.nd, k.nh, k.nw = c["n"]
+            k.dd0, k.dh0, k.dw0 = c["first"]
+            k.sd, k.sh, k.sw = c["step"]
+            k.wbase = c["wbase"]
+            k.wsd, k.wsh, k.wsw = c["wstep"]
             k.out_off_d, k.out_off_h, k.out_off_w = c["off"]
-        if ti > _lib.DRC_MAX_TAPS:
-            raise ValueError("too many taps")
         self.p = p
         self.device = x.device
-        self.flops = 2 * x.N * OD * OH * OW * sum(len(c["taps"]) for c in classes) * x.C * cout
+        ntaps = sum(c["n"][0] * c["n"][1] * c["n"][2] for c in classes)
+        self.flops = 2 * x.N * OD * OH * OW * ntaps * x.C * cout       # algorithmic (unpadded channels, valid voxels)
         nvt = -(-(R * WT) // 16)
         ct = p.cout_pad // 16
-        self.kname = "tapconv_kernel<%d,%d>" % (4 if nvt <= 4 else 7, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1))
+        self.kname = "tapconv_kernel<%d,%d>" % (nvt, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1))
 
     def run(self, x, w, scale, shift, y, res=None):
         p = self.p

@@ -28,7 +28,6 @@
 extern "C" {
 #endif
 
-#define DRC_MAX_TAPS 64
 #define DRC_MAX_CLASSES 8
 #define DRC_CB 16 /* channels per block */
 
@@ -76,16 +75,15 @@ int drc_blocked_to_dense(const float* blk, float* dense, int N, int C, int D, in
  *
  * fp32 in, fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
  */
-typedef struct drc_tap {
-    int32_t dd, dh, dw; /* input offset (in padded-input coordinates) relative to in_mul*o */
-    int32_t widx;       /* index of the [cb_in][Cout][16] weight slab for this tap */
-} drc_tap;
-
+/* One tap class = a full Cartesian grid of taps (nd x nh x nw).  A plain convolution has one class
+ * (3x3x3, 1xkxk, 1x1x1); the k3/s2 transposed convolution has 8 output-parity classes of {1,2}^3 taps.
+ *   tap (a,b,c): input offset (dd0+a*sd, dh0+b*sh, dw0+c*sw) in padded-input coordinates relative to in_mul*o,
+ *                weight slab index wbase + a*wsd + b*wsh + c*wsw  (steps may be negative). */
 typedef struct drc_tap_class {
-    int32_t tap_begin, tap_end;      /* taps sorted by dd inside a class */
-    int32_t n_phase;                 /* number of distinct dd */
-    int32_t phase_tap_begin[4];      /* tap ranges per distinct dd (phase_tap_begin[n_phase] = tap_end) */
-    int32_t min_dh, max_dh, min_dw, max_dw;
+    int32_t nd, nh, nw;
+    int32_t dd0, dh0, dw0;
+    int32_t sd, sh, sw;
+    int32_t wbase, wsd, wsh, wsw;
     int32_t out_off_d, out_off_h, out_off_w; /* parity offsets (0/1) */
 } drc_tap_class;
 
@@ -111,7 +109,6 @@ typedef struct drc_tapconv_params {
     int32_t lds_bytes_per_wave; /* >= 2 * staged tile bytes of the largest class */
     int32_t reserved;
     drc_tap_class cls[DRC_MAX_CLASSES];
-    drc_tap taps[DRC_MAX_TAPS];
 } drc_tapconv_params;
 
 /* Validates, picks the (voxel-tiles, cout-tiles) instantiation and launches. */

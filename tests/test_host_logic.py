@@ -27,7 +27,7 @@ def test_params_struct_matches_header_size():
     """sizeof(drc_tapconv_params) computed by gcc must equal the ctypes mirror."""
     import subprocess, tempfile
     from disprcnn_amd import _lib
-    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(drc_tap));return 0;}'
+    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(int32_t));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -35,7 +35,7 @@ def test_params_struct_matches_header_size():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         a, b, t = map(int, subprocess.check_output([exe]).split())
     assert a == ctypes.sizeof(_lib.DrcTapconvParams)
-    assert b == ctypes.sizeof(_lib.DrcTapClass) and t == ctypes.sizeof(_lib.DrcTap)
+    assert b == ctypes.sizeof(_lib.DrcTapClass) and t == 4
 
 
 def test_state_dict_layout():
@@ -78,9 +78,15 @@ def test_deconv_parity_classes_cover_all_taps():
     from disprcnn_amd import engine as E
     cls = E.taps_deconv3d_k3s2()
     assert len(cls) == 8
-    widx = sorted(t[3] for c in cls for t in c["taps"])
+    widx = sorted(t[3] for c in cls for t in E.class_taps(c))
     assert widx == list(range(27))
-    assert sorted(len(c["taps"]) for c in cls) == [1, 2, 2, 2, 4, 4, 4, 8]
+    assert sorted(len(E.class_taps(c)) for c in cls) == [1, 2, 2, 2, 4, 4, 4, 8]
+    # o = 2i - 1 + k: class parity p, tap (offset, k) must satisfy 2*(j+off) - 1 + k == 2j + p per dimension
+    for c in cls:
+        for (dd, dh, dw, w) in E.class_taps(c):
+            ks = (w // 9, (w // 3) % 3, w % 3)
+            for off, k, par in zip((dd - 1, dh - 1, dw - 1), ks, c["off"]):
+                assert 2 * off - 1 + k == par
 
 
 @pytest.mark.parametrize("shape", [(28, 28, 1, 2, 2), (56, 56, 1, 2, 2), (14, 14, 2, 2, 2), (7, 7, 1, 1, 1), (112, 112, 2, 2, 2),
