@@ -12,9 +12,9 @@
 //       D[cout][voxel]: lane l holds couts 4*(l>>4)..+3 of voxel l&15  -> one float4 store per tile
 //   * a WAVE owns a group of R output rows x WT columns (VT*16 voxel slots) of one (n, od) slice and
 //     CT*16 output channels: VT*CT accumulators of 4 registers.
-//   * per phase (one depth offset, one 16-channel input block) the wave stages the input rows it needs into
-//     ITS OWN LDS region with global_load_lds_dwordx4 (no VGPR round trip, no block barrier: waves are
-//     independent), double-buffered; the (kh,kw) taps of the phase are LDS address offsets.
+//   * per phase (one depth offset, one 8-channel half of a 16-channel input block) the wave stages the input rows
+//     it needs into ITS OWN LDS region with global_load_lds_dwordx4 (no VGPR round trip, no block barrier: waves
+//     are independent), double-buffered; the (kh,kw) taps of the phase are LDS address offsets.
 //   * weights stream from L2/L1 straight into VGPRs (the 4 waves of a block share them through L1);
 //     weights and B fragments are register double-buffered one tap ahead (A/B sets, no runtime indexing).
 //   * epilogue: folded-BN scale/shift, residual add, ReLU, coalesced float4 stores (16 voxels x 64 B).
@@ -28,10 +28,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef WAVES_PER_BLOCK
+#define WAVES_PER_BLOCK 4
+#endif
+
 namespace {
 
+// A phase covers one depth tap, one 16-channel input block and one 8-channel HALF of it: the LDS tile of a wave is
+// [rows_in][seg_vox][8 floats] (32 B per voxel), double-buffered.  Half-width phases keep a wave's LDS footprint
+// near 11 KB, so 8-12 waves (2-3 per SIMD) are resident per CU and one wave's prologue / epilogue / memory waits
+// overlap another wave's MFMAs.
 template <int VT, int CT>
-__global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void tapconv_kernel(const drc_tapconv_params p) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -42,7 +52,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
     const int n_wt = (p.OW + p.WT - 1) / p.WT;
     const int n_rt = (p.OH + p.R - 1) / p.R;
     const int groups = p.N * p.OD * n_rt * n_wt;
-    int gid = blockIdx.x * 4 + wave;
+    int gid = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (gid >= groups) return;  // wave-uniform; the kernel has no block-level barrier
     const int wt = gid % n_wt; gid /= n_wt;
     const int rt = gid % n_rt; gid /= n_rt;
@@ -53,40 +63,47 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
 
     const int rows_in = p.in_mul * (p.R - 1) + (cls.nh - 1) * cls.sh + 1;
     const int seg_vox = p.in_mul * (p.WT - 1) + (cls.nw - 1) * cls.sw + 1;
-    const int seg_floats = seg_vox * 16;
+    const int seg_floats = seg_vox * 8;          // LDS floats per staged row (8 channels per voxel)
+    const int seg_units = seg_vox * 2;           // 16-byte units per staged row
     const int buf_floats = rows_in * seg_floats;
     float* lds = lds_all + wave * (p.lds_bytes_per_wave >> 2);
     const int nslots = p.R * p.WT;
 
-    // per-lane B-operand offsets (floats) inside a staged tile
+    // per-lane B-operand offsets (floats) inside a staged tile: voxel (r,c), channels 2g,2g+1 of the half
     int lane_off[VT];
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) {
         const int s = vt * 16 + j;
         int r = s / p.WT, c = s - r * p.WT;
         if (s >= nslots) { r = 0; c = 0; }
-        lane_off[vt] = (p.in_mul * r * seg_vox + p.in_mul * c) * 16 + g * 4;
+        lane_off[vt] = (p.in_mul * r * seg_vox + p.in_mul * c) * 8 + g * 2;
     }
 
     const float* xbase = p.x + (int64_t)n * p.x_n_stride + (int64_t)(p.in_mul * oh0 + cls.dh0) * p.x_h_stride +
                          (int64_t)(p.in_mul * ow0 + cls.dw0) * 16;
-    const int nt = cls.nh * cls.nw;        // taps per phase
-    const int n_ph = cls.nd * p.cb_in;     // phases: depth tap (outer) x input channel block (inner)
+    const int nt = cls.nh * cls.nw;            // taps per phase
+    const int n_ph = cls.nd * p.cb_in * 2;     // phases: depth tap (outer) x input channel block x half (inner)
 
-    auto stage = [&](int ph) {
-        const int di = ph / p.cb_in, cb = ph - di * p.cb_in;
-        const float* src = xbase + (int64_t)cb * p.x_cb_stride + (int64_t)(p.in_mul * od + cls.dd0 + di * cls.sd) * p.x_d_stride;
+    // LDS-DMA rows [r0, r1) of phase ph's input tile into its LDS buffer.  Lane l of a piece moves 16 B: LDS side is
+    // lane-linear (piece*1 KiB + l*16), global side is per-lane: voxel (unit>>1), 16-byte part (unit&1) of the half.
+    // The rows of the NEXT phase are spread over the tap steps of the current one: a smooth request stream instead of
+    // one burst per phase from every wave at once.
+    auto stage_rows = [&](int ph, int r0, int r1) {
+        const int h = ph & 1, pc = ph >> 1;
+        const int di = pc / p.cb_in, cb = pc - di * p.cb_in;
+        const float* src = xbase + (int64_t)cb * p.x_cb_stride + (int64_t)(p.in_mul * od + cls.dd0 + di * cls.sd) * p.x_d_stride + h * 8;
         float* dst = lds + (ph & 1) * buf_floats;
-        for (int r = 0; r < rows_in; ++r) {
+        for (int r = r0; r < r1; ++r) {
             const float* srow = src + (int64_t)r * p.x_h_stride;
             float* drow = dst + r * seg_floats;
-            for (int piece = 0; piece < seg_floats; piece += 256) {
-                const int idx = piece + lane * 4;
-                if (idx < seg_floats)
-                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srow + idx), LDS_PTR(drow + piece), 16, 0, 0);
+            for (int u0 = 0; u0 < seg_units; u0 += 64) {
+                const int u = u0 + lane;
+                if (u < seg_units)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srow + (u >> 1) * 16 + (u & 1) * 4), LDS_PTR(drow + u0 * 4), 16, 0, 0);
             }
         }
     };
+    const int rows_per_step = (rows_in + (nt > 1 ? nt - 2 : 0)) / (nt > 1 ? nt - 1 : 1);
 
     f32x4 acc[VT][CT];
 #pragma unroll
@@ -94,70 +111,69 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weight fragment address: slab [widx][cb][cout_pad][16]
-    const float* wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 16 + g * 4;
-    const int64_t w_cb_stride = (int64_t)p.cout_pad * 16;
-    const int64_t w_tap_stride = w_cb_stride * p.cb_in;
+    // weight fragment address: packed [widx][cb][half][cout_pad][8]; lane (cout j, k member g) reads channels 2g,2g+1
+    const float* wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 8 + g * 2;
+    const int64_t w_half_stride = (int64_t)p.cout_pad * 8;
+    const int64_t w_tap_stride = w_half_stride * 2 * p.cb_in;
 
-    // "next step" cursor, advanced incrementally (no divisions in the loop): phase (di,cb), tap (tb,tc)
-    int n_di = 0, n_cb = 0, n_tb = 0, n_tc = 0;
+    // "next step" cursor, advanced incrementally (no divisions in the loop): phase counter n_pc = (di*cb_in+cb)*2+h
+    int n_di = 0, n_pcb = 0, n_tb = 0, n_tc = 0;   // n_pcb = cb*2+h within the depth tap
     auto next_wptr = [&]() -> const float* {
         const int widx = cls.wbase + n_di * cls.wsd + n_tb * cls.wsh + n_tc * cls.wsw;
-        return wlane + (int64_t)widx * w_tap_stride + (int64_t)n_cb * w_cb_stride;
+        return wlane + (int64_t)widx * w_tap_stride + (int64_t)n_pcb * w_half_stride;
     };
-    auto next_tap_off = [&]() -> int { return (n_tb * cls.sh * seg_vox + n_tc * cls.sw) * 16; };
-    auto advance = [&]() {   // move the cursor one tap step forward (wraps into the next phase; saturates at the end)
+    auto next_tap_off = [&]() -> int { return (n_tb * cls.sh * seg_vox + n_tc * cls.sw) * 8; };
+    auto advance = [&]() {   // one tap step forward (wraps into the next phase; n_di == cls.nd marks the end)
         if (++n_tc == cls.nw) {
             n_tc = 0;
             if (++n_tb == cls.nh) {
                 n_tb = 0;
-                if (++n_cb == p.cb_in) { n_cb = 0; ++n_di; }
+                if (++n_pcb == 2 * p.cb_in) { n_pcb = 0; ++n_di; }
             }
         }
     };
 
-    f32x4 wA[CT], wB[CT], bA[VT], bB[VT];
-    stage(0);
+    f32x2 wA[CT], wB[CT], bA[VT], bB[VT];
+    stage_rows(0, 0, rows_in);
     {
         const float* wp = next_wptr();
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) wA[ct] = *(const f32x4*)(wp + ct * 256);
+        for (int ct = 0; ct < CT; ++ct) wA[ct] = *(const f32x2*)(wp + ct * 128);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const int t_stage = nt >= 2 ? nt - 2 : 0;
-
-#define DRC_MFMA_BLOCK(KK, W_USE, B_USE)                                                               \
-    _Pragma("unroll") for (int vt = 0; vt < VT; ++vt)                                                  \
+#define DRC_MFMA(VT0, VT1, KK, W_USE, B_USE)                                                           \
+    _Pragma("unroll") for (int vt = VT0; vt < VT1; ++vt)                                               \
         _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
             acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[ct][KK], B_USE[vt][KK], acc[vt][ct], 0, 0, 0);
 
-// One tap step.  Every prefetch (next LDS tile via LDS-DMA, next weights, next B fragments) is issued AFTER the first
-// MFMA block and is therefore >= 3/4 of a step old when the next step's first MFMA waits for it: the waits hipcc
-// places (conservatively vmcnt(0)/lgkmcnt(0)) never see a young load.
+// One tap step (2*VT*CT MFMAs).  The first CT MFMAs carry the wait for this step's operands; every prefetch (next
+// LDS rows via LDS-DMA, next weights, next B fragments) is issued right after them, i.e. almost a full step before
+// it is needed, so the (conservative, vmcnt(0)/lgkmcnt(0)) waits hipcc places never see a young load.
 #define DRC_STEP(T, W_USE, B_USE, W_LD, B_LD)                                                          \
     {                                                                                                  \
-        DRC_MFMA_BLOCK(0, W_USE, B_USE)                                                                \
+        DRC_MFMA(0, 1, 0, W_USE, B_USE)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        if ((T) == t_stage && ph + 1 < n_ph) stage(ph + 1);                                            \
+        if (ph + 1 < n_ph) {                                                                           \
+            const int r0_ = (T) * rows_per_step;                                                       \
+            if (r0_ < rows_in) stage_rows(ph + 1, r0_, r0_ + rows_per_step < rows_in ? r0_ + rows_per_step : rows_in); \
+        }                                                                                              \
         advance();                                                                                     \
         const bool in_phase_ = (T) + 1 < nt;                                                           \
         const float* wp_ = next_wptr();                                                                \
         if (n_di < cls.nd) {                                                                           \
-            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) W_LD[ct] = *(const f32x4*)(wp_ + ct * 256); \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) W_LD[ct] = *(const f32x2*)(wp_ + ct * 128); \
         }                                                                                              \
         const int to_ = in_phase_ ? next_tap_off() : 0;                                                \
-        _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x4*)(buf + lane_off[vt] + to_); \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        DRC_MFMA_BLOCK(1, W_USE, B_USE)                                                                \
-        DRC_MFMA_BLOCK(2, W_USE, B_USE)                                                                \
-        DRC_MFMA_BLOCK(3, W_USE, B_USE)                                                                \
+        _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x2*)(buf + lane_off[vt] + to_); \
+        DRC_MFMA(1, VT, 0, W_USE, B_USE)                                                               \
+        DRC_MFMA(0, VT, 1, W_USE, B_USE)                                                               \
     }
 
     for (int ph = 0; ph < n_ph; ++ph) {
         const float* buf = lds + (ph & 1) * buf_floats;
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x4*)(buf + lane_off[vt]);   // tap 0 of this phase
+        for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x2*)(buf + lane_off[vt]);   // tap 0 of this phase
         int t = 0;
         for (; t + 1 < nt; t += 2) {
             DRC_STEP(t, wA, bA, wB, bB);
@@ -168,11 +184,11 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const drc_tapconv_params p
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) wA[ct] = wB[ct];
         }
-        // the next phase's tile (issued >= 3/4 of a tap step ago) must have landed before it is read
+        // the next phase's tile must have landed before it is read
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #undef DRC_STEP
-#undef DRC_MFMA_BLOCK
+#undef DRC_MFMA
 
     // epilogue: folded BN, residual, ReLU, store
 #pragma unroll
@@ -206,14 +222,14 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     const int n_wt = (p.OW + p.WT - 1) / p.WT;
     const int n_rt = (p.OH + p.R - 1) / p.R;
     const long groups = (long)p.N * p.OD * n_rt * n_wt;
-    dim3 grid((unsigned)((groups + 3) / 4), (unsigned)(p.cout_pad / 16 / CT), (unsigned)p.n_classes);
-    const size_t lds = (size_t)p.lds_bytes_per_wave * 4;
+    dim3 grid((unsigned)((groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), (unsigned)(p.cout_pad / 16 / CT), (unsigned)p.n_classes);
+    const size_t lds = (size_t)p.lds_bytes_per_wave * WAVES_PER_BLOCK;
     static bool attr_done = false;  // idempotent attribute set; benign race
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)tapconv_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((tapconv_kernel<VT, CT>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((tapconv_kernel<VT, CT>), grid, dim3(64 * WAVES_PER_BLOCK), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -250,14 +266,19 @@ extern "C" int drc_tapconv_fwd(const drc_tapconv_params* pp, void* stream) {
         if (k.dd0 < 0 || k.dh0 < 0 || k.dw0 < 0) return -4;
         const int rows_in = p.in_mul * (p.R - 1) + (k.nh - 1) * k.sh + 1;
         const int seg_vox = p.in_mul * (p.WT - 1) + (k.nw - 1) * k.sw + 1;
-        const int bytes = rows_in * seg_vox * 64 * 2;
+        const int bytes = rows_in * seg_vox * 32 * 2;
         if (bytes > need) need = bytes;
     }
     if (p.lds_bytes_per_wave < need || (p.lds_bytes_per_wave & 15) || (size_t)p.lds_bytes_per_wave * 4 > 160 * 1024) return -5;
     hipStream_t s = (hipStream_t)stream;
     const int ct = p.cout_pad / 16;
     const int nvt = (p.R * p.WT + 15) / 16;
-    if (ct % 4 == 0) return launch_vt<4>(nvt, p, s);
-    if (ct % 2 == 0) return launch_vt<2>(nvt, p, s);
+    // cout tiles per wave: as many as divide the layer (A-operand reuse), but split further when the launch would
+    // otherwise leave most of the 1024 SIMDs without a wave (small pyramid levels)
+    const long groups = (long)p.N * p.OD * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT) * p.n_classes;
+    int CT = (ct % 4 == 0) ? 4 : (ct % 2 == 0) ? 2 : 1;
+    while (CT > 1 && (groups * (ct / CT) < 2048 || nvt * CT > 16)) CT >>= 1;   // <=16 accumulators: 2+ waves per SIMD
+    if (CT == 4) return launch_vt<4>(nvt, p, s);
+    if (CT == 2) return launch_vt<2>(nvt, p, s);
     return launch_vt<1>(nvt, p, s);
 }

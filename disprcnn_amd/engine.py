@@ -99,7 +99,8 @@ def _base_ptr(t):
 
 # ------------------------------------------------------------------------------------------- weights
 def pack_weight(w, transposed=False):
-    """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) -> [K][cb_in][cout_pad][16] fp32 contiguous."""
+    """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) -> [K][cb_in][2 halves][cout_pad][8] fp32 contiguous
+    (shape[3] is cout_pad; channel c of block cb sits in half c//8, slot c%8)."""
     if transposed:
         w = w.transpose(0, 1)
     cout, cin = w.shape[:2]
@@ -108,7 +109,8 @@ def pack_weight(w, transposed=False):
     cout_pad = (cout + CB - 1) // CB * CB
     wp = torch.zeros(K, cb * CB, cout_pad, dtype=torch.float32, device=w.device)
     wp[:, :cin, :cout] = w.reshape(cout, cin, K).permute(2, 1, 0)
-    return wp.view(K, cb, CB, cout_pad).permute(0, 1, 3, 2).contiguous()
+    # [K][cb][half][8][cout] -> [K][cb][half][cout][8]
+    return wp.view(K, cb, 2, 8, cout_pad).permute(0, 1, 2, 4, 3).contiguous()
 
 
 def pack_weight_cout1(w):
@@ -179,7 +181,7 @@ def choose_tile(OH, OW, in_mul, span_h, span_w):
         for r in range(1, min(OH, MAX_SLOTS // wt) + 1):
             rows_in = in_mul * (r - 1) + span_h + 1
             seg = in_mul * (wt - 1) + span_w + 1
-            lds = 2 * rows_in * seg * 64
+            lds = 2 * rows_in * seg * 32      # double-buffered [rows][voxels][8 ch] fp32 tile per wave
             if lds > LDS_PER_WAVE_MAX:
                 continue
             n_rt, n_wt = -(-OH // r), -(-OW // wt)
@@ -187,7 +189,7 @@ def choose_tile(OH, OW, in_mul, span_h, span_w):
             useful = OH * OW
             issued = n_rt * n_wt * nvt * 16
             eff = useful / issued
-            key = (round(eff, 4), r * wt, -lds)
+            key = (round(eff, 4), r * wt, wt, -lds)       # ties: more slots, then WIDE tiles (long contiguous rows)
             if best is None or key > best[0]:
                 best = (key, r, wt, lds)
     if best is None:
@@ -229,7 +231,11 @@ class ConvPlan:
         self.flops = 2 * x.N * OD * OH * OW * ntaps * x.C * cout       # algorithmic (unpadded channels, valid voxels)
         nvt = -(-(R * WT) // 16)
         ct = p.cout_pad // 16
-        self.kname = "tapconv_kernel<%d,%d>" % (nvt, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1))
+        groups = x.N * OD * (-(-OH // R)) * (-(-OW // WT)) * len(classes)
+        CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
+        while CT > 1 and (groups * (ct // CT) < 2048 or nvt * CT > 16):      # mirrors drc_tapconv_fwd's choice
+            CT //= 2
+        self.kname = "tapconv_kernel<%d,%d>" % (nvt, CT)
 
     def run(self, x, w, scale, shift, y, res=None):
         p = self.p

@@ -17,7 +17,7 @@ class _Conv:
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
         self.cout = w.shape[1] if transposed else w.shape[0]
         self.w = E.pack_weight(w, transposed)
-        cout_pad = self.w.shape[2]
+        cout_pad = self.w.shape[3]
         if bn is not None:
             self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
                                                bn.running_mean.detach().to(device).float(),

@@ -64,7 +64,7 @@ def conv3d_bn(x, weight, scale, shift, stride=1, relu=False, residual=None, tran
     rb = E.Blocked(n, cout, od, oh, ow, 1, 1, 1, dev).from_dense(residual) if residual is not None else None
     plan = E.plan_deconv3d(xb, yb, cout, relu) if transposed else E.plan_conv3d(xb, yb, stride, cout, relu)
     wp = E.pack_weight(weight.to(dev).float(), transposed)
-    cp = wp.shape[2]
+    cp = wp.shape[3]
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale; sh[:cout] = shift
     plan.run(xb, wp, sc, sh, yb, rb)
@@ -85,7 +85,7 @@ def conv2d_bn(x, weight, scale, shift, stride=1, pad=1, dilation=1, relu=False, 
     rb = E.Blocked(n, cout, 1, oh, ow, 0, 2, 2, dev).from_dense(residual) if residual is not None else None
     plan = E.plan_conv2d(xb, yb, k, stride, pad, dilation, cout, relu)
     wp = E.pack_weight(weight.to(dev).float())
-    cp = wp.shape[2]
+    cp = wp.shape[3]
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale; sh[:cout] = shift
     plan.run(xb, wp, sc, sh, yb, rb)

@@ -63,15 +63,19 @@ def test_pack_weight_layout():
     from disprcnn_amd import engine as E
     w = torch.arange(2 * 3 * 27, dtype=torch.float32).view(2, 3, 3, 3, 3)
     p = E.pack_weight(w)
-    assert tuple(p.shape) == (27, 1, 16, 16)
+    assert tuple(p.shape) == (27, 1, 2, 16, 8)          # [tap][cb][half][cout][8 ch]
     for t in (0, 13, 26):
         for co in range(2):
             for ci in range(3):
-                assert p[t, 0, co, ci] == w[co, ci].reshape(-1)[t]
-    assert p[:, :, 2:, :].abs().sum() == 0 and p[:, :, :, 3:].abs().sum() == 0
+                assert p[t, 0, ci // 8, co, ci % 8] == w[co, ci].reshape(-1)[t]
+    assert p[:, :, :, 2:, :].abs().sum() == 0 and p[:, :, 0, :, 3:].abs().sum() == 0 and p[:, :, 1].abs().sum() == 0
+    w2 = torch.arange(4 * 20 * 27, dtype=torch.float32).view(4, 20, 3, 3, 3)
+    p2 = E.pack_weight(w2)
+    assert tuple(p2.shape) == (27, 2, 2, 16, 8)
+    assert p2[7, 1, 0, 3, 2] == w2[3, 18].reshape(-1)[7] and p2[7, 0, 1, 3, 5] == w2[3, 13].reshape(-1)[7]
     wt = torch.arange(3 * 2 * 27, dtype=torch.float32).view(3, 2, 3, 3, 3)     # ConvTranspose: [Cin,Cout,...]
     pt = E.pack_weight(wt, transposed=True)
-    assert pt[5, 0, 1, 2] == wt[2, 1].reshape(-1)[5]
+    assert pt[5, 0, 0, 1, 2] == wt[2, 1].reshape(-1)[5]
 
 
 def test_deconv_parity_classes_cover_all_taps():
@@ -96,4 +100,4 @@ def test_tile_choice_fits_lds(shape):
     OH, OW, im, sh, sw = shape
     R, WT, lds = E.choose_tile(OH, OW, im, sh, sw)
     assert R * WT <= 112 and lds <= E.LDS_PER_WAVE_MAX
-    assert lds == 2 * (im * (R - 1) + sh + 1) * (im * (WT - 1) + sw + 1) * 64
+    assert lds == 2 * (im * (R - 1) + sh + 1) * (im * (WT - 1) + sw + 1) * 32

@@ -1,0 +1,42 @@
+"""Micro-benchmark of one tapconv layer (development tool; not part of the product or the tests)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from disprcnn_amd import _lib
+if os.environ.get("DRC_LIB"):
+    _lib.LIB_PATH = os.environ["DRC_LIB"]
+from disprcnn_amd import engine as E
+
+def run(N, cin, cout, dims, stride=1, deconv=False, reps=20):
+    dev = torch.device("cuda:0")
+    x = E.Blocked(N, cin, *dims, 1, 1, 1, dev)
+    x.view6().normal_()
+    od = tuple(2 * d for d in dims) if deconv else tuple(-(-d // stride) for d in dims)
+    y = E.Blocked(N, cout, *od, 1, 1, 1, dev)
+    plan = E.plan_deconv3d(x, y, cout, True) if deconv else E.plan_conv3d(x, y, stride, cout, True)
+    w = torch.randn((cin, cout, 3, 3, 3) if deconv else (cout, cin, 3, 3, 3), device=dev) * 0.05
+    wp = E.pack_weight(w, deconv)
+    sc = torch.ones(wp.shape[3], device=dev); sh = torch.zeros(wp.shape[3], device=dev)
+    for _ in range(3):
+        plan.run(x, wp, sc, sh, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        plan.run(x, wp, sc, sh, y)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print(f"{os.environ.get('DRC_LIB','default').split('/')[-1]:28s} N={N} {cin}->{cout} {dims} s{stride} dc={deconv} {plan.kname} R={plan.p.R} WT={plan.p.WT}: {us:8.1f} us  {plan.flops/us/1e6:6.1f} TF")
+
+if __name__ == "__main__":
+    N = int(os.environ.get("N", "128"))
+    run(N, 32, 32, (12, 28, 28))
+    if os.environ.get("ALL"):
+        run(N, 64, 32, (12, 28, 28))
+        run(N, 32, 64, (12, 28, 28), stride=2)
+        run(N, 64, 64, (6, 14, 14))
+        run(N, 64, 64, (6, 14, 14), stride=2)
+        run(N, 64, 64, (3, 7, 7))
+        run(N, 64, 64, (3, 7, 7), deconv=True)
+        run(N, 64, 32, (6, 14, 14), deconv=True)
+        run(16, 32, 32, (24, 56, 56))
