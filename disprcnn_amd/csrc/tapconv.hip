@@ -52,13 +52,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void tapconv_kernel(const drc
     const int n_wt = (p.OW + p.WT - 1) / p.WT;
     const int n_rt = (p.OH + p.R - 1) / p.R;
     const int groups = p.N * p.OD * n_rt * n_wt;
+    // PERSISTENT waves: wave w of the launch walks groups w, w+G, w+2G, ... (G = resident waves).  While a group's last
+    // phase computes, the first tile of the wave's NEXT group is already being staged, so only the very first tile of
+    // a wave is an exposed HBM round trip; with 2-3 waves per SIMD the epilogue of one group hides behind a
+    // neighbour's MFMAs.
+    const int G = gridDim.x * WAVES_PER_BLOCK;
     int gid = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (gid >= groups) return;  // wave-uniform; the kernel has no block-level barrier
-    const int wt = gid % n_wt; gid /= n_wt;
-    const int rt = gid % n_rt; gid /= n_rt;
-    const int od = gid % p.OD;
-    const int n = gid / p.OD;
-    const int oh0 = rt * p.R, ow0 = wt * p.WT;
+    struct GroupPos { int n, od, oh0, ow0; };
+    auto decode = [&](int gidx) -> GroupPos {
+        GroupPos q;
+        const int wt = gidx % n_wt; gidx /= n_wt;
+        const int rt = gidx % n_rt; gidx /= n_rt;
+        q.od = gidx % p.OD; q.n = gidx / p.OD;
+        q.oh0 = rt * p.R; q.ow0 = wt * p.WT;
+        return q;
+    };
+    auto group_base = [&](const GroupPos& q) -> const float* {   // input pointer of the group's tile origin (depth tap 0)
+        return p.x + (int64_t)q.n * p.x_n_stride + (int64_t)(p.in_mul * q.od + cls.dd0) * p.x_d_stride +
+               (int64_t)(p.in_mul * q.oh0 + cls.dh0) * p.x_h_stride + (int64_t)(p.in_mul * q.ow0 + cls.dw0) * 16;
+    };
     const int ct0 = blockIdx.y * CT;
 
     const int rows_in = p.in_mul * (p.R - 1) + (cls.nh - 1) * cls.sh + 1;
@@ -79,8 +92,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void tapconv_kernel(const drc
         lane_off[vt] = (p.in_mul * r * seg_vox + p.in_mul * c) * 8 + g * 2;
     }
 
-    const float* xbase = p.x + (int64_t)n * p.x_n_stride + (int64_t)(p.in_mul * oh0 + cls.dh0) * p.x_h_stride +
-                         (int64_t)(p.in_mul * ow0 + cls.dw0) * 16;
+    GroupPos cur = decode(gid);
+    const float* xcur = group_base(cur);     // this group's input origin
+    const float* xnext = xcur;               // next group's input origin (valid when gid + G < groups)
     const int nt = cls.nh * cls.nw;            // taps per phase
     const int n_ph = cls.nd * p.cb_in * 2;     // phases: depth tap (outer) x input channel block x half (inner)
 
@@ -88,11 +102,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void tapconv_kernel(const drc
     // lane-linear (piece*1 KiB + l*16), global side is per-lane: voxel (unit>>1), 16-byte part (unit&1) of the half.
     // The rows of the NEXT phase are spread over the tap steps of the current one: a smooth request stream instead of
     // one burst per phase from every wave at once.
-    auto stage_rows = [&](int ph, int r0, int r1) {
+    auto stage_rows = [&](const float* base, int ph, int bufi, int r0, int r1) {
         const int h = ph & 1, pc = ph >> 1;
         const int di = pc / p.cb_in, cb = pc - di * p.cb_in;
-        const float* src = xbase + (int64_t)cb * p.x_cb_stride + (int64_t)(p.in_mul * od + cls.dd0 + di * cls.sd) * p.x_d_stride + h * 8;
-        float* dst = lds + (ph & 1) * buf_floats;
+        const float* src = base + (int64_t)cb * p.x_cb_stride + (int64_t)(di * cls.sd) * p.x_d_stride + h * 8;
+        float* dst = lds + bufi * buf_floats;
         for (int r = r0; r < r1; ++r) {
             const float* srow = src + (int64_t)r * p.x_h_stride;
             float* drow = dst + r * seg_floats;
@@ -116,29 +130,37 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void tapconv_kernel(const drc
     const int64_t w_half_stride = (int64_t)p.cout_pad * 8;
     const int64_t w_tap_stride = w_half_stride * 2 * p.cb_in;
 
-    // "next step" cursor, advanced incrementally (no divisions in the loop): phase counter n_pc = (di*cb_in+cb)*2+h
+    // "next step" cursor, advanced incrementally (no divisions in the loop); wraps to the first step of the next group
     int n_di = 0, n_pcb = 0, n_tb = 0, n_tc = 0;   // n_pcb = cb*2+h within the depth tap
     auto next_wptr = [&]() -> const float* {
         const int widx = cls.wbase + n_di * cls.wsd + n_tb * cls.wsh + n_tc * cls.wsw;
         return wlane + (int64_t)widx * w_tap_stride + (int64_t)n_pcb * w_half_stride;
     };
     auto next_tap_off = [&]() -> int { return (n_tb * cls.sh * seg_vox + n_tc * cls.sw) * 8; };
-    auto advance = [&]() {   // one tap step forward (wraps into the next phase; n_di == cls.nd marks the end)
+    auto advance = [&]() {
         if (++n_tc == cls.nw) {
             n_tc = 0;
             if (++n_tb == cls.nh) {
                 n_tb = 0;
-                if (++n_pcb == 2 * p.cb_in) { n_pcb = 0; ++n_di; }
+                if (++n_pcb == 2 * p.cb_in) { n_pcb = 0; if (++n_di == cls.nd) n_di = 0; }
             }
         }
     };
 
     f32x2 wA[CT], wB[CT], bA[VT], bB[VT];
-    stage_rows(0, 0, rows_in);
+    int bufsel = 0;                               // LDS buffer holding the phase being computed
+    stage_rows(xcur, 0, 0, 0, rows_in);           // the only exposed tile load of this wave
     {
         const float* wp = next_wptr();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) wA[ct] = *(const f32x2*)(wp + ct * 128);
+    }
+    // folded-BN scale/shift of this wave's couts (same for every group)
+    f32x4 bn_sc[CT], bn_sh[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
+        bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -154,67 +176,79 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void tapconv_kernel(const drc
     {                                                                                                  \
         DRC_MFMA(0, 1, 0, W_USE, B_USE)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        if (ph + 1 < n_ph) {                                                                           \
+        if (st_on) {                                                                                   \
             const int r0_ = (T) * rows_per_step;                                                       \
-            if (r0_ < rows_in) stage_rows(ph + 1, r0_, r0_ + rows_per_step < rows_in ? r0_ + rows_per_step : rows_in); \
+            if (r0_ < rows_in) stage_rows(st_base, st_ph, bufsel ^ 1, r0_, r0_ + rows_per_step < rows_in ? r0_ + rows_per_step : rows_in); \
         }                                                                                              \
         advance();                                                                                     \
         const bool in_phase_ = (T) + 1 < nt;                                                           \
         const float* wp_ = next_wptr();                                                                \
-        if (n_di < cls.nd) {                                                                           \
-            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) W_LD[ct] = *(const f32x2*)(wp_ + ct * 128); \
-        }                                                                                              \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) W_LD[ct] = *(const f32x2*)(wp_ + ct * 128);  \
         const int to_ = in_phase_ ? next_tap_off() : 0;                                                \
         _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x2*)(buf + lane_off[vt] + to_); \
         DRC_MFMA(1, VT, 0, W_USE, B_USE)                                                               \
         DRC_MFMA(0, VT, 1, W_USE, B_USE)                                                               \
     }
 
-    for (int ph = 0; ph < n_ph; ++ph) {
-        const float* buf = lds + (ph & 1) * buf_floats;
+    for (;;) {
+        const bool has_next = gid + G < groups;
+        if (has_next) xnext = group_base(decode(gid + G));
+        for (int ph = 0; ph < n_ph; ++ph) {
+            const float* buf = lds + bufsel * buf_floats;
+            // what this phase's steps stage into the other buffer: this group's next phase, or the next group's first
+            const bool st_on = (ph + 1 < n_ph) || has_next;
+            const float* st_base = (ph + 1 < n_ph) ? xcur : xnext;
+            const int st_ph = (ph + 1 < n_ph) ? ph + 1 : 0;
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x2*)(buf + lane_off[vt]);   // tap 0 of this phase
-        int t = 0;
-        for (; t + 1 < nt; t += 2) {
-            DRC_STEP(t, wA, bA, wB, bB);
-            DRC_STEP(t + 1, wB, bB, wA, bA);
-        }
-        if (t < nt) {
-            DRC_STEP(t, wA, bA, wB, bB);
+            for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x2*)(buf + lane_off[vt]);   // tap 0 of this phase
+            int t = 0;
+            for (; t + 1 < nt; t += 2) {
+                DRC_STEP(t, wA, bA, wB, bB);
+                DRC_STEP(t + 1, wB, bB, wA, bA);
+            }
+            if (t < nt) {
+                DRC_STEP(t, wA, bA, wB, bB);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wA[ct] = wB[ct];
+                for (int ct = 0; ct < CT; ++ct) wA[ct] = wB[ct];
+            }
+            // the staged tile must have landed before the next phase reads it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bufsel ^= 1;
         }
-        // the next phase's tile must have landed before it is read
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // epilogue of this group: folded BN, residual, ReLU, store; then clear the accumulators
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) {
+            const int s = vt * 16 + j;
+            const int r = s / p.WT, c = s - r * p.WT;
+            const bool valid = (s < nslots) && (cur.oh0 + r < p.OH) && (cur.ow0 + c < p.OW);
+            if (valid) {
+                const int zd = cur.od * p.out_mul + cls.out_off_d, zh = (cur.oh0 + r) * p.out_mul + cls.out_off_h,
+                          zw = (cur.ow0 + c) * p.out_mul + cls.out_off_w;
+                const int64_t yo = p.y_off0 + (int64_t)cur.n * p.y_n_stride + (int64_t)zd * p.y_d_stride +
+                                   (int64_t)zh * p.y_h_stride + (int64_t)zw * 16 + g * 4;
+                const int64_t ro = p.r_off0 + (int64_t)cur.n * p.r_n_stride + (int64_t)zd * p.r_d_stride +
+                                   (int64_t)zh * p.r_h_stride + (int64_t)zw * 16 + g * 4;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    f32x4 v = acc[vt][ct] * bn_sc[ct] + bn_sh[ct];
+                    if (p.res) v += *(const f32x4*)(p.res + ro + (int64_t)(ct0 + ct) * p.r_cb_stride);
+                    if (p.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *(f32x4*)(p.y + yo + (int64_t)(ct0 + ct) * p.y_cb_stride) = v;
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (!has_next) break;
+        gid += G;
+        cur = decode(gid);
+        xcur = xnext;
     }
 #undef DRC_STEP
 #undef DRC_MFMA
-
-    // epilogue: folded BN, residual, ReLU, store
-#pragma unroll
-    for (int vt = 0; vt < VT; ++vt) {
-        const int s = vt * 16 + j;
-        const int r = s / p.WT, c = s - r * p.WT;
-        const bool valid = (s < nslots) && (oh0 + r < p.OH) && (ow0 + c < p.OW);
-        if (!valid) continue;
-        const int zd = od * p.out_mul + cls.out_off_d, zh = (oh0 + r) * p.out_mul + cls.out_off_h,
-                  zw = (ow0 + c) * p.out_mul + cls.out_off_w;
-        const int64_t yo = p.y_off0 + (int64_t)n * p.y_n_stride + (int64_t)zd * p.y_d_stride + (int64_t)zh * p.y_h_stride +
-                           (int64_t)zw * 16 + g * 4;
-        const int64_t ro = p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)zd * p.r_d_stride + (int64_t)zh * p.r_h_stride +
-                           (int64_t)zw * 16 + g * 4;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const f32x4 sc = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
-            const f32x4 sh = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
-            f32x4 v = acc[vt][ct] * sc + sh;
-            if (p.res) v += *(const f32x4*)(p.res + ro + (int64_t)(ct0 + ct) * p.r_cb_stride);
-            if (p.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            *(f32x4*)(p.y + yo + (int64_t)(ct0 + ct) * p.y_cb_stride) = v;
-        }
-    }
 }
 
 template <int VT, int CT>
@@ -222,7 +256,24 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     const int n_wt = (p.OW + p.WT - 1) / p.WT;
     const int n_rt = (p.OH + p.R - 1) / p.R;
     const long groups = (long)p.N * p.OD * n_rt * n_wt;
-    dim3 grid((unsigned)((groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), (unsigned)(p.cout_pad / 16 / CT), (unsigned)p.n_classes);
+    // persistent launch: at most as many blocks as stay resident (256 CUs x blocks per CU by LDS and registers);
+    // each wave then walks several groups back to back
+    const size_t lds_blk = (size_t)p.lds_bytes_per_wave * WAVES_PER_BLOCK;
+    static size_t occ_lds = (size_t)-1;   // per-instantiation cache of the occupancy query (benign race: idempotent)
+    static int occ_blocks = 1;
+    if (occ_lds != lds_blk) {
+        int nb = 0;
+        (void)hipFuncSetAttribute((const void*)tapconv_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tapconv_kernel<VT, CT>, 64 * WAVES_PER_BLOCK, lds_blk) != hipSuccess || nb < 1) nb = 1;
+        occ_blocks = nb;
+        occ_lds = lds_blk;
+    }
+    const int blocks_per_cu = occ_blocks;
+    const long want = (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const long yz = (long)(p.cout_pad / 16 / CT) * p.n_classes;
+    long cap = (256L * blocks_per_cu + yz - 1) / yz;
+    if (cap < 1) cap = 1;
+    dim3 grid((unsigned)(want < cap ? want : cap), (unsigned)(p.cout_pad / 16 / CT), (unsigned)p.n_classes);
     const size_t lds = (size_t)p.lds_bytes_per_wave * WAVES_PER_BLOCK;
     static bool attr_done = false;  // idempotent attribute set; benign race
     if (!attr_done) {
