@@ -1,0 +1,177 @@
+// roi_ops.hip -- the step in front of the disparity path: ROI pairing and ROIAlign crops (gfx950).
+//
+//   drc_roi_align_fwd   : ROIAlign forward, semantics of the reference op (csrc/cpu/ROIAlign_cpu.cpp:18-111,113-219,
+//                         csrc/cuda/ROIAlign_cuda.cu:64-122) with the ImageNet normalisation of
+//                         DispRCNN3D.crop_and_transform_roi_img (disprcnn3d.py:44-50) optionally fused in.
+//   drc_roi_align_bwd   : its adjoint (csrc/cuda/ROIAlign_cuda.cu:177-254), atomicAdd scatter.
+//   drc_align_roi_pairs : the per-ROI box arithmetic of prepare_psmnet_input_and_target (disprcnn3d.py:118-146) on the
+//                         device, so no .tolist() host sync sits between the 2D detections and the crops.
+// All HBM-bound and tiny next to the regressor: one thread per output element, coalesced along x.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Bilin { int p1, p2, p3, p4; float w1, w2, w3, w4; };
+
+// one bilinear sample at (y, x): reference pre_calc_for_bilinear_interpolate (ROIAlign_cpu.cpp:41-105)
+__device__ __forceinline__ Bilin bilinear_setup(float y, float x, int height, int width) {
+    Bilin b;
+    if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+        b.p1 = b.p2 = b.p3 = b.p4 = 0; b.w1 = b.w2 = b.w3 = b.w4 = 0.f;
+        return b;
+    }
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+    if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+    const float ly = y - y_low, lx = x - x_low, hy = 1.f - ly, hx = 1.f - lx;
+    b.p1 = y_low * width + x_low; b.p2 = y_low * width + x_high;
+    b.p3 = y_high * width + x_low; b.p4 = y_high * width + x_high;
+    b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+    return b;
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(const float* __restrict__ in, const float* __restrict__ rois,
+                                                                 float* __restrict__ out, int K, int C, int H, int W, int PH, int PW,
+                                                                 float spatial_scale, int sampling_ratio,
+                                                                 const float* __restrict__ mean, const float* __restrict__ stdv) {
+    const long total = (long)K * C * PH * PW;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH); t /= PH;
+        const int c = (int)(t % C);
+        const int k = (int)(t / C);
+        const float* r = rois + (long)k * 5;
+        const int b = (int)r[0];
+        // no rounding of the roi (ROIAlign_cpu.cpp:146-150); malformed rois forced to 1x1 (:157-158)
+        const float rsw = r[1] * spatial_scale, rsh = r[2] * spatial_scale;
+        const float rew = r[3] * spatial_scale, reh = r[4] * spatial_scale;
+        const float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+        const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
+        const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+        const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+        const float count = (float)(gh * gw);
+        const float* src = in + ((long)b * C + c) * H * W;
+        float acc = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float yy = rsh + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float xx = rsw + pw * bin_w + (ix + 0.5f) * bin_w / (float)gw;
+                const Bilin q = bilinear_setup(yy, xx, H, W);
+                acc += q.w1 * src[q.p1] + q.w2 * src[q.p2] + q.w3 * src[q.p3] + q.w4 * src[q.p4];
+            }
+        }
+        acc /= count;
+        if (mean) acc = (acc - mean[c]) / stdv[c];
+        out[idx] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                                 float* __restrict__ gin, int K, int C, int H, int W, int PH, int PW,
+                                                                 float spatial_scale, int sampling_ratio) {
+    const long total = (long)K * C * PH * PW;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH); t /= PH;
+        const int c = (int)(t % C);
+        const int k = (int)(t / C);
+        const float* r = rois + (long)k * 5;
+        const int b = (int)r[0];
+        const float rsw = r[1] * spatial_scale, rsh = r[2] * spatial_scale;
+        const float rew = r[3] * spatial_scale, reh = r[4] * spatial_scale;
+        const float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+        const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
+        const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+        const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+        const float gval = gout[idx] / (float)(gh * gw);
+        float* dst = gin + ((long)b * C + c) * H * W;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float yy = rsh + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float xx = rsw + pw * bin_w + (ix + 0.5f) * bin_w / (float)gw;
+                const Bilin q = bilinear_setup(yy, xx, H, W);
+                if (q.w1 != 0.f || q.w2 != 0.f || q.w3 != 0.f || q.w4 != 0.f) {
+                    atomicAdd(dst + q.p1, gval * q.w1); atomicAdd(dst + q.p2, gval * q.w2);
+                    atomicAdd(dst + q.p3, gval * q.w3); atomicAdd(dst + q.p4, gval * q.w4);
+                }
+            }
+        }
+    }
+}
+
+// expand_box_to_integer (stereo_utils.py:219-229): floor(x1), floor(y1), ceil(x2), ceil(y2); then the clamps and the
+// common width of disprcnn3d.py:121-131.
+__global__ void align_roi_pairs_kernel(const float* __restrict__ lbox, const float* __restrict__ rbox, const int* __restrict__ img_idx,
+                                       int R, int img_w, int img_h, float* __restrict__ rois_l, float* __restrict__ rois_r,
+                                       int* __restrict__ geom) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    int x1 = (int)floorf(lbox[i * 4 + 0]), y1 = (int)floorf(lbox[i * 4 + 1]);
+    int x2 = (int)ceilf(lbox[i * 4 + 2]), y2 = (int)ceilf(lbox[i * 4 + 3]);
+    int x1p = (int)floorf(rbox[i * 4 + 0]), x2p = (int)ceilf(rbox[i * 4 + 2]);
+    x1 = max(0, x1); x1p = max(0, x1p); y1 = max(0, y1);
+    y2 = min(y2, img_h - 1); x2 = min(x2, img_w - 1); x2p = min(x2p, img_w - 1);
+    int mw = max(x2 - x1, x2p - x1p);
+    mw = min(mw, min(img_w - x1, img_w - x1p));
+    const float b = (float)img_idx[i];
+    rois_l[i * 5 + 0] = b; rois_l[i * 5 + 1] = (float)x1; rois_l[i * 5 + 2] = (float)y1;
+    rois_l[i * 5 + 3] = (float)(x1 + mw); rois_l[i * 5 + 4] = (float)y2;
+    rois_r[i * 5 + 0] = b; rois_r[i * 5 + 1] = (float)x1p; rois_r[i * 5 + 2] = (float)y1;
+    rois_r[i * 5 + 3] = (float)(x1p + mw); rois_r[i * 5 + 4] = (float)y2;
+    geom[i * 4 + 0] = x1; geom[i * 4 + 1] = x1p; geom[i * 4 + 2] = x1 + mw; geom[i * 4 + 3] = x1p + mw;
+}
+
+inline unsigned grid_for(long work) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int drc_roi_align_fwd(const float* input, const float* rois, float* out, int K, int C, int H, int W, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, const float* mean, const float* stdv, void* stream) {
+    if (K < 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || sampling_ratio < 0) return -2;
+    if ((mean == nullptr) != (stdv == nullptr)) return -2;
+    if (K == 0) return 0;   // empty rois -> empty output, nothing launched (ROIAlign_cuda.cu:278-281)
+    if (!input || !rois || !out) return -1;
+    const long total = (long)K * C * PH * PW;
+    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, input, rois, out, K, C, H, W,
+                       PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+    return (int)hipGetLastError();
+}
+
+int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, int K, int C, int H, int W, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, void* stream) {
+    if (K < 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || sampling_ratio < 0) return -2;
+    if (K == 0) return 0;
+    if (!grad_out || !rois || !grad_in) return -1;   // grad_in must be zero-filled by the caller
+    const long total = (long)K * C * PH * PW;
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, grad_out, rois, grad_in, K, C,
+                       H, W, PH, PW, spatial_scale, sampling_ratio);
+    return (int)hipGetLastError();
+}
+
+int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const int32_t* img_idx, int R, int img_w, int img_h,
+                        float* rois_left, float* rois_right, int32_t* geom, void* stream) {
+    if (R < 0 || img_w <= 0 || img_h <= 0) return -2;
+    if (R == 0) return 0;
+    if (!left_boxes || !right_boxes || !img_idx || !rois_left || !rois_right || !geom) return -1;
+    hipLaunchKernelGGL(align_roi_pairs_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, left_boxes, right_boxes, img_idx, R,
+                       img_w, img_h, rois_left, rois_right, geom);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,1 @@
+from .roi_align import ROIAlign, roi_align  # noqa: F401

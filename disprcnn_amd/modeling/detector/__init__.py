@@ -1,0 +1,2 @@
+from .detectors import build_detection_model  # noqa: F401
+from .disprcnn3d import DispRCNN3D  # noqa: F401

@@ -1,0 +1,2 @@
+from .bounding_box import BoxList  # noqa: F401
+from .image_list import ImageList, to_image_list  # noqa: F401

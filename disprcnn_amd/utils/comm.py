@@ -1,0 +1,66 @@
+"""Distributed helpers (reference: disprcnn/utils/comm.py:12-116), RCCL over xGMI on MI355X (backend "nccl"), gloo on CPU.
+
+ROIs (and images) are independent units: inference shards them across ranks with NO collective in the compute path;
+the only exchange is one tensor ``all_gather`` of the [R,H,W] disparities at the end, replacing the reference's
+pickle-over-NCCL gather (comm.py:47-87)."""
+import torch
+import torch.distributed as dist
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def synchronize():
+    """Barrier; no-op for world size 1 (reference comm.py:34-44)."""
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def shard_range(n_items, rank=None, world=None):
+    """Contiguous, balanced shard [lo,hi) of n_items for this rank (sizes differ by at most 1; empty shards allowed)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(t):
+    """Gather tensors that differ only in dim 0 from every rank and concatenate them in rank order.
+    Two collectives: sizes (int64[1]) then zero-padded payloads -- tensors, not pickles."""
+    world = get_world_size()
+    if world == 1:
+        return t
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    pad = t.new_zeros((mx,) + tuple(t.shape[1:]))
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+
+
+def reduce_dict(d, average=True):
+    """Reduce a dict of scalar tensors to rank 0 (reference comm.py:90-116, trainer.py:19-41)."""
+    world = get_world_size()
+    if world < 2:
+        return d
+    with torch.no_grad():
+        names = sorted(d)
+        vals = torch.stack([d[k] for k in names], 0)
+        dist.reduce(vals, dst=0)
+        if dist.get_rank() == 0 and average:
+            vals = vals / world
+        return dict(zip(names, vals))

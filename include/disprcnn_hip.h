@@ -140,6 +140,37 @@ int drc_bilinear_up_blocked(const float* x, float* y, int N, int CB, int IH, int
 int drc_copy_blocks(const float* x, float* y, int N, int CB, int64_t vox_per_cb,
                     int y_cb_total, int y_cb_off, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * f1. ROIAlign (the crop in front of the path) -- replaces disprcnn._C.roi_align_forward / roi_align_backward
+ * (csrc/vision.cpp:7-15, csrc/ROIAlign.h:11-45, csrc/cpu/ROIAlign_cpu.cpp:113-219, csrc/cuda/ROIAlign_cuda.cu:64-122,177-254).
+ *   input [B,C,H,W]; rois [K,5] = (batch index, x1, y1, x2, y2); out [K,C,PH,PW].
+ * No rounding of roi coordinates, roi size clamped to >= 1, sampling grid = sampling_ratio or ceil(roi/pooled),
+ * samples outside [-1, size] contribute 0.  mean/stdv (per channel, both or neither) fuse the ImageNet normalisation
+ * of DispRCNN3D.crop_and_transform_roi_img (disprcnn3d.py:44-50) into the crop.
+ * Backward accumulates with atomicAdd into grad_in, which the caller zero-fills. */
+int drc_roi_align_fwd(const float* input, const float* rois, float* out, int K, int C, int H, int W, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, const float* mean, const float* stdv, void* stream);
+int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, int K, int C, int H, int W, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, void* stream);
+
+/* Left/right ROI alignment of DispRCNN3D.prepare_psmnet_input_and_target (disprcnn3d.py:118-146) on the device:
+ * expand_box_to_integer (stereo_utils.py:219-229), clamps, common width.
+ *   left/right_boxes [R,4] xyxy, img_idx [R]  ->  rois_left/right [R,5] for drc_roi_align_fwd,
+ *   geom [R,4] = (x1, x1p, x1+mw, x1p+mw)  (the x1s, x1ps, x2s, x2ps of the reference) */
+int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const int32_t* img_idx, int R, int img_w, int img_h,
+                        float* rois_left, float* rois_right, int32_t* geom, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a10. PSMLoss / EndPointErrorLoss (utils/loss_utils.py:9-32, utils/stereo_utils.py:185-208).
+ *   sums5 (caller-zeroed) += { sum m*smoothl1(p1-t), sum m*smoothl1(p2-t), sum m*smoothl1(p3-t), sum m, sum m*|p1-t| }
+ *   (pred2/pred3 may be NULL for the eval form).  The scalar loss is assembled by the caller:
+ *   train: 0.5*s0/s3 + 0.7*s1/s3 + s2/s3 (division skipped when s3 == 0); eval: s4/s3 (0 when s3 == 0).
+ *   grad:  grad_pred = grad_scale[0] * weight * m * clamp(pred - t, -1, 1) / s3 */
+int drc_psm_loss_sums(const float* pred1, const float* pred2, const float* pred3, const float* target, const uint8_t* mask,
+                      int64_t numel, float* sums5, void* stream);
+int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mask, int64_t numel, const float* sums5, float weight,
+                      const float* grad_scale, float* grad_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

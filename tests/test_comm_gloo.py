@@ -1,0 +1,64 @@
+"""world_size-2 gloo test (CPU) of the N>1 path: ROI sharding without a data-path collective + one tensor all_gather."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from disprcnn_amd.utils import comm
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_rois, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert comm.get_world_size() == world and comm.get_rank() == rank and comm.is_main_process() == (rank == 0)
+        lo, hi = comm.shard_range(n_rois)
+        # stand-in for the per-ROI work: every ROI i yields a [H,W] map filled with i (independent units, no exchange)
+        local = torch.stack([torch.full((3, 4), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros(0, 3, 4)
+        comm.synchronize()
+        full = comm.all_gather_rows(local)
+        red = comm.reduce_dict({"loss": torch.tensor(float(rank + 1))})
+        q.put((rank, lo, hi, full[:, 0, 0].tolist(), float(red["loss"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(n_rois):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_rois, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_shard_and_gather_two_ranks():
+    res = _run(7)
+    (r0, lo0, hi0, g0, l0), (r1, lo1, hi1, g1, l1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)                 # balanced contiguous shards
+    assert g0 == g1 == [float(i) for i in range(7)]             # gathered in rank order, ragged sizes handled
+    assert abs(l0 - 1.5) < 1e-6                                 # reduce_dict averages on rank 0
+
+
+def test_empty_shard_is_handled():
+    res = _run(1)                                               # rank 1 owns nothing: must still join the collectives
+    assert res[0][3] == res[1][3] == [0.0]
+
+
+def test_single_process_fallbacks():
+    assert comm.get_world_size() == 1 and comm.get_rank() == 0 and comm.is_main_process()
+    comm.synchronize()
+    t = torch.arange(6.).view(2, 3)
+    assert torch.equal(comm.all_gather_rows(t), t)
+    assert comm.shard_range(10, 2, 4) == (6, 8) and comm.shard_range(2, 3, 4) == (2, 2)

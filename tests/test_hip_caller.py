@@ -1,0 +1,125 @@
+"""GPU parity tests for the rows around the path: ROIAlign crop (f1), ROI pairing + DispRCNN3D caller (a11), losses (a10)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import psmnet_oracle as O
+from oracle import roi_oracle as R
+from disprcnn_amd.utils import synth
+from tests.helpers import state_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_roi_align_vs_oracle(dev):
+    from disprcnn_amd.layers import ROIAlign
+    img = synth.hash_uniform("roi:img", (2, 3, 37, 53), 0.0, 1.0)
+    rois = torch.tensor([[0, 3.2, 4.7, 30.9, 28.1], [1, 10.0, 5.0, 24.0, 33.0], [0, -4.0, -3.0, 20.0, 12.0],
+                         [1, 40.0, 20.0, 60.0, 45.0], [0, 8.0, 8.0, 6.0, 7.0], [1, 0.0, 0.0, 52.0, 36.0]])
+    for (ph, pw, sr, scale) in [(7, 7, 2, 1.0), (6, 5, 0, 1.0), (14, 14, 0, 0.5), (3, 4, 1, 0.25)]:
+        ref = R.roi_align(img.numpy(), rois.numpy(), scale, ph, pw, sr)
+        got = ROIAlign((ph, pw), scale, sr)(img.to(dev), rois.to(dev)).cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 2e-6, (ph, pw, sr, np.abs(got - ref).max())
+    empty = ROIAlign((7, 7), 1.0, 2)(img.to(dev), torch.zeros(0, 5, device=dev))
+    assert tuple(empty.shape) == (0, 3, 7, 7)
+
+
+def test_roi_align_backward_is_adjoint(dev):
+    """<roi_align(x), g> == <x, roi_align_backward(g)> (the forward is linear in x)."""
+    from disprcnn_amd.layers.roi_align import roi_align
+    x = synth.hash_uniform("roi:x", (2, 2, 20, 24)).to(dev).requires_grad_(True)
+    rois = torch.tensor([[0, 2.5, 3.5, 17.0, 15.2], [1, 0.0, 1.0, 23.0, 19.0]], device=dev)
+    y = roi_align(x, rois, (5, 6), 1.0, 0)
+    g = synth.hash_uniform("roi:g", tuple(y.shape)).to(dev)
+    y.backward(g)
+    lhs = (y.detach() * g).sum().item()
+    rhs = (x.detach() * x.grad).sum().item()
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_align_roi_pairs_and_crops_vs_oracle(dev):
+    from disprcnn_amd.modeling.detector.disprcnn3d import DispRCNN3D, default_cfg
+    from disprcnn_amd.structures import BoxList, ImageList
+    W, H, res = 160, 96, 32
+    model = DispRCNN3D(default_cfg(resolution=res)).to(dev).eval()
+    limg = synth.hash_uniform("cal:L", (2, 3, H, W), 0.0, 1.0)
+    rimg = synth.hash_uniform("cal:R", (2, 3, H, W), 0.0, 1.0)
+    lboxes = [torch.tensor([[10.3, 5.8, 50.2, 40.1], [-3.0, -2.0, 170.0, 120.0]]), torch.tensor([[100.5, 20.2, 158.9, 90.7]])]
+    rboxes = [torch.tensor([[2.9, 6.0, 44.5, 40.0], [120.5, 0.0, 159.9, 99.0]]), torch.tensor([[90.1, 20.0, 140.0, 91.0]])]
+    lres = [BoxList(b, (W, H)) for b in lboxes]
+    rres = [BoxList(b, (W, H)) for b in rboxes]
+    left, right, geom = model.prepare_psmnet_input(ImageList(limg.to(dev), [(H, W)] * 2), ImageList(rimg.to(dev), [(H, W)] * 2), lres, rres)
+    rois_l, rois_r, gexp = [], [], []
+    for i, (lb, rb) in enumerate(zip(lboxes, rboxes)):
+        for l, r in zip(lb.tolist(), rb.tolist()):
+            x1, y1, x1p, y2, mw = R.align_roi_pair(l, r, W, H)
+            rois_l.append([i, x1, y1, x1 + mw, y2]); rois_r.append([i, x1p, y1, x1p + mw, y2]); gexp.append([x1, x1p, x1 + mw, x1p + mw])
+    assert geom.cpu().tolist() == gexp
+    ref_l = R.crop_and_normalise(limg.numpy(), np.array(rois_l, dtype=np.float32), res)
+    ref_r = R.crop_and_normalise(rimg.numpy(), np.array(rois_r, dtype=np.float32), res)
+    assert np.abs(left.cpu().numpy() - ref_l).max() < 2e-5 and np.abs(right.cpu().numpy() - ref_r).max() < 2e-5
+
+
+def test_disprcnn3d_eval_end_to_end(dev):
+    """images + detections -> 'disparity' field, vs the oracle pipeline (crop oracle -> PSMNet oracle)."""
+    from disprcnn_amd.modeling.detector import build_detection_model
+    from disprcnn_amd.modeling.detector.disprcnn3d import default_cfg
+    from disprcnn_amd.structures import BoxList, ImageList
+    W, H, res = 320, 256, 224
+    model = build_detection_model(default_cfg(48, -48, res))
+    sd = state_for("B")
+    model.dispnet.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    # smooth images (coarse noise upsampled) so the crops look like image content rather than white noise
+    base_l = synth.hash_uniform("e2e:L", (1, 3, H // 8, W // 8), 0.0, 1.0)
+    limg = torch.nn.functional.interpolate(base_l, (H, W), mode="bilinear", align_corners=True)
+    rimg = torch.roll(limg, -5, 3)
+    lb = torch.tensor([[20.4, 10.2, 200.7, 180.3], [0.5, 0.5, 1.2, 1.4]])      # second box is illegal (w,h <= 1): removed
+    rb = torch.tensor([[14.9, 10.0, 195.2, 181.0], [0.5, 0.5, 1.2, 1.4]])
+    lres, rres = [BoxList(lb, (W, H))], [BoxList(rb, (W, H))]
+    with torch.no_grad():
+        out = model({"left": ImageList(limg.to(dev), [(H, W)]), "right": ImageList(rimg.to(dev), [(H, W)])}, {"left": lres, "right": rres})
+    disp = out["left"][0].get_field("disparity").cpu()
+    assert tuple(disp.shape) == (1, res, res) and len(out["left"][0]) == 1
+    x1, y1, x1p, y2, mw = R.align_roi_pair(lb[0].tolist(), rb[0].tolist(), W, H)
+    assert out["left"][0].get_field("roi_geom").cpu().tolist() == [[x1, x1p, x1 + mw, x1p + mw]]
+    cl = torch.from_numpy(R.crop_and_normalise(limg.numpy(), np.array([[0, x1, y1, x1 + mw, y2]], dtype=np.float32), res))
+    cr = torch.from_numpy(R.crop_and_normalise(rimg.numpy(), np.array([[0, x1p, y1, x1p + mw, y2]], dtype=np.float32), res))
+    with torch.no_grad():
+        ref = O.psmnet_forward(sd, cl, cr, 48, -48)
+    err = (disp - ref).abs()
+    assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
+    # empty detections -> empty field, no launch (reference disprcnn3d.py:272-275)
+    out = model({"left": ImageList(limg.to(dev), [(H, W)]), "right": ImageList(rimg.to(dev), [(H, W)])},
+                {"left": [BoxList(torch.zeros(0, 4), (W, H))], "right": [BoxList(torch.zeros(0, 4), (W, H))]})
+    assert tuple(out["left"][0].get_field("disparity").shape) == (0, res, res)
+
+
+def test_psm_loss_forward_backward_vs_oracle(dev):
+    from disprcnn_amd.utils.loss_utils import PSMLoss, EndPointErrorLoss
+    shape = (3, 40, 56)
+    tgt = synth.hash_uniform("loss:t", shape, -48.0, 48.0)
+    mask = (synth.hash_uniform("loss:m", shape, 0.0, 1.0) > 0.4).to(torch.uint8)
+    preds = [tgt + synth.hash_uniform(f"loss:p{k}", shape, -3.0, 3.0) for k in range(3)]
+    ref_in = [p.clone().requires_grad_(True) for p in preds]
+    ref = O.psm_loss(ref_in, tgt, mask)
+    ref.backward()
+    got_in = [p.to(dev).requires_grad_(True) for p in preds]
+    got = PSMLoss()(tuple(got_in), {"disparity": tgt.to(dev), "mask": mask.to(dev)})
+    (got * 2.0).backward()
+    assert abs(got.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    for a, b in zip(got_in, ref_in):
+        assert (a.grad.cpu() - 2.0 * b.grad).abs().max().item() < 1e-7
+    # eval form (EPE) and the empty-mask conventions (train: no division; eval: 0)
+    epe = EndPointErrorLoss()(tgt.to(dev), preds[0].to(dev), mask.to(dev))
+    assert abs(epe.item() - O.psm_loss(preds[0], tgt, mask).item()) < 1e-5
+    zero = torch.zeros(shape, dtype=torch.uint8, device=dev)
+    assert EndPointErrorLoss()(tgt.to(dev), preds[0].to(dev), zero).item() == 0.0
+    assert PSMLoss()(tuple(p.to(dev) for p in preds), {"disparity": tgt.to(dev), "mask": zero}).item() == 0.0

@@ -1,0 +1,54 @@
+"""Known-answer tests that pin the ROIAlign / ROI-pairing oracle (no reference binary exists for them; see oracle/roi_oracle.py)."""
+import numpy as np
+
+from oracle import roi_oracle as R
+
+
+def _affine(B, C, H, W):
+    y, x = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.stack([np.stack([(0.5 + c) * x + (1.5 - 0.25 * c) * y + 3.0 * c + b for c in range(C)]) for b in range(B)])
+    return img.astype(np.float32)
+
+
+def test_affine_image_is_sampled_exactly():
+    """Bilinear interpolation is exact on affine images away from the border, so each output equals the image
+    function at the bin centre -- a closed-form answer for arbitrary (non-integer) rois and adaptive sampling grids."""
+    img = _affine(2, 2, 40, 50)
+    rois = np.array([[0, 3.2, 4.7, 30.9, 28.1], [1, 10.0, 5.0, 24.0, 33.0]], dtype=np.float32)
+    out = R.roi_align(img, rois, 1.0, 6, 7, 0)
+    for k, (b, x1, y1, x2, y2) in enumerate(rois):
+        bw, bh = (x2 - x1) / 7, (y2 - y1) / 6
+        for c in range(2):
+            for i in range(6):
+                for j in range(7):
+                    cx, cy = x1 + (j + 0.5) * bw, y1 + (i + 0.5) * bh     # mean of the symmetric sample grid = bin centre
+                    exp = (0.5 + c) * cx + (1.5 - 0.25 * c) * cy + 3.0 * c + int(b)
+                    assert abs(out[k, c, i, j] - exp) < 2e-3
+
+
+def test_constant_and_malformed_roi_clamped_to_1x1():
+    img = np.full((1, 1, 8, 8), 5.0, dtype=np.float32)
+    out = R.roi_align(img, np.array([[0, 4.0, 4.0, 2.0, 1.0]], dtype=np.float32), 1.0, 2, 2, 2)   # x2<x1, y2<y1 -> 1x1 roi
+    assert np.allclose(out, 5.0)
+    ramp = _affine(1, 1, 8, 8)
+    out = R.roi_align(ramp, np.array([[0, 4.0, 4.0, 2.0, 1.0]], dtype=np.float32), 1.0, 1, 1, 1)
+    assert abs(out[0, 0, 0, 0] - (0.5 * 4.5 + 1.5 * 4.5)) < 1e-4                                   # centre of the clamped 1x1 roi
+
+
+def test_samples_outside_contribute_zero_and_grid_is_ceil():
+    img = np.ones((1, 1, 10, 10), dtype=np.float32)
+    # roi far outside to the right: every sample has x > W -> 0
+    assert np.all(R.roi_align(img, np.array([[0, 20.0, 2.0, 26.0, 6.0]], dtype=np.float32), 1.0, 2, 2, 0) == 0)
+    # roi half outside on the left (x in [-6, 2)): with a 1-wide output and grid ceil(8/1)=8, samples at x=-5.5..1.5;
+    # x < -1 contribute 0 (5 samples), -1 <= x <= 0 clamp to column 0 (1 sample), 2 inside -> mean = 3/8
+    out = R.roi_align(img, np.array([[0, -6.0, 2.0, 2.0, 3.0]], dtype=np.float32), 1.0, 1, 1, 0)
+    assert abs(out[0, 0, 0, 0] - 3.0 / 8.0) < 1e-6
+
+
+def test_align_roi_pair_matches_reference_arithmetic():
+    # left [10.3,5.8,50.2,40.1] -> (10,5,51,41); right [2.9,6,44.5,40] -> x1p=2, x2p=45; width 1242, height 375
+    x1, y1, x1p, y2, mw = R.align_roi_pair([10.3, 5.8, 50.2, 40.1], [2.9, 6.0, 44.5, 40.0], 1242, 375)
+    assert (x1, y1, x1p, y2, mw) == (10, 5, 2, 41, 43)
+    # clamps: negative coordinates, bottom/right borders, width limited by the image edge
+    x1, y1, x1p, y2, mw = R.align_roi_pair([-3.0, -2.0, 1300.0, 400.0], [1200.5, 0.0, 1241.9, 380.0], 1242, 375)
+    assert (x1, y1, x1p, y2) == (0, 0, 1200, 374) and mw == min(max(1241 - 0, 1241 - 1200), min(1242 - 0, 1242 - 1200))
