@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rois", type=int, default=64, help="ROI pairs per step per GPU")
+    ap.add_argument("--rois", type=int, default=128, help="ROI pairs per step per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Config-B extra measurement")
     args = ap.parse_args()
@@ -134,8 +134,19 @@ def main():
         dom = max(agg, key=lambda k: agg[k][1])
         calls, secs, flops = agg[dom]
         achieved = flops / secs / 1e12
+        # HBM bytes per launch of the same kernel from the committed PMC pass of this command (profiles/collect.sh):
+        # FETCH_SIZE (x2: gfx950 128-B request correction) + WRITE_SIZE; null if that profile is absent
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            key = [k for k in tj if k.replace(" ", "") == dom.replace(" ", "")]
+            if key:
+                traffic = round(tj[key[0]]["fetch_bytes_corrected"] + tj[key[0]]["write_bytes"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate pass; profiles/r1_pmc.md)",
                     "calls_per_step": calls // args.steps, "avg_launch_us": round(secs / calls * 1e6, 2),
                     "algorithmic_flops_per_launch": flops / calls}
         extra["kernels"] = {k: {"calls_per_step": v[0] // args.steps, "avg_us": round(v[1] / v[0] * 1e6, 2),
