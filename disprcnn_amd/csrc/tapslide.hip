@@ -1,0 +1,297 @@
+// tapslide.hip -- stride-1 3x3x3 convolution (+BN, +residual, +ReLU) with a SLIDING DEPTH WINDOW (gfx950 / CDNA4).
+//
+// Same arithmetic, layouts and MFMA mapping as tapconv.hip (v_mfma_f32_16x16x4_f32, blocked zero-haloed tensors,
+// LDS-DMA staged [rows][voxels][8 ch] tiles), specialised for the layers that carry ~70 % of the regressor's FLOPs:
+//   dres0/dres1, classifN[0], hourglass conv2/conv4            reference: stackhourglass.py:63-88, :14-20
+//
+// A wave owns a COLUMN: R output rows x WT columns of ALL depth slices of one ROI.  It walks the input slices once;
+// every staged tile is applied to the three output slices it touches (depth taps dd = 0,1,2 -> od = d_in+1-dd), which
+// keeps three accumulator sets live and rotates them without runtime indexing (the slice loop is unrolled by 3).
+// Versus one-output-slice-per-wave this stages 3x fewer bytes per MFMA and reads each B fragment from LDS once for
+// three depth taps; the all-zero halo slices are never staged or multiplied.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define SLIDE_WAVES 4
+
+namespace {
+
+template <int VT, int CT>
+__global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_tapconv_params p, const int seg_len) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int g = lane >> 4;
+
+    const drc_tap_class cls = p.cls[0];
+    const int n_wt = (p.OW + p.WT - 1) / p.WT;
+    const int n_rt = (p.OH + p.R - 1) / p.R;
+    const int cols = p.N * n_rt * n_wt;            // columns = (n, row tile, col tile); the wave walks all OD slices
+    int cid = blockIdx.x * SLIDE_WAVES + wave;
+    if (cid >= cols) return;                       // wave-uniform; no workgroup barrier in this kernel
+    const int wt = cid % n_wt; cid /= n_wt;
+    const int rt = cid % n_rt;
+    const int n = cid / n_rt;
+    const int oh0 = rt * p.R, ow0 = wt * p.WT;
+    const int ct0 = blockIdx.y * CT;
+    const int D = p.OD;
+    // depth segment of this wave: outputs od in [od_lo, od_hi); it reads input slices od_lo-1 .. od_hi (clipped to the volume)
+    const int od_lo = blockIdx.z * seg_len;
+    const int od_hi = od_lo + seg_len < D ? od_lo + seg_len : D;
+    const int din_lo = od_lo > 0 ? od_lo - 1 : 0;
+    const int din_hi = od_hi < D ? od_hi : D - 1;      // inclusive
+
+    const int rows_in = p.R + 2;
+    const int seg_vox = p.WT + 2;
+    const int seg_floats = seg_vox * 8;
+    const int seg_units = seg_vox * 2;
+    const int buf_floats = rows_in * seg_floats;
+    float* lds = lds_all + wave * (p.lds_bytes_per_wave >> 2);
+    const int nslots = p.R * p.WT;
+
+    int lane_off[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+        const int s = vt * 16 + j;
+        int r = s / p.WT, c = s - r * p.WT;
+        if (s >= nslots) { r = 0; c = 0; }
+        lane_off[vt] = (r * seg_vox + c) * 8 + g * 2;
+    }
+
+    // input origin of the column at padded depth index 0 (row oh0+dh0, col ow0+dw0)
+    const float* xcol = p.x + (int64_t)n * p.x_n_stride + (int64_t)(oh0 + cls.dh0) * p.x_h_stride + (int64_t)(ow0 + cls.dw0) * 16;
+    const int n_pc = p.cb_in * 2;                  // (channel block, half) phases per input slice
+
+    // LDS-DMA rows [r0,r1) of the tile (input slice d_in, phase pc) into tile buffer bufi
+    auto stage_rows = [&](int d_in, int pc, int bufi, int r0, int r1) {
+        const int h = pc & 1, cb = pc >> 1;
+        const float* src = xcol + (int64_t)cb * p.x_cb_stride + (int64_t)(d_in + cls.dd0 + 1) * p.x_d_stride + h * 8;   // real slice d_in sits at padded depth d_in + dd0 + 1
+        float* dst = lds + bufi * buf_floats;
+        for (int r = r0; r < r1; ++r) {
+            const float* srow = src + (int64_t)r * p.x_h_stride;
+            float* drow = dst + r * seg_floats;
+            for (int u0 = 0; u0 < seg_units; u0 += 64) {
+                const int u = u0 + lane;
+                if (u < seg_units)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srow + (u >> 1) * 16 + (u & 1) * 4), LDS_PTR(drow + u0 * 4), 16, 0, 0);
+            }
+        }
+    };
+    const int rows_per_step = (rows_in + 7) / 8;   // 9 taps per phase: rows go out during taps 0..7
+
+    // weights: packed [widx = (kd*3+kh)*3+kw][cb*2+half][cout_pad][8]
+    const float* wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 8 + g * 2;
+    const int64_t w_half_stride = (int64_t)p.cout_pad * 8;
+    const int64_t w_tap_stride = w_half_stride * n_pc;
+
+    f32x4 bn_sc[CT], bn_sh[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
+        bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
+    }
+
+    f32x4 acc0[VT][CT], acc1[VT][CT], acc2[VT][CT];   // three output slices in flight
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { acc0[vt][ct] = acc1[vt][ct] = acc2[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // epilogue of output slice od from accumulator set ACC, then clear the set
+#define SLIDE_EPILOGUE(OD, ACC)                                                                        \
+    {                                                                                                  \
+        _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) {                                            \
+            const int s_ = vt * 16 + j;                                                                \
+            const int r_ = s_ / p.WT, c_ = s_ - r_ * p.WT;                                             \
+            const bool valid_ = (s_ < nslots) && (oh0 + r_ < p.OH) && (ow0 + c_ < p.OW);               \
+            if (valid_) {                                                                              \
+                const int64_t yo_ = p.y_off0 + (int64_t)n * p.y_n_stride + (int64_t)(OD) * p.y_d_stride + \
+                                    (int64_t)(oh0 + r_) * p.y_h_stride + (int64_t)(ow0 + c_) * 16 + g * 4; \
+                const int64_t ro_ = p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)(OD) * p.r_d_stride + \
+                                    (int64_t)(oh0 + r_) * p.r_h_stride + (int64_t)(ow0 + c_) * 16 + g * 4; \
+                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                    \
+                    f32x4 v_ = ACC[vt][ct] * bn_sc[ct] + bn_sh[ct];                                    \
+                    if (p.res) v_ += *(const f32x4*)(p.res + ro_ + (int64_t)(ct0 + ct) * p.r_cb_stride); \
+                    if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); } \
+                    *(f32x4*)(p.y + yo_ + (int64_t)(ct0 + ct) * p.y_cb_stride) = v_;                  \
+                }                                                                                      \
+            }                                                                                          \
+            _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) ACC[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; \
+        }                                                                                              \
+    }
+
+#define SLIDE_MFMA(ACC, W, B, KK)                                                                      \
+    _Pragma("unroll") for (int vt = 0; vt < VT; ++vt)                                                  \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
+            ACC[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[ct][KK], B[vt][KK], ACC[vt][ct], 0, 0, 0);
+
+    // weights of step (pc, tap t) for the three depth taps: widx = (dd*3+kh)*3+kw = dd*9 + t
+    f32x2 wA[3][CT], wB[3][CT], bA[VT], bB[VT];
+    auto load_w = [&](f32x2 (&W)[3][CT], int pc, int t) {
+        const float* wp = wlane + (int64_t)t * w_tap_stride + (int64_t)pc * w_half_stride;
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) W[dd][ct] = *(const f32x2*)(wp + (int64_t)dd * 9 * w_tap_stride + ct * 128);
+    };
+
+    int bufsel = 0;
+    stage_rows(din_lo, 0, 0, 0, rows_in);
+    load_w(wA, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+// one tap step of input slice d_in: accumulate into (dd=0 -> A0 if v0), (dd=1 -> A1 if v1), (dd=2 -> A2 if v2).
+// Interior slices (v1) issue the prefetch behind the first MFMAs of the dd=1 block; the two edge slices of a depth
+// segment (v1 false) prefetch first and accept the wait.
+#define SLIDE_PREFETCH(T, W_LD, B_LD)                                                                  \
+        if (st_on) {                                                                                   \
+            const int r0_ = (T) * rows_per_step;                                                       \
+            if (r0_ < rows_in) stage_rows(st_d, st_pc, bufsel ^ 1, r0_, r0_ + rows_per_step < rows_in ? r0_ + rows_per_step : rows_in); \
+        }                                                                                              \
+        {                                                                                              \
+            const bool in_ph_ = (T) + 1 < 9;                                                           \
+            const int tn_ = in_ph_ ? (T) + 1 : 0;                                                      \
+            load_w(W_LD, in_ph_ ? pc : nx_pc, tn_);                                                    \
+            const int to_ = in_ph_ ? ((tn_ / 3) * seg_vox + (tn_ % 3)) * 8 : 0;                        \
+            _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x2*)(buf + lane_off[vt] + to_); \
+        }
+
+#define SLIDE_STEP(T, W_USE, B_USE, W_LD, B_LD, A0, A1, A2)                                            \
+    {                                                                                                  \
+        /* first tile row of the dd=1 block is unconditional: it carries the operand wait; on the two edge slices  \
+           of a depth segment (v1 false) it feeds a set that is cleared before its next use */          \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
+            A1[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[1][ct][0], B_USE[0][0], A1[0][ct], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        SLIDE_PREFETCH(T, W_LD, B_LD)                                                                  \
+        if (v1) {                                                                                      \
+            _Pragma("unroll") for (int vt = 1; vt < VT; ++vt)                                          \
+                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                      \
+                    A1[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[1][ct][0], B_USE[vt][0], A1[vt][ct], 0, 0, 0); \
+            SLIDE_MFMA(A1, W_USE[1], B_USE, 1)                                                         \
+        }                                                                                              \
+        if (v0) { SLIDE_MFMA(A0, W_USE[0], B_USE, 0) SLIDE_MFMA(A0, W_USE[0], B_USE, 1) }              \
+        if (v2) { SLIDE_MFMA(A2, W_USE[2], B_USE, 0) SLIDE_MFMA(A2, W_USE[2], B_USE, 1) }              \
+    }
+
+// all phases of input slice d_in; afterwards output slice d_in-1 (set A2) is complete
+#define SLIDE_SLICE(A0, A1, A2)                                                                        \
+    {                                                                                                  \
+        const bool v0 = d_in + 1 >= od_lo && d_in + 1 < od_hi;                                         \
+        const bool v1 = d_in >= od_lo && d_in < od_hi;                                                 \
+        const bool v2 = d_in - 1 >= od_lo && d_in - 1 < od_hi;                                         \
+        for (int pc = 0; pc < n_pc; ++pc) {                                                            \
+            const float* buf = lds + bufsel * buf_floats;                                              \
+            const bool last_pc = pc + 1 == n_pc;                                                       \
+            const bool st_on = !last_pc || (d_in + 1 <= din_hi);                                       \
+            const int st_d = last_pc ? d_in + 1 : d_in, st_pc = last_pc ? 0 : pc + 1;                  \
+            const int nx_pc = st_pc;                                                                   \
+            _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x2*)(buf + lane_off[vt]); \
+            for (int t = 0; t < 8; t += 2) {                                                           \
+                SLIDE_STEP(t, wA, bA, wB, bB, A0, A1, A2)                                              \
+                SLIDE_STEP(t + 1, wB, bB, wA, bA, A0, A1, A2)                                          \
+            }                                                                                          \
+            SLIDE_STEP(8, wA, bA, wB, bB, A0, A1, A2)                                                  \
+            _Pragma("unroll") for (int dd = 0; dd < 3; ++dd)                                           \
+                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) wA[dd][ct] = wB[dd][ct];             \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+            bufsel ^= 1;                                                                               \
+        }                                                                                              \
+        if (v2) SLIDE_EPILOGUE(d_in - 1, A2)                                                           \
+        else { _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) A2[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+        if (v1 && d_in + 1 == D) SLIDE_EPILOGUE(d_in, A1)                                              \
+    }
+
+    // output od lives in set (od mod 3): slice d_in feeds dd0 -> set (d_in+1)%3, dd1 -> d_in%3, dd2 -> (d_in+2)%3.
+    // The loop is unrolled by 3 so the sets rotate without runtime indexing; it starts at the right phase for din_lo.
+    for (int d_in = din_lo - din_lo % 3;;) {
+        if (d_in >= din_lo) SLIDE_SLICE(acc1, acc0, acc2)
+        if (++d_in > din_hi) break;
+        if (d_in >= din_lo) SLIDE_SLICE(acc2, acc1, acc0)
+        if (++d_in > din_hi) break;
+        if (d_in >= din_lo) SLIDE_SLICE(acc0, acc2, acc1)
+        if (++d_in > din_hi) break;
+    }
+#undef SLIDE_SLICE
+#undef SLIDE_STEP
+#undef SLIDE_PREFETCH
+#undef SLIDE_MFMA
+#undef SLIDE_EPILOGUE
+}
+
+template <int VT, int CT>
+int launch(const drc_tapconv_params& p, hipStream_t stream) {
+    const long cols = (long)p.N * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
+    const size_t lds = (size_t)p.lds_bytes_per_wave * SLIDE_WAVES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)tapslide_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    // depth segments: one wave per column when that already fills the SIMDs, otherwise split D (each segment re-stages
+    // its two neighbouring slices) until every SIMD has a wave; segments stay >= 3 slices long
+    static int occ_blocks = 0;   // per-instantiation, idempotent
+    if (!occ_blocks) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tapslide_kernel<VT, CT>, 64 * SLIDE_WAVES, lds) != hipSuccess || nb < 1) nb = 1;
+        occ_blocks = nb;
+    }
+    const long waves = cols * (p.cout_pad / 16 / CT);
+    const long slots = 256L * SLIDE_WAVES * occ_blocks;
+    int nseg = (int)(slots / (waves > 0 ? waves : 1));
+    if (nseg < 1) nseg = 1;
+    if (nseg > p.OD / 3) nseg = p.OD / 3 > 0 ? p.OD / 3 : 1;
+    const int seg_len = (p.OD + nseg - 1) / nseg;
+    nseg = (p.OD + seg_len - 1) / seg_len;
+    dim3 grid((unsigned)((cols + SLIDE_WAVES - 1) / SLIDE_WAVES), (unsigned)(p.cout_pad / 16 / CT), (unsigned)nseg);
+    hipLaunchKernelGGL((tapslide_kernel<VT, CT>), grid, dim3(64 * SLIDE_WAVES), lds, stream, p, seg_len);
+    return (int)hipGetLastError();
+}
+
+template <int CT>
+int launch_vt(int nvt, const drc_tapconv_params& p, hipStream_t s) {
+    switch (nvt) {
+        case 1: return launch<1, CT>(p, s);
+        case 2: return launch<2, CT>(p, s);
+        case 3: return launch<3, CT>(p, s);
+        case 4: return launch<4, CT>(p, s);
+        case 5: return launch<5, CT>(p, s);
+        case 6: return launch<6, CT>(p, s);
+        case 7: return launch<7, CT>(p, s);
+    }
+    return -3;
+}
+
+}  // namespace
+
+extern "C" int drc_tapconv3d_slide_fwd(const drc_tapconv_params* pp, int cout_tiles_per_wave, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
+    if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 112) return -3;
+    const drc_tap_class& k = p.cls[0];
+    // only the stride-1 3x3x3 class with unit tap spacing and halo 1 in depth
+    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 ||
+        k.sw != 1 || k.wbase != 0 || k.wsd != 9 || k.wsh != 3 || k.wsw != 1)
+        return -4;
+    const int need = (p.R + 2) * (p.WT + 2) * 32 * 2;
+    if (p.lds_bytes_per_wave < need || (p.lds_bytes_per_wave & 15) || (size_t)p.lds_bytes_per_wave * SLIDE_WAVES > 160 * 1024) return -5;
+    const int ct = p.cout_pad / 16;
+    const int CT = cout_tiles_per_wave;
+    if ((CT != 1 && CT != 2) || ct % CT) return -2;
+    const int nvt = (p.R * p.WT + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    return CT == 2 ? launch_vt<2>(nvt, p, s) : launch_vt<1>(nvt, p, s);
+}

@@ -16,6 +16,7 @@ SLACK_FLOATS = 1 << 16          # over-read room behind every blocked tensor (ra
 LDS_PER_WAVE_MAX = 38 * 1024    # 4 waves/block -> 152 KiB of the 160 KiB LDS
 MAX_SLOTS = 112                 # 7 voxel tiles of 16
 TIMING = None                   # bench.py sets this to a list to collect (kernel name, flops, start_evt, end_evt)
+SLIDE = {"enabled": True, "max_slots": 112, "ct": 2}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
 
 
 def _stream_ptr(device):
@@ -173,12 +174,12 @@ def class_taps(c):
     return out
 
 
-def choose_tile(OH, OW, in_mul, span_h, span_w):
+def choose_tile(OH, OW, in_mul, span_h, span_w, max_slots=MAX_SLOTS):
     """Pick (R, WT): rows x cols of output per wave.  Maximise useful MFMA slots under the LDS budget."""
     best = None
-    wts = {-(-OW // parts) for parts in range(1, OW + 1) if -(-OW // parts) <= MAX_SLOTS}
+    wts = {-(-OW // parts) for parts in range(1, OW + 1) if -(-OW // parts) <= max_slots}
     for wt in sorted(wts):
-        for r in range(1, min(OH, MAX_SLOTS // wt) + 1):
+        for r in range(1, min(OH, max_slots // wt) + 1):
             rows_in = in_mul * (r - 1) + span_h + 1
             seg = in_mul * (wt - 1) + span_w + 1
             lds = 2 * rows_in * seg * 32      # double-buffered [rows][voxels][8 ch] fp32 tile per wave
@@ -200,8 +201,9 @@ def choose_tile(OH, OW, in_mul, span_h, span_w):
 class ConvPlan:
     """A fully resolved tapconv launch: geometry, tap classes, tile choice.  Pointers are patched per call."""
 
-    def __init__(self, x, y, classes, in_mul, out_mul, grid_dhw, cout, relu):
+    def __init__(self, x, y, classes, in_mul, out_mul, grid_dhw, cout, relu, slide=False):
         p = DrcTapconvParams()
+        self.slide = slide
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -214,7 +216,7 @@ class ConvPlan:
         p.n_classes = len(classes)
         span_h = max((c["n"][1] - 1) * c["step"][1] for c in classes)
         span_w = max((c["n"][2] - 1) * c["step"][2] for c in classes)
-        R, WT, lds = choose_tile(OH, OW, in_mul, span_h, span_w)
+        R, WT, lds = choose_tile(OH, OW, in_mul, span_h, span_w, SLIDE["max_slots"] if slide else MAX_SLOTS)
         p.R, p.WT = R, WT
         p.lds_bytes_per_wave = (lds + 1023) // 1024 * 1024
         for ci, c in enumerate(classes):
@@ -236,6 +238,15 @@ class ConvPlan:
         while CT > 1 and (groups * (ct // CT) < 2048 or nvt * CT > 16):      # mirrors drc_tapconv_fwd's choice
             CT //= 2
         self.kname = "tapconv_kernel<%d,%d>" % (nvt, CT)
+        if slide:
+            # the sliding-window kernel runs one long-lived wave per (column, depth segment of >= 3 slices): use it
+            # only when that still yields enough waves to fill the 1024 SIMDs (measured cross-over, tools/exp_conv.py)
+            self.slide_ct = SLIDE["ct"] if ct % SLIDE["ct"] == 0 else 1
+            cols = x.N * (-(-OH // R)) * (-(-OW // WT))
+            if OD < 6 or cols * (ct // self.slide_ct) * max(1, OD // 3) < 700:
+                self.slide = False
+            else:
+                self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)
 
     def run(self, x, w, scale, shift, y, res=None):
         p = self.p
@@ -250,8 +261,12 @@ class ConvPlan:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        st = _lib.lib().drc_tapconv_fwd(C.byref(p), _stream_ptr(self.device))
-        _lib.check(st, "drc_tapconv_fwd")
+        if self.slide:
+            st = _lib.lib().drc_tapconv3d_slide_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_tapconv3d_slide_fwd")
+        else:
+            st = _lib.lib().drc_tapconv_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_tapconv_fwd")
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(self.device))
             TIMING.append((self.kname, self.flops, e0, e1))
@@ -261,7 +276,7 @@ def plan_conv3d(x, y, stride, cout, relu):
     """Conv3d(k3,pad1,stride) on a blocked tensor with halo 1."""
     assert (x.pd, x.ph, x.pw) == (1, 1, 1)
     classes = taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
-    return ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu)
+    return ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu, slide=(stride == 1 and SLIDE["enabled"]))
 
 
 def plan_deconv3d(x, y, cout, relu):

@@ -114,6 +114,12 @@ typedef struct drc_tapconv_params {
 /* Validates, picks the (voxel-tiles, cout-tiles) instantiation and launches. */
 int drc_tapconv_fwd(const drc_tapconv_params* p, void* stream);
 
+/* Same operation as drc_tapconv_fwd for the stride-1 3x3x3 class only (one class, nd=nh=nw=3, unit spacing,
+ * in_mul=out_mul=1), executed with a sliding depth window: a wave owns R x WT voxels of ALL depth slices of a ROI and
+ * applies every staged input tile to the three output slices it touches (3x fewer staged bytes per MFMA).
+ * lds_bytes_per_wave >= 2*(R+2)*(WT+2)*32.  cout_tiles_per_wave in {1,2} must divide cout_pad/16. */
+int drc_tapconv3d_slide_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* Final classifier conv Conv3d(32->1,k3,p1,bias=False) (stackhourglass.py:78-88 `classifN[2]`)
  * with the cumulative head add (`+ cost_{k-1}`, :142-144) fused.
  *   x : blocked [N][cb_in][D+2][H+2][W+2][16];  w : [27][cb_in*16];  out,res : dense [N,D,H,W] */

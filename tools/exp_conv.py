@@ -30,6 +30,12 @@ def run(N, cin, cout, dims, stride=1, deconv=False, reps=20):
 
 if __name__ == "__main__":
     N = int(os.environ.get("N", "128"))
+    if os.environ.get("SLIDE") is not None:
+        E.SLIDE["enabled"] = os.environ["SLIDE"] != "0"
+    if os.environ.get("SLIDE_SLOTS"):
+        E.SLIDE["max_slots"] = int(os.environ["SLIDE_SLOTS"])
+    if os.environ.get("SLIDE_CT"):
+        E.SLIDE["ct"] = int(os.environ["SLIDE_CT"])
     run(N, 32, 32, (12, 28, 28))
     if os.environ.get("ALL"):
         run(N, 64, 32, (12, 28, 28))
