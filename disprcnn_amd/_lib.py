@@ -54,6 +54,8 @@ _SIGS = {
     "drc_upsample_softargmin_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_avgpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_bilinear_up_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_bilinear_resize_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_maxpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_copy_blocks": (_I, [_P, _P, _I, _I, C.c_int64, _I, _I, _P]),
     "drc_roi_align_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "drc_roi_align_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),

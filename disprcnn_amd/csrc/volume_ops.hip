@@ -276,11 +276,12 @@ __global__ __launch_bounds__(64) void avgpool2d_blocked_kernel(const float* __re
 
 __global__ __launch_bounds__(kThreads) void bilinear_up_blocked_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int CB,
                                                                        int IH, int IW, int px, int OH, int OW, int py, int y_cb_total,
-                                                                       int y_cb_off) {
+                                                                       int y_cb_off, int align_corners) {
     const long total = (long)N * CB * OH * OW * 4;
     const long iW = IW + 2 * px, iH = IH + 2 * px, oW = OW + 2 * py, oH = OH + 2 * py;
-    const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
-    const float sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    // align_corners=True: src = dst*(in-1)/(out-1);  False: src = max((dst+0.5)*in/out - 0.5, 0)  (ATen area_pixel_compute_source_index)
+    const float sy = align_corners ? (OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f) : (float)IH / (float)OH;
+    const float sx = align_corners ? (OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f) : (float)IW / (float)OW;
     for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
         long t = idx;
         const int q = (int)(t & 3); t >>= 2;
@@ -288,7 +289,8 @@ __global__ __launch_bounds__(kThreads) void bilinear_up_blocked_kernel(const flo
         const int oy = (int)(t % OH); t /= OH;
         const int cb = (int)(t % CB);
         const int n = (int)(t / CB);
-        const float fy = sy * oy, fx = sx * ox;
+        const float fy = align_corners ? sy * oy : fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f);
+        const float fx = align_corners ? sx * ox : fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f);
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < IH - 1), x1 = x0 + (x0 < IW - 1);
         const float ty = fy - y0, tx = fx - x0;
@@ -300,6 +302,35 @@ __global__ __launch_bounds__(kThreads) void bilinear_up_blocked_kernel(const flo
         // same association as ATen's upsample_bilinear2d: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
         const f32x4 v = (1.f - ty) * ((1.f - tx) * v00 + tx * v01) + ty * ((1.f - tx) * v10 + tx * v11);
         *(f32x4*)(y + ((((long)n * y_cb_total + y_cb_off + cb) * oH + (oy + py)) * oW + (ox + py)) * 16 + q * 4) = v;
+    }
+}
+
+// max_pool2d(k, stride, padding 0, ceil_mode) on blocked 2D tensors: windows are clipped to the valid region
+// (reference: BaseStem max_pool2d(3,2,0,ceil_mode=True), resnet.py:303; LastLevelMaxPool max_pool2d(1,2,0), fpn.py:80-82)
+__global__ __launch_bounds__(kThreads) void maxpool2d_blocked_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int CB, int H,
+                                                                     int W, int px, int k, int stride, int OH, int OW, int py) {
+    const long total = (long)N * CB * OH * OW * 4;
+    const long iW = W + 2 * px, iH = H + 2 * px, oW = OW + 2 * py, oH = OH + 2 * py;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH); t /= OH;
+        const int cb = (int)(t % CB);
+        const int n = (int)(t / CB);
+        const float* xb = x + (((long)n * CB + cb) * iH) * iW * 16 + q * 4;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int a = 0; a < k; ++a) {
+            const int iy = oy * stride + a;
+            if (iy >= H) break;
+            for (int b = 0; b < k; ++b) {
+                const int ix = ox * stride + b;
+                if (ix >= W) break;
+                const f32x4 v = *(const f32x4*)(xb + ((long)(iy + px) * iW + (ix + px)) * 16);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *(f32x4*)(y + ((((long)n * CB + cb) * oH + (oy + py)) * oW + (ox + py)) * 16 + q * 4) = m;
     }
 }
 
@@ -413,7 +444,28 @@ int drc_bilinear_up_blocked(const float* x, float* y, int N, int CB, int IH, int
     const long total = (long)N * CB * OH * OW * 4;
     if (total == 0) return 0;
     if (!x || !y) return -1;
-    hipLaunchKernelGGL(bilinear_up_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, N, CB, IH, IW, px, OH, OW, py, y_cb_total, y_cb_off);
+    hipLaunchKernelGGL(bilinear_up_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, N, CB, IH, IW, px, OH, OW, py, y_cb_total, y_cb_off, 1);
+    return done();
+}
+
+int drc_bilinear_resize_blocked(const float* x, float* y, int N, int CB, int IH, int IW, int px, int OH, int OW, int py, int y_cb_total,
+                                int y_cb_off, int align_corners, void* stream) {
+    if (N < 0 || CB <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || y_cb_off < 0 || y_cb_off + CB > y_cb_total) return -2;
+    const long total = (long)N * CB * OH * OW * 4;
+    if (total == 0) return 0;
+    if (!x || !y) return -1;
+    hipLaunchKernelGGL(bilinear_up_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, N, CB, IH, IW, px, OH, OW, py, y_cb_total, y_cb_off, align_corners ? 1 : 0);
+    return done();
+}
+
+int drc_maxpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W, int px, int k, int stride, int OH, int OW, int py,
+                          void* stream) {
+    if (N < 0 || CB <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || OH <= 0 || OW <= 0) return -2;
+    if ((OH - 1) * stride >= H || (OW - 1) * stride >= W) return -2;   // every window must start inside the input
+    const long total = (long)N * CB * OH * OW * 4;
+    if (total == 0) return 0;
+    if (!x || !y) return -1;
+    hipLaunchKernelGGL(maxpool2d_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, N, CB, H, W, px, k, stride, OH, OW, py);
     return done();
 }
 

@@ -1,0 +1,153 @@
+"""ResNet-FPN on the HIP tap-conv engine (eval mode: BN folded).  Graph restated from the reference
+(resnet.py:137-146,274-316; fpn.py:44-77) as a flat schedule over blocked 2D tensors."""
+import torch
+
+from ... import _lib
+from ... import engine as E
+
+
+class _Site:
+    def __init__(self, conv, bn, device):
+        w = conv.weight.detach().to(device=device, dtype=torch.float32)
+        self.w = E.pack_weight(w)
+        cp = self.w.shape[3]
+        if bn is not None:
+            self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
+                                               bn.running_mean.detach().to(device).float(), bn.running_var.detach().to(device).float(),
+                                               bn.eps, cp)
+        else:
+            self.scale = torch.ones(cp, device=device)
+            self.shift = torch.zeros(cp, device=device)
+            if conv.bias is not None:
+                self.shift[: conv.bias.numel()] = conv.bias.detach().to(device).float()
+
+
+def _half(n):       # conv k1/k3 stride 2 (pad k//2) and max_pool2d(1,2,0): floor((n-1)/2)+1
+    return (n - 1) // 2 + 1
+
+
+class BackboneRuntime:
+    def __init__(self, model, device):
+        self.model, self.device = model, device
+        self._w, self._ver, self._ws = None, None, {}
+
+    def _version(self):
+        return tuple(t._version for t in list(self.model.parameters()) + list(self.model.buffers())) + \
+            tuple(t.data_ptr() for t in self.model.parameters())
+
+    def _compile(self):
+        v = self._version()
+        if self._w is not None and v == self._ver:
+            return self._w
+        body, fpn, dev = self.model.body, self.model.fpn, self.device
+        W = {"stem": _Site(body.stem.conv1, body.stem.bn1, dev)}
+        for li in range(1, 5):
+            for b, u in enumerate(getattr(body, f"layer{li}")):
+                p = f"l{li}.{b}"
+                W[p + ".c1"], W[p + ".c2"], W[p + ".c3"] = _Site(u.conv1, u.bn1, dev), _Site(u.conv2, u.bn2, dev), _Site(u.conv3, u.bn3, dev)
+                if u.downsample is not None:
+                    W[p + ".ds"] = _Site(u.downsample[0], u.downsample[1], dev)
+        for i in range(1, 5):
+            W[f"inner{i}"] = _Site(getattr(fpn, f"fpn_inner{i}"), None, dev)
+            W[f"layer{i}"] = _Site(getattr(fpn, f"fpn_layer{i}"), None, dev)
+        self._w, self._ver = W, v
+        return W
+
+    def _workspace(self, N, H, W_):
+        key = (N, H, W_)
+        if key in self._ws:
+            return self._ws[key]
+        dev, body = self.device, self.model.body
+        B2 = lambda c, h, w, pad: E.Blocked(N, c, 1, h, w, 0, pad, pad, dev)
+        t, p, sched = {}, {}, []
+        t["img"] = B2(3, H, W_, 3)
+        h1, w1 = _half(H), _half(W_)                                    # 7x7 s2 p3
+        t["stem"] = B2(64, h1, w1, 0)
+        p["stem"] = E.plan_conv2d(t["img"], t["stem"], 7, 2, 3, 1, 64, True)
+        # max_pool2d(3, 2, 0, ceil_mode=True): out = ceil((n-3)/2)+1, dropping a last window that would start outside
+        ph, pw = -(-(h1 - 3) // 2) + 1, -(-(w1 - 3) // 2) + 1
+        if (ph - 1) * 2 >= h1: ph -= 1
+        if (pw - 1) * 2 >= w1: pw -= 1
+        t["pool"] = B2(64, ph, pw, 0)
+        cur, ch, hw = "pool", 64, (ph, pw)
+        stage_out = []
+        for li in range(1, 5):
+            for b, u in enumerate(getattr(body, f"layer{li}")):
+                s = u.stride
+                mid, cout = u.conv1.out_channels, u.conv3.out_channels
+                ohw = (_half(hw[0]), _half(hw[1])) if s == 2 else hw
+                q = f"l{li}.{b}"
+                t[q + ".a"] = B2(mid, ohw[0], ohw[1], 1)                # feeds the 3x3
+                t[q + ".b"] = B2(mid, ohw[0], ohw[1], 0)
+                t[q + ".o"] = B2(cout, ohw[0], ohw[1], 0)
+                p[q + ".c1"] = E.plan_conv2d(t[cur], t[q + ".a"], 1, s, 0, 1, mid, True)
+                p[q + ".c2"] = E.plan_conv2d(t[q + ".a"], t[q + ".b"], 3, 1, 1, 1, mid, True)
+                p[q + ".c3"] = E.plan_conv2d(t[q + ".b"], t[q + ".o"], 1, 1, 0, 1, cout, True)   # relu(bn3(conv3) + identity)
+                res = cur
+                if u.downsample is not None:
+                    t[q + ".s"] = B2(cout, ohw[0], ohw[1], 0)
+                    p[q + ".ds"] = E.plan_conv2d(t[cur], t[q + ".s"], 1, s, 0, 1, cout, False)
+                    sched.append((q + ".ds", cur, q + ".s", None))
+                    res = q + ".s"
+                sched += [(q + ".c1", cur, q + ".a", None), (q + ".c2", q + ".a", q + ".b", None), (q + ".c3", q + ".b", q + ".o", res)]
+                cur, ch, hw = q + ".o", cout, ohw
+            stage_out.append((cur, ch, hw))
+        # FPN (top-down)
+        fsched, outs = [], [None] * 5
+        top, tch, thw = stage_out[3]
+        t["in4"] = B2(256, thw[0], thw[1], 1)
+        p["inner4"] = E.plan_conv2d(t[top], t["in4"], 1, 1, 0, 1, 256, False)
+        fsched.append(("conv", "inner4", top, "in4", None))
+        outs[3] = "in4"                                                 # top level: no 3x3 block (fork quirk)
+        last, lhw = "in4", thw
+        for i in (3, 2, 1):
+            feat, fch, fhw = stage_out[i - 1]
+            t[f"td{i}"] = B2(256, fhw[0], fhw[1], 0)
+            t[f"sum{i}"] = B2(256, fhw[0], fhw[1], 1)
+            t[f"out{i}"] = B2(256, fhw[0], fhw[1], 1 if i > 1 else 0)
+            p[f"inner{i}"] = E.plan_conv2d(t[feat], t[f"sum{i}"], 1, 1, 0, 1, 256, False)
+            p[f"layer{i}"] = E.plan_conv2d(t[f"sum{i}"], t[f"out{i}"], 3, 1, 1, 1, 256, False)
+            fsched.append(("resize", last, f"td{i}", lhw, fhw))
+            fsched.append(("conv", f"inner{i}", feat, f"sum{i}", f"td{i}"))      # inner_lateral + inner_top_down
+            fsched.append(("conv", f"layer{i}", f"sum{i}", f"out{i}", None))
+            outs[i - 1] = f"out{i}"
+            last, lhw = f"out{i}", fhw                                  # reference: last_inner = layer_block(lateral + top_down)
+        t["p6"] = B2(256, _half(thw[0]), _half(thw[1]), 0)
+        outs[4] = "p6"
+        ws = dict(t=t, p=p, sched=sched, fsched=fsched, outs=outs, pool=(h1, w1, ph, pw), thw=thw,
+                  flops=sum(pl.flops for pl in p.values()))
+        self._ws[key] = ws
+        return ws
+
+    def forward(self, x):
+        E.require_gpu(x, "backbone input")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected [N,3,H,W], got {tuple(x.shape)}")
+        N, _, H, W_ = x.shape
+        Wt = self._compile()
+        ws = self._workspace(N, H, W_)
+        t, p = ws["t"], ws["p"]
+        lib, sp = _lib.lib(), E._stream_ptr(self.device)
+
+        def conv(plan, x_, y_, res=None):
+            c = Wt[plan]
+            p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None)
+
+        t["img"].from_dense(x)
+        conv("stem", "img", "stem")
+        h1, w1, ph, pw = ws["pool"]
+        _lib.check(lib.drc_maxpool2d_blocked(E._ptr(t["stem"].storage), E._ptr(t["pool"].storage), N, 4, h1, w1, 0, 3, 2, ph, pw, 0, sp),
+                   "drc_maxpool2d_blocked")
+        for plan, x_, y_, res in ws["sched"]:
+            conv(plan, x_, y_, res)
+        for item in ws["fsched"]:
+            if item[0] == "conv":
+                conv(item[1], item[2], item[3], item[4])
+            else:
+                _, src, dst, (ih, iw), (oh, ow) = item
+                _lib.check(lib.drc_bilinear_resize_blocked(E._ptr(t[src].storage), E._ptr(t[dst].storage), N, 16, ih, iw, t[src].ph, oh, ow,
+                                                           t[dst].ph, 16, 0, 0, sp), "drc_bilinear_resize_blocked")
+        th, tw = ws["thw"]
+        _lib.check(lib.drc_maxpool2d_blocked(E._ptr(t["in4"].storage), E._ptr(t["p6"].storage), N, 16, th, tw, t["in4"].ph, 1, 2,
+                                             t["p6"].H, t["p6"].W, 0, sp), "drc_maxpool2d_blocked")
+        return tuple(t[o].to_dense()[:, :, 0] for o in ws["outs"])

@@ -100,3 +100,26 @@ def synth_images(n, h, w, tag="img"):
     # right view = left shifted by a few pixels + noise so matching is non-trivial
     right = torch.roll(left, shifts=-6, dims=3) * 0.9 + 0.1 * hash_uniform(f"{tag}:R", (n, 3, h, w), 0.0, 1.0)
     return (left - mean) / std, (right - mean) / std
+
+
+def synth_backbone_state(template):
+    """Closed-form ResNet-FPN weights: kaiming_uniform(a=1) bounds for convs (reference resnet.py:262-263, make_layers.py:51),
+    BN affine near identity, small FPN biases; running statistics at (0,1) until a calibrated fixture is overlaid."""
+    out = {}
+    for k, v in template.items():
+        shape = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_mean"):
+            out[k] = torch.zeros(shape)
+        elif k.endswith("running_var"):
+            out[k] = torch.ones(shape)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = (3.0 / fan_in) ** 0.5
+            out[k] = hash_uniform("bb:" + k, shape, -b, b)
+        elif ".bn" in k or "downsample.1" in k:
+            out[k] = hash_uniform("bb:" + k, shape, 0.8, 1.2) if k.endswith("weight") else hash_uniform("bb:" + k, shape, -0.1, 0.1)
+        else:                                   # fpn conv bias
+            out[k] = hash_uniform("bb:" + k, shape, -0.05, 0.05)
+    return out

@@ -142,6 +142,13 @@ int drc_avgpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W,
                           int k, int OH, int OW, int py, void* stream);
 int drc_bilinear_up_blocked(const float* x, float* y, int N, int CB, int IH, int IW, int px,
                             int OH, int OW, int py, int y_cb_total, int y_cb_off, void* stream);
+/* a12 helpers (ResNet-FPN): bilinear resize with either align_corners convention (the fork's FPN top-down path uses
+ * F.interpolate(bilinear, align_corners=False), fpn.py:62-64) and max_pool2d(k, stride, pad 0, ceil_mode) with windows
+ * clipped to the valid region (stem pool resnet.py:303; LastLevelMaxPool fpn.py:80-82). */
+int drc_bilinear_resize_blocked(const float* x, float* y, int N, int CB, int IH, int IW, int px, int OH, int OW, int py,
+                                int y_cb_total, int y_cb_off, int align_corners, void* stream);
+int drc_maxpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W, int px, int k, int stride, int OH, int OW, int py,
+                          void* stream);
 /* copy channel blocks of a blocked tensor into a channel slice of another (same spatial geometry) */
 int drc_copy_blocks(const float* x, float* y, int N, int CB, int64_t vox_per_cb,
                     int y_cb_total, int y_cb_off, void* stream);

@@ -1,0 +1,73 @@
+"""ResNet-50-FPN backbone: oracle vs the reference goldens (CPU) and HIP engine vs the goldens (GPU)."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_oracle as BO
+from disprcnn_amd.utils import synth
+from tests.helpers import GOLDEN
+
+CASES = {"small": (2, 3, 96, 160), "odd": (1, 3, 75, 131), "kitti": (2, 3, 375, 1242)}
+
+
+def _cfg():
+    return NS(MODEL=NS(BACKBONE=NS(CONV_BODY="R-50-FPN"), RESNETS=NS(BACKBONE_OUT_CHANNELS=256, RES2_OUT_CHANNELS=256)))
+
+
+def _model_and_state():
+    from disprcnn_amd.modeling.backbone import build_backbone
+    m = build_backbone(_cfg())
+    sd = synth.synth_backbone_state(m.state_dict())
+    synth.load_bn_stats(sd, os.path.join(GOLDEN, "bn_stats_backbone.npz"))
+    m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+def _check(z, tag, t, rel):
+    flat = t.detach().cpu().reshape(-1).double()
+    assert tuple(t.shape) == tuple(z[tag + "_shape"])
+    ref = torch.from_numpy(z[tag + "_val"]).double()
+    got = flat[torch.from_numpy(z[tag + "_idx"])]
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() <= rel * scale, (tag, (got - ref).abs().max().item(), scale)
+    assert abs(flat.abs().sum().item() - float(z[tag + "_abssum"])) <= 10 * rel * float(z[tag + "_abssum"])
+
+
+def test_state_dict_keys_match_reference():
+    m, _ = _model_and_state()
+    z = np.load(os.path.join(GOLDEN, "backbone_golden.npz"))
+    assert list(m.state_dict().keys()) == [str(k) for k in z["keys"]]
+    assert m.out_channels == 256 and sum(p.numel() for p in m.parameters()) == 26852416
+
+
+@pytest.mark.parametrize("tag", ["small", "odd"])
+def test_oracle_vs_reference_golden(tag):
+    _, sd = _model_and_state()
+    z = np.load(os.path.join(GOLDEN, "backbone_golden.npz"))
+    x = synth.hash_uniform("bb:" + tag, CASES[tag], -2.0, 2.0)
+    with torch.no_grad():
+        feats = BO.resnet(sd, x)
+        outs = BO.fpn(sd, feats)
+    for i, f in enumerate(feats):
+        _check(z, f"{tag}_c{i + 2}", f, 1e-4)
+    for i, o in enumerate(outs):
+        _check(z, f"{tag}_p{i + 2}", o, 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["small", "odd", "kitti"])
+def test_hip_backbone_vs_reference_golden(tag):
+    """fp32 MFMA trunk of ~53 convs vs the reference's torch-CPU output: |err| <= 2e-4 * max|ref| on sampled values."""
+    dev = torch.device("cuda:0")
+    m, _ = _model_and_state()
+    m = m.to(dev).eval()
+    z = np.load(os.path.join(GOLDEN, "backbone_golden.npz"))
+    x = synth.hash_uniform("bb:" + tag, CASES[tag], -2.0, 2.0).to(dev)
+    with torch.no_grad():
+        outs = m(x)
+    assert len(outs) == 5
+    for i, o in enumerate(outs):
+        _check(z, f"{tag}_p{i + 2}", o, 2e-4)
