@@ -172,9 +172,56 @@ def main():
                 extra["config_b_full_psmnet"] = {"roi_pairs_per_s": round(16 / tb, 1), "ms_per_16_roi_image": round(tb * 1e3, 2),
                                                  "stereo_pairs_per_s_16roi": round(1 / tb, 2),
                                                  "workload": "16 ROI crops 224x224, D=96 (-48..48): 2D CNN + cost volume + 3D + soft-argmin"}
-                del mB
+                # ---- extra: BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
+                # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
+                from types import SimpleNamespace as NS
+                from disprcnn_amd.modeling.backbone import build_backbone
+                from disprcnn_amd.modeling.detector.disprcnn3d import DispRCNN3D, default_cfg
+                from disprcnn_amd.structures import BoxList, ImageList
+                bb = build_backbone(NS(MODEL=NS(BACKBONE=NS(CONV_BODY="R-50-FPN"), RESNETS=NS(BACKBONE_OUT_CHANNELS=256, RES2_OUT_CHANNELS=256))))
+                bsd = synth.synth_backbone_state(bb.state_dict())
+                bnf = os.path.join(ROOT, "tests", "golden", "bn_stats_backbone.npz")
+                if os.path.exists(bnf):
+                    synth.load_bn_stats(bsd, bnf)
+                bb.load_state_dict(bsd)
+                bb = bb.to(dev).eval()
+                det = DispRCNN3D(default_cfg(48, -48, 224))
+                det.dispnet = mB
+                det = det.to(dev).eval()
+                Wi, Hi = 1242, 375
+                pair = synth.hash_uniform("benchpair", (2, 3, Hi, Wi), 0.0, 1.0).to(dev)
+                u = synth.hash_uniform("benchboxes", (16, 4), 0.0, 1.0)
+                x1 = 20 + u[:, 0] * (Wi - 400); y1 = 10 + u[:, 1] * (Hi - 240)
+                lb = torch.stack([x1, y1, x1 + 40 + u[:, 2] * 260, y1 + 30 + u[:, 3] * 170], 1)
+                rb = lb.clone(); rb[:, [0, 2]] -= 2 + 78 * u[:, 0:1]
+                rb[:, [0, 2]] = rb[:, [0, 2]].clamp(min=0)
+
+                def pair_step():
+                    feats = bb(pair)
+                    out = det({"left": ImageList(pair[:1], [(Hi, Wi)]), "right": ImageList(pair[1:], [(Hi, Wi)])},
+                              {"left": [BoxList(lb, (Wi, Hi))], "right": [BoxList(rb, (Wi, Hi))]})
+                    return feats, out
+                with torch.no_grad():
+                    for _ in range(2):
+                        pair_step()
+                    torch.cuda.synchronize()
+                    tp = time.perf_counter()
+                    for _ in range(5):
+                        pair_step()
+                    torch.cuda.synchronize()
+                    tp = (time.perf_counter() - tp) / 5
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    for _ in range(5):
+                        bb(pair)
+                    torch.cuda.synchronize(); tbb = (time.perf_counter() - t1) / 5
+                extra["kitti_pair_r50fpn_plus_16roi"] = {
+                    "stereo_pairs_per_s": round(1.0 / tp, 2), "ms_per_pair": round(tp * 1e3, 2), "backbone_ms": round(tbb * 1e3, 2),
+                    "backbone_tflops": round(250.3e9 / tbb / 1e12, 2),
+                    "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
+                del mB, bb, det
             except Exception as ex:  # report, never hide
-                extra["config_b_full_psmnet"] = {"error": repr(ex)}
+                extra["config_b_full_psmnet"] = extra.get("config_b_full_psmnet") or {"error": repr(ex)}
+                extra["extra_error"] = repr(ex)
 
     cpu = None
     if rank == 0 and not args.no_cpu:

@@ -199,6 +199,104 @@ __global__ __launch_bounds__(kThreads) void conv3d_cout1_kernel(const float* __r
     }
 }
 
+
+// classifN[2] with a sliding depth window: a wave owns R rows x W columns of ALL depth slices of one ROI, stages every
+// input tile ([rows][W+2][16 ch], LDS-DMA, double-buffered) once and applies it to the three output slices it touches
+// (od = d_in+1-dd), so the 32-channel input is fetched ~1.5x (row halo) instead of once per tap.  VALU dot products:
+// 864 MACs per output voxel are nothing next to reading 128 B per input voxel.
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr int kC1Waves = 4;
+__global__ __launch_bounds__(64 * kC1Waves) void conv3d_cout1_slide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                           const float* __restrict__ res, float* __restrict__ out, int N,
+                                                                           int cb_in, int D, int H, int W, int R, int seg_len) {
+    extern __shared__ __attribute__((aligned(16))) float lds_c1[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int n_rt = (H + R - 1) / R;
+    int cid = blockIdx.x * kC1Waves + wave;
+    if (cid >= N * n_rt) return;                          // wave-uniform, no workgroup barrier below
+    const int rt = cid % n_rt, n = cid / n_rt;
+    const int oh0 = rt * R;
+    const int Wp = W + 2, Hp = H + 2;
+    const long sH = (long)Wp * 16, sD = (long)Hp * sH, sC = (long)(D + 2) * sD, sN = sC * cb_in;
+    const int rows_in = R + 2;
+    const int seg_floats = Wp * 16, seg_units = Wp * 4;    // 64 B per voxel
+    const int buf_floats = rows_in * seg_floats;
+    float* lds = lds_c1 + wave * 2 * buf_floats;
+    const float* xcol = x + n * sN + (long)oh0 * sH;      // padded row oh0 (= real row oh0-1), padded col 0
+    // this lane's (up to two) voxels inside the R x W tile
+    const int nvox = R * W;
+    int voff[2]; bool vok[2]; int vr[2], vc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int s = lane + 64 * k;
+        vok[k] = s < nvox && oh0 + s / W < H;
+        vr[k] = vok[k] ? s / W : 0; vc[k] = vok[k] ? s - (s / W) * W : 0;
+        voff[k] = (vr[k] * Wp + vc[k]) * 16;
+    }
+    auto stage = [&](int d_in, int cb, int bufi) {
+        const float* src = xcol + cb * sC + (long)(d_in + 1) * sD;
+        float* dst = lds + bufi * buf_floats;
+        for (int r = 0; r < rows_in; ++r)
+            for (int u0 = 0; u0 < seg_units; u0 += 64) {
+                const int u = u0 + lane;
+                if (u < seg_units) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + r * sH + u * 4), LDS_PTR(dst + r * seg_floats + u0 * 4), 16, 0, 0);
+            }
+    };
+    float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};   // outputs od = d_in+1, d_in, d_in-1 in flight
+    // depth segment of this wave: outputs [od_lo, od_hi), input slices od_lo-1 .. od_hi clipped to the volume
+    const int od_lo = blockIdx.y * seg_len;
+    const int od_hi = od_lo + seg_len < D ? od_lo + seg_len : D;
+    const int din_lo = od_lo > 0 ? od_lo - 1 : 0, din_hi = od_hi < D ? od_hi : D - 1;
+    int bufsel = 0;
+    stage(din_lo, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int rot = lane & 3;                              // rotate the channel-quad order per lane: conflict-free b128 reads
+    for (int d_in = din_lo; d_in <= din_hi; ++d_in) {
+        const bool v0 = d_in + 1 < D;
+        const bool v2 = d_in - 1 >= od_lo && d_in - 1 < od_hi;          // output d_in-1 belongs to this segment
+        const bool v1s = d_in + 1 == D && d_in >= od_lo;                // last slice of the volume: output d_in completes too
+        for (int cb = 0; cb < cb_in; ++cb) {
+            const bool last = cb + 1 == cb_in;
+            if (!last || d_in + 1 <= din_hi) stage(last ? d_in + 1 : d_in, last ? 0 : cb + 1, bufsel ^ 1);
+            const float* buf = lds + bufsel * buf_floats;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int t = kh * 3 + kw;
+                    const float* w0 = w + ((0 * 9 + t) * cb_in + cb) * 16;   // wave-uniform -> scalar loads
+                    const float* w1 = w + ((1 * 9 + t) * cb_in + cb) * 16;
+                    const float* w2 = w + ((2 * 9 + t) * cb_in + cb) * 16;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float* px = buf + voff[k] + (kh * Wp + kw) * 16;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int q = (qq + rot) & 3;
+                            const f32x4 v = *(const f32x4*)(px + q * 4);
+                            const f32x4 u0 = *(const f32x4*)(w0 + q * 4), u1 = *(const f32x4*)(w1 + q * 4), u2 = *(const f32x4*)(w2 + q * 4);
+                            a0[k] = fmaf(v.x, u0.x, fmaf(v.y, u0.y, fmaf(v.z, u0.z, fmaf(v.w, u0.w, a0[k]))));
+                            a1[k] = fmaf(v.x, u1.x, fmaf(v.y, u1.y, fmaf(v.z, u1.z, fmaf(v.w, u1.w, a1[k]))));
+                            a2[k] = fmaf(v.x, u2.x, fmaf(v.y, u2.y, fmaf(v.z, u2.z, fmaf(v.w, u2.w, a2[k]))));
+                        }
+                    }
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bufsel ^= 1;
+        }
+        // output slice d_in-1 is complete (its dd=2 contribution just arrived); the last slice also completes d_in
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long o = (((long)n * D) * H + (oh0 + vr[k])) * W + vc[k];
+            if (vok[k] && v2) { const long oo = o + (long)(d_in - 1) * H * W; out[oo] = res ? a2[k] + res[oo] : a2[k]; }
+            if (vok[k] && v1s) { const long oo = o + (long)d_in * H * W; out[oo] = res ? a1[k] + res[oo] : a1[k]; }
+            a2[k] = a1[k]; a1[k] = v0 ? a0[k] : 0.f; a0[k] = 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a7: trilinear(align_corners=True) x softmax over D x soft-argmin, one thread per output pixel.
 // Bilinear (y,x) resample of every coarse slice into LDS (column per thread), then one pass over the D fine
@@ -413,6 +511,27 @@ int drc_conv3d_cout1_fwd(const float* x, const float* w, const float* res, float
     const long total = (long)N * D * H * W * 4;
     if (total == 0) return 0;
     if (!x || !w || !out) return -1;
+    // sliding-window kernel when a wave's R x W tile (<= 128 voxels, 2 per lane) and its two LDS tiles fit; else the direct one
+    int R = 128 / (W > 0 ? W : 1);
+    if (R > H) R = H;
+    while (R > 1 && H % R && (H + R - 1) / R * R - H > R / 2) --R;     // avoid a mostly empty last row tile
+    const size_t lds = R >= 1 ? (size_t)kC1Waves * 2 * (R + 2) * (W + 2) * 64 : 0;
+    if (W <= 64 && R >= 1 && lds <= 160 * 1024 && D >= 2) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)conv3d_cout1_slide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        const long cols = (long)N * ((H + R - 1) / R);
+        int nseg = (int)(1024 / (cols > 0 ? cols : 1));                // split D only while SIMDs would otherwise sit idle
+        if (nseg > D / 3) nseg = D / 3;
+        if (nseg < 1) nseg = 1;
+        const int seg_len = (D + nseg - 1) / nseg;
+        nseg = (D + seg_len - 1) / seg_len;
+        hipLaunchKernelGGL(conv3d_cout1_slide_kernel, dim3((unsigned)((cols + kC1Waves - 1) / kC1Waves), (unsigned)nseg), dim3(64 * kC1Waves), lds,
+                           (hipStream_t)stream, x, w, res, out, N, cb_in, D, H, W, R, seg_len);
+        return done();
+    }
     hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(grid_for(total, 256 * 32)), dim3(kThreads), 0, (hipStream_t)stream, x, w, res, out, N, cb_in, D, H, W);
     return done();
 }

@@ -46,3 +46,23 @@ if __name__ == "__main__":
         run(N, 64, 64, (3, 7, 7), deconv=True)
         run(N, 64, 32, (6, 14, 14), deconv=True)
         run(16, 32, 32, (24, 56, 56))
+
+
+def run_cout1(N, dims, reps=20):
+    dev = torch.device("cuda:0")
+    x = E.Blocked(N, 32, *dims, 1, 1, 1, dev)
+    x.view6()[:, :, 1:-1, 1:-1, 1:-1].normal_()
+    w = E.pack_weight_cout1(torch.randn(1, 32, 3, 3, 3, device=dev) * 0.05)
+    out = torch.empty(N, *dims, device=dev)
+    res = torch.randn(N, *dims, device=dev)
+    for _ in range(3):
+        E.conv3d_cout1(x, w, res, out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        E.conv3d_cout1(x, w, res, out)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    byts = x.numel * 4
+    print(f"cout1 N={N} {dims}: {us:8.1f} us  input {byts/1e6:.0f} MB -> {byts/us/1e6:.2f} TB/s (input bytes / time)")
