@@ -7,6 +7,8 @@
 
 #include "../../include/disprcnn_hip.h"
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -92,6 +94,122 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
     if (!pred || !target || !mask || !sums5 || !grad_scale || !grad_pred) return -1;
     hipLaunchKernelGGL(psm_loss_grad_kernel, dim3(grid_for(numel)), dim3(kThreads), 0, (hipStream_t)stream, pred, target, mask,
                        (long)numel, sums5, weight, grad_scale, grad_pred);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm on blocked tensors (reference: nn.BatchNorm3d/2d inside convbn_3d / convbn, submodule.py:13-22,
+// per-GPU batch statistics, eps 1e-5, momentum 0.1 handled by the caller).
+//   bn_stats   : per-channel sum of (x - shift) and (x - shift)^2 over the interior voxels (two-pass variance: call once
+//                with shift = 0 to get the mean, again with shift = mean for the centred second moment)
+//   bn_apply   : y = act( (x - mean) * invstd * gamma + beta (+ res) ), interior only (halos stay zero)
+//   bn_bwd_reduce / bn_bwd_apply : the standard BN backward with the ReLU mask and residual fan-out fused
+namespace {
+
+struct BlkGeom { int N, CB, D, H, W, pd, ph, pw; };
+
+__device__ __forceinline__ long blk_off(const BlkGeom& g, int n, int cb, int d, int y, int x) {
+    const long Wp = g.W + 2 * g.pw, Hp = g.H + 2 * g.ph, Dp = g.D + 2 * g.pd;
+    return ((((long)n * g.CB + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
+}
+
+// grid: (chunks, CB); each block walks a slice of the (n,d,y,x) voxels of one channel block; thread = float4 quad of a voxel
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, BlkGeom g, const float* __restrict__ shift,
+                                                            float* __restrict__ sums /* [2][CB*16] */) {
+    const int cb = blockIdx.y;
+    const int q = threadIdx.x & 3;
+    const long nvox = (long)g.N * g.D * g.H * g.W;
+    f32x4_t sh = {0.f, 0.f, 0.f, 0.f};
+    if (shift) sh = *(const f32x4_t*)(shift + cb * 16 + q * 4);
+    f32x4_t s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (long v = (long)blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2); v < nvox; v += (long)gridDim.x * (kThreads / 4)) {
+        long t = v;
+        const int xx = (int)(t % g.W); t /= g.W;
+        const int yy = (int)(t % g.H); t /= g.H;
+        const int dd = (int)(t % g.D);
+        const int n = (int)(t / g.D);
+        const f32x4_t val = *(const f32x4_t*)(x + blk_off(g, n, cb, dd, yy, xx) + q * 4) - sh;
+        s1 += val; s2 += val * val;
+    }
+    // reduce over the 16 voxel-lanes that share this quad inside the wave, then across waves through LDS
+    float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) r[k] += __shfl_xor(r[k], m);
+    __shared__ float red[kThreads / 64][4][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[w][lane][k] = r[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int qq = threadIdx.x >> 3, k = threadIdx.x & 7;
+        float v = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
+        const int c = cb * 16 + qq * 4 + (k & 3);
+        atomicAdd(sums + (k >> 2) * g.CB * 16 + c, v);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ x, BlkGeom gx, float* __restrict__ y, BlkGeom gy,
+                                                            const float* __restrict__ res, BlkGeom gr, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu) {
+    const long total = (long)gx.N * gx.CB * gx.D * gx.H * gx.W * 4;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int xx = (int)(t % gx.W); t /= gx.W;
+        const int yy = (int)(t % gx.H); t /= gx.H;
+        const int dd = (int)(t % gx.D); t /= gx.D;
+        const int cb = (int)(t % gx.CB);
+        const int n = (int)(t / gx.CB);
+        const int c = cb * 16 + q * 4;
+        const f32x4_t m = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+        const f32x4_t ga = *(const f32x4_t*)(gamma + c), be = *(const f32x4_t*)(beta + c);
+        f32x4_t v = (*(const f32x4_t*)(x + blk_off(gx, n, cb, dd, yy, xx) + q * 4) - m) * is * ga + be;
+        if (res) v += *(const f32x4_t*)(res + blk_off(gr, n, cb, dd, yy, xx) + q * 4);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(f32x4_t*)(y + blk_off(gy, n, cb, dd, yy, xx) + q * 4) = v;
+    }
+}
+
+inline bool geom_ok(const int* g) { return g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0; }
+inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]}; }
+
+}  // namespace
+
+extern "C" {
+
+int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, void* stream) {
+    if (!geom8 || !geom_ok(geom8)) return -2;
+    if (geom8[0] == 0) return 0;
+    if (!x || !sums) return -1;
+    const BlkGeom g = to_geom(geom8);
+    const long nvox = (long)g.N * g.D * g.H * g.W;
+    long chunks = (nvox + (kThreads / 4) * 8 - 1) / ((kThreads / 4) * 8);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 512) chunks = 512;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, shift, sums);
+    return (int)hipGetLastError();
+}
+
+int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int* geom_y, const float* res, const int* geom_r,
+                         const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, void* stream) {
+    if (!geom_x || !geom_y || !geom_ok(geom_x) || !geom_ok(geom_y)) return -2;
+    if (res && (!geom_r || !geom_ok(geom_r))) return -2;
+    for (int i = 0; i < 5; ++i)
+        if (geom_x[i] != geom_y[i] || (res && geom_x[i] != geom_r[i])) return -2;     // same logical shape
+    if (geom_x[0] == 0) return 0;
+    if (!x || !y || !mean || !invstd || !gamma || !beta) return -1;
+    const BlkGeom gx = to_geom(geom_x), gy = to_geom(geom_y), gr = res ? to_geom(geom_r) : gx;
+    const long total = (long)gx.N * gx.CB * gx.D * gx.H * gx.W * 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total * 1)), dim3(kThreads), 0, (hipStream_t)stream, x, gx, y, gy, res, gr, mean, invstd,
+                       gamma, beta, relu);
     return (int)hipGetLastError();
 }
 

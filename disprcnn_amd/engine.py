@@ -248,9 +248,17 @@ class ConvPlan:
             else:
                 self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)
 
-    def run(self, x, w, scale, shift, y, res=None):
+    def run(self, x, w, scale, shift, y, res=None, relu=None):
         p = self.p
+        relu_saved = p.relu
+        if relu is not None:
+            p.relu = int(relu)
         p.x, p.y = _base_ptr(x), _base_ptr(y)
+        # strides come from the tensors actually passed (same logical shape as at plan time; e.g. a train-mode raw buffer
+        # instead of a concat slice)
+        p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
+        p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
+        p.y_off0 = y.interior_off
         p.w, p.scale, p.shift = w.data_ptr(), scale.data_ptr(), shift.data_ptr()
         if res is not None:
             p.res = _base_ptr(res)
@@ -267,6 +275,7 @@ class ConvPlan:
         else:
             st = _lib.lib().drc_tapconv_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_tapconv_fwd")
+        p.relu = relu_saved
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(self.device))
             TIMING.append((self.kname, self.flops, e0, e1))
@@ -312,3 +321,33 @@ def upsample_softargmin(cost, disp, maxdisp, mindisp):
     st = _lib.lib().drc_upsample_softargmin_fwd(_ptr(cost), _ptr(disp), N, Dp, Hp, Wp, maxdisp - mindisp, H, W, mindisp,
                                                 _stream_ptr(cost.device))
     _lib.check(st, "drc_upsample_softargmin_fwd")
+
+
+# ------------------------------------------------------------------------------------------- train-mode BatchNorm
+def _geom8(t):
+    import ctypes
+    return (ctypes.c_int * 8)(t.N, t.cb, t.D, t.H, t.W, t.pd, t.ph, t.pw)
+
+
+def bn_batch_stats(raw):
+    """Per-channel batch mean and biased variance of a Blocked tensor's interior (two passes: mean, then centred moment)."""
+    dev = raw.device
+    C16 = raw.cb * CB
+    M = raw.N * raw.D * raw.H * raw.W
+    sums = torch.zeros(2, C16, dtype=torch.float32, device=dev)
+    g = _geom8(raw)
+    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, None, _ptr(sums), _stream_ptr(dev))
+    _lib.check(st, "drc_bn_stats_blocked")
+    mean = sums[0] / M
+    sums2 = torch.zeros(2, C16, dtype=torch.float32, device=dev)
+    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, _ptr(mean), _ptr(sums2), _stream_ptr(dev))
+    _lib.check(st, "drc_bn_stats_blocked")
+    var = sums2[1] / M
+    return mean.contiguous(), var.contiguous(), M
+
+
+def bn_apply(raw, y, res, mean, invstd, gamma, beta, relu):
+    st = _lib.lib().drc_bn_apply_blocked(_ptr(raw.storage), _geom8(raw), _ptr(y.storage), _geom8(y),
+                                         _ptr(res.storage) if res is not None else None, _geom8(res) if res is not None else None,
+                                         _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _stream_ptr(raw.device))
+    _lib.check(st, "drc_bn_apply_blocked")

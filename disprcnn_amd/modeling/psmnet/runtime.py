@@ -18,6 +18,14 @@ class _Conv:
         self.cout = w.shape[1] if transposed else w.shape[0]
         self.w = E.pack_weight(w, transposed)
         cout_pad = self.w.shape[3]
+        self.bn = bn
+        self.unit_scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
+        self.zero_shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+        if bn is not None:
+            self.gamma = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+            self.beta = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+            self.gamma[: self.cout] = bn.weight.detach().to(device).float()
+            self.beta[: self.cout] = bn.bias.detach().to(device).float()
         if bn is not None:
             self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
                                                bn.running_mean.detach().to(device).float(),
@@ -34,6 +42,7 @@ class PSMNetRuntime:
         self._weights_version = None
         self._w = None
         self._ws = {}      # workspaces: key -> dict of tensors/plans
+        self._training = False
 
     def invalidate(self):
         self._weights_version = None
@@ -77,6 +86,48 @@ class PSMNetRuntime:
         W["fe.lastconv.2"] = _Conv(fe.lastconv[2], None, dev)
         self._w, self._weights_version = W, v
         return W
+
+    # ------------------------------------------------------------------ one conv(+BN)(+res)(+ReLU) site
+    def _site(self, ws, W, plan, wname, x, y, res=None):
+        """Eval: BN folded into the conv epilogue.  Train: conv -> per-GPU batch statistics (biased var, eps 1e-5) ->
+        normalise + affine (+res) (+ReLU); running statistics updated like nn.BatchNorm (momentum, unbiased var).
+        Reference: submodule.py:13-22 with the activations / adds of stackhourglass.py:32-51,130-144."""
+        t, p = ws["t"], ws["p"]
+        c = W[wname]
+        pl = p[plan]
+        rs = t[res] if res else None
+        if not self._training or c.bn is None:
+            pl.run(t[x], c.w, c.scale, c.shift, t[y], rs)
+            return
+        yt = t[y]
+        raw = ws.setdefault("raw", {}).get(plan)
+        if raw is None:
+            raw = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
+            ws["raw"][plan] = raw
+        pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False)
+        mean, var, M = E.bn_batch_stats(raw)
+        invstd = torch.rsqrt(var + c.bn.eps)
+        bn = c.bn
+        with torch.no_grad():                                   # running statistics (buffers live on the module)
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            unb = var[: c.cout] * (M / max(M - 1, 1))
+            bn.running_mean.mul_(1 - mom).add_(mean[: c.cout].to(bn.running_mean.device), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(unb.to(bn.running_var.device), alpha=mom)
+        relu = bool(pl.p.relu)
+        if isinstance(yt, E.BlockedSlice):                      # concat slices: normalise into a temp, then copy the blocks in
+            tmp = ws["raw"].get(plan + ":y")
+            if tmp is None:
+                tmp = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
+                ws["raw"][plan + ":y"] = tmp
+            E.bn_apply(raw, tmp, rs, mean, invstd, c.gamma, c.beta, relu)
+            from ... import _lib
+            st = _lib.lib().drc_copy_blocks(E._ptr(tmp.storage), E._ptr(yt.base.storage), yt.N, yt.cb, tmp.cb_stride // 16,
+                                            yt.base.cb, yt.cb_off, E._stream_ptr(self.device))
+            _lib.check(st, "drc_copy_blocks")
+        else:
+            E.bn_apply(raw, yt, rs, mean, invstd, c.gamma, c.beta, relu)
+        ws.setdefault("saved", {})[plan] = (mean, invstd, M)
 
     # ------------------------------------------------------------------ 3D regressor
     def _ws3d(self, N, Dp, Hp, Wp):
@@ -123,8 +174,7 @@ class PSMNetRuntime:
         t, p = ws["t"], ws["p"]
 
         def run(plan, wname, x, y, res=None):
-            c = W[wname]
-            p[plan].run(t[x], c.w, c.scale, c.shift, t[y], t[res] if res else None)
+            self._site(ws, W, plan, wname, x, y, res)
 
         run("dres0.0", "dres0.0", "cost", "d0a")
         run("dres0.2", "dres0.2", "d0a", "cost0a")
@@ -153,9 +203,20 @@ class PSMNetRuntime:
             raise ValueError("maxdisp/mindisp must be multiples of 4 with a range divisible by 16 (SURVEY 8, a1)")
         return mx, mn
 
+    def _heads(self, costs, N, H, W, mx, mn, training):
+        """eval: disparity from cost3; train: the three heads (stackhourglass.py:145-174)."""
+        outs = []
+        for c in (costs if training else costs[2:]):
+            d = torch.empty(N, H, W, dtype=torch.float32, device=self.device)
+            E.upsample_softargmin(c, d, mx, mn)
+            outs.append(d)
+        return tuple(outs) if training else outs[0]
+
     def forward_features(self, fl, fr, out_hw, training=False):
-        if training:
-            raise NotImplementedError("training-mode (batch-statistics BN + backward) is not built yet on the HIP engine")
+        self._training = bool(training)
+        if training and torch.is_grad_enabled() and (fl.requires_grad or any(p.requires_grad for p in self.model.parameters())):
+            raise NotImplementedError("backward through the HIP engine is not built yet: run the train-mode forward under "
+                                      "torch.no_grad() (batch-statistics BN, 3 heads), or train through the reference")
         E.require_gpu(fl, "PSMNet features"); E.require_gpu(fr, "PSMNet features")
         mx, mn = self._check_disp()
         N, C, Hp, Wp = fl.shape
@@ -168,13 +229,11 @@ class PSMNetRuntime:
         Wt = self._compile()
         ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
         E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
-        _, _, cost3 = self._regress(ws, Wt)
-        E.upsample_softargmin(cost3, disp, mx, mn)
-        return disp
+        return self._heads(self._regress(ws, Wt), N, H, W, mx, mn, training)
 
     # ------------------------------------------------------------------ 2D feature CNN
-    def _ws2d(self, N, H, W):
-        key = ("2d", N, H, W)
+    def _ws2d(self, N, H, W, side=None):
+        key = ("2d", N, H, W) if side is None else ("2d", N, H, W, side)
         ws = self._ws.get(key)
         if ws is not None:
             return ws
@@ -246,8 +305,7 @@ class PSMNetRuntime:
         t["img"].from_dense(images)
 
         def run(plan, wname, x, y, res=None):
-            c = W[wname]
-            p[plan].run(t[x], c.w, c.scale, c.shift, t[y], t[res] if res else None)
+            self._site(ws, W, plan, wname, x, y, res)
 
         run("fe.firstconv.0", "fe.firstconv.0", "img", "f0")
         run("fe.firstconv.2", "fe.firstconv.2", "f0", "f1")
@@ -283,8 +341,10 @@ class PSMNetRuntime:
         return st
 
     def forward_images(self, left, right, training=False):
-        if training:
-            raise NotImplementedError("training-mode (batch-statistics BN + backward) is not built yet on the HIP engine")
+        self._training = bool(training)
+        if training and torch.is_grad_enabled() and (left.requires_grad or any(p.requires_grad for p in self.model.parameters())):
+            raise NotImplementedError("backward through the HIP engine is not built yet: run the train-mode forward under "
+                                      "torch.no_grad() (batch-statistics BN, 3 heads), or train through the reference")
         E.require_gpu(left, "PSMNet input"); E.require_gpu(right, "PSMNet input")
         mx, mn = self._check_disp()
         N, _, H, W = left.shape
@@ -292,12 +352,17 @@ class PSMNetRuntime:
         if N == 0:
             return disp
         Wt = self._compile()
-        ws2 = self._ws2d(2 * N, H, W)
-        feat = self._features(ws2, Wt, torch.cat((left, right), 0))
         ws3 = self._ws3d(N, (mx - mn) // 4, H // 4, W // 4)
-        fv = feat.storage
-        right_view = fv[N * feat.n_stride:]
-        E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
-        _, _, cost3 = self._regress(ws3, Wt)
-        E.upsample_softargmin(cost3, disp, mx, mn)
-        return disp
+        if training:
+            # the reference runs feature_extraction(left) and feature_extraction(right) as two calls (stackhourglass.py:112-113):
+            # batch statistics and running-stat updates are per call, so the two views must not share a batch here
+            featL = self._features(self._ws2d(N, H, W, "L"), Wt, left)
+            featR = self._features(self._ws2d(N, H, W, "R"), Wt, right)
+            E.cost_volume_blocked(featL.storage, featR.storage, ws3["t"]["cost"], mn // 4, mx // 4, featL.ph)
+        else:
+            ws2 = self._ws2d(2 * N, H, W)
+            feat = self._features(ws2, Wt, torch.cat((left, right), 0))
+            fv = feat.storage
+            right_view = fv[N * feat.n_stride:]
+            E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
+        return self._heads(self._regress(ws3, Wt), N, H, W, mx, mn, training)

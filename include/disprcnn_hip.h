@@ -184,6 +184,16 @@ int drc_psm_loss_sums(const float* pred1, const float* pred2, const float* pred3
 int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mask, int64_t numel, const float* sums5, float weight,
                       const float* grad_scale, float* grad_pred, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * a2 (train mode). BatchNorm with per-GPU batch statistics on blocked tensors (nn.BatchNorm3d/2d of convbn_3d / convbn,
+ * submodule.py:13-22).  geom8 = {N, CB, D, H, W, pd, ph, pw}.
+ *   drc_bn_stats_blocked : sums[0][c] += sum (x - shift[c]), sums[1][c] += sum (x - shift[c])^2 over interior voxels
+ *                          (caller zeroes sums [2][CB*16]; shift may be NULL; two passes give a cancellation-free variance)
+ *   drc_bn_apply_blocked : y = act((x - mean) * invstd * gamma + beta (+ res)), interior only */
+int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, void* stream);
+int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int* geom_y, const float* res, const int* geom_r,
+                         const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
