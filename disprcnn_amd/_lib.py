@@ -39,6 +39,18 @@ class DrcTapconvParams(C.Structure):
                 ("cls", DrcTapClass * DRC_MAX_CLASSES)]
 
 
+class DrcWgradParams(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p),
+                ("a_n_stride", C.c_int64), ("a_cb_stride", C.c_int64), ("a_d_stride", C.c_int64), ("a_h_stride", C.c_int64),
+                ("b_n_stride", C.c_int64), ("b_cb_stride", C.c_int64), ("b_d_stride", C.c_int64), ("b_h_stride", C.c_int64),
+                ("b_off0", C.c_int64),
+                ("N", C.c_int32), ("OD", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+                ("in_mul", C.c_int32), ("cb_a", C.c_int32), ("cb_b", C.c_int32),
+                ("nd", C.c_int32), ("nh", C.c_int32), ("nw", C.c_int32), ("dd0", C.c_int32), ("dh0", C.c_int32), ("dw0", C.c_int32),
+                ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+                ("R", C.c_int32), ("WT", C.c_int32), ("lds_bytes_per_wave", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _SIGS = {
@@ -62,6 +74,12 @@ _SIGS = {
     "drc_align_roi_pairs": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P]),
     "drc_bn_apply_blocked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "drc_tapconv_wgrad": (_I, [C.POINTER(DrcWgradParams), _P]),
+    "drc_upsample_softargmin_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_conv3d_cout1_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_conv3d_cout1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "drc_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "drc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P, _I, _P]),
     "drc_psm_loss_sums": (_I, [_P, _P, _P, _P, _P, C.c_int64, _P, _P]),
     "drc_psm_loss_grad": (_I, [_P, _P, _P, C.c_int64, _P, C.c_float, _P, _P, _P]),
 }

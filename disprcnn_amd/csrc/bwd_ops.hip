@@ -1,0 +1,336 @@
+// bwd_ops.hip -- backward kernels of the disparity path (gfx950): soft-argmin / trilinear adjoint, the 32->1 classifier
+// conv, training-mode BatchNorm.  (The data gradients of the MFMA convolutions reuse the forward engine: the dgrad of a
+// stride-1 conv is a stride-1 conv with flipped, transposed weights; the dgrad of a stride-2 conv IS the transposed-conv
+// parity-class list and vice versa -- see disprcnn_amd/autograd.py.  Weight gradients: wgrad.hip.)
+// Reference semantics: autograd of stackhourglass.py:130-174, submodule.py:19-22,51-57.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned grid_for(long work, long cap = 4096) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+struct BlkGeom { int N, CB, D, H, W, pd, ph, pw; };
+__device__ __forceinline__ long blk_off(const BlkGeom& g, int n, int cb, int d, int y, int x) {
+    const long Wp = g.W + 2 * g.pw, Hp = g.H + 2 * g.ph, Dp = g.D + 2 * g.pd;
+    return ((((long)n * g.CB + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
+}
+inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0; }
+inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]}; }
+
+// ------------------------------------------------------------------------------------------------ a7 backward
+// disp = sum_d p_d * dval_d, p = softmax_d(c_up), c_up = trilinear(cost).  d disp / d c_up[d] = p_d (dval_d - disp).
+// One thread per output pixel: recompute the LDS column of bilinear-resampled coarse slices, fold the D fine gradients
+// back onto the coarse slices (lerp weights), then scatter the D' values to the 4 bilinear neighbours with atomicAdd.
+constexpr int kSAThreads = 128;
+__global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ gdisp,
+                                                                             float* __restrict__ gcost, int N, int Dp, int Hp, int Wp,
+                                                                             int D, int H, int W, int mindisp) {
+    extern __shared__ float sm[];                      // cz [Dp][T] then gz [Dp][T]
+    float* cz = sm;
+    float* gz = sm + Dp * kSAThreads;
+    const long total = (long)N * H * W;
+    const long idx = (long)blockIdx.x * kSAThreads + threadIdx.x;
+    if (idx >= total) return;
+    long t = idx;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const float sd = D > 1 ? (float)(Dp - 1) / (float)(D - 1) : 0.f;
+    const float fy = sy * y, fx = sx * x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
+    const float ty = fy - y0, tx = fx - x0;
+    const float* c = cost + (long)n * Dp * Hp * Wp;
+    float m = -INFINITY;
+    for (int k = 0; k < Dp; ++k) {
+        const float* s = c + (long)k * Hp * Wp;
+        const float a = s[y0 * Wp + x0] * (1.f - tx) + s[y0 * Wp + x1] * tx;
+        const float b = s[y1 * Wp + x0] * (1.f - tx) + s[y1 * Wp + x1] * tx;
+        const float v = a * (1.f - ty) + b * ty;
+        cz[k * kSAThreads + threadIdx.x] = v;
+        gz[k * kSAThreads + threadIdx.x] = 0.f;
+        m = fmaxf(m, v);
+    }
+    float se = 0.f, sde = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float fd = sd * d;
+        const int k0 = (int)fd;
+        const int k1 = k0 + (k0 < Dp - 1);
+        const float td = fd - k0;
+        const float e = expf(cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td - m);
+        se += e; sde = fmaf(e, (float)(mindisp + d), sde);
+    }
+    const float disp = sde / se, g = gdisp[idx] / se;
+    for (int d = 0; d < D; ++d) {
+        const float fd = sd * d;
+        const int k0 = (int)fd;
+        const int k1 = k0 + (k0 < Dp - 1);
+        const float td = fd - k0;
+        const float e = expf(cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td - m);
+        const float gv = g * e * ((float)(mindisp + d) - disp);
+        gz[k0 * kSAThreads + threadIdx.x] += gv * (1.f - td);
+        gz[k1 * kSAThreads + threadIdx.x] += gv * td;
+    }
+    float* gc = gcost + (long)n * Dp * Hp * Wp;
+    for (int k = 0; k < Dp; ++k) {
+        const float v = gz[k * kSAThreads + threadIdx.x];
+        float* s = gc + (long)k * Hp * Wp;
+        atomicAdd(s + y0 * Wp + x0, v * (1.f - ty) * (1.f - tx));
+        atomicAdd(s + y0 * Wp + x1, v * (1.f - ty) * tx);
+        atomicAdd(s + y1 * Wp + x0, v * ty * (1.f - tx));
+        atomicAdd(s + y1 * Wp + x1, v * ty * tx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ classifN[2] backward
+// data: gx[n,c,u] (=|+=) sum_t w[t][c] * gy[n, u - t + 1]   (gather form, zero outside);  thread = (voxel u, channel quad)
+__global__ __launch_bounds__(kThreads) void cout1_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                  float* __restrict__ gx, int N, int cb_in, int D, int H, int W,
+                                                                  int accumulate) {
+    const long total = (long)N * cb_in * D * H * W * 4;
+    const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1};
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H); t /= H;
+        const int d = (int)(t % D); t /= D;
+        const int cb = (int)(t % cb_in);
+        const int n = (int)(t / cb_in);
+        const float* gyn = gy + (long)n * D * H * W;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const int od = d - kd + 1;
+            if (od < 0 || od >= D) continue;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int oh = y - kh + 1;
+                if (oh < 0 || oh >= H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ow = x - kw + 1;
+                    if (ow < 0 || ow >= W) continue;
+                    const float gv = gyn[((long)od * H + oh) * W + ow];
+                    acc += gv * *(const f32x4*)(w + (((kd * 3 + kh) * 3 + kw) * cb_in + cb) * 16 + q * 4);
+                }
+            }
+        }
+        float* dst = gx + blk_off(g, n, cb, d, y, x) + q * 4;
+        if (accumulate) acc += *(const f32x4*)dst;
+        *(f32x4*)dst = acc;
+    }
+}
+
+// weight: gw[t][c] += sum_{n,v} x[n,c,v+t] * gy[n,v];  thread = (voxel, quad) strided, 27 float4 partials, block reduce
+__global__ __launch_bounds__(kThreads) void cout1_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                    float* __restrict__ gw, int N, int cb_in, int D, int H, int W) {
+    const int cb = blockIdx.y;
+    const int q = threadIdx.x & 3;
+    const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1};
+    const long nvox = (long)N * D * H * W;
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long sH = (long)(W + 2) * 16, sD = (long)(H + 2) * sH;
+    for (long v = (long)blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2); v < nvox; v += (long)gridDim.x * (kThreads / 4)) {
+        long t = v;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H); t /= H;
+        const int dd = (int)(t % D);
+        const int n = (int)(t / D);
+        const float gv = gy[v];
+        const float* xb = x + blk_off(g, n, cb, dd, yy, xx) - sD - sH - 16 + q * 4;    // tap (0,0,0) = voxel - 1 in every dim
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[(kd * 3 + kh) * 3 + kw] += gv * *(const f32x4*)(xb + kd * sD + kh * sH + kw * 16);
+    }
+    __shared__ float red[kThreads / 64][4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = 0; t < 27; ++t) {
+        float r[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) r[k] += __shfl_xor(r[k], m);
+        if (lane < 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[wv][lane][k] = r[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int qq = threadIdx.x >> 2, k = threadIdx.x & 3;
+            float v = 0.f;
+            for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
+            atomicAdd(gw + (t * cb_in + cb) * 16 + qq * 4 + k, v);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm backward
+// dz = dy * [y > 0] (if relu);  sums[0][c] += sum dz,  sums[1][c] += sum dz * xhat,  xhat = (raw - mean) * invstd
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __restrict__ dy, BlkGeom gdy, const float* __restrict__ y,
+                                                                 BlkGeom gy, const float* __restrict__ raw, BlkGeom graw,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                                 float* __restrict__ sums) {
+    const int cb = blockIdx.y;
+    const int q = threadIdx.x & 3;
+    const long nvox = (long)gdy.N * gdy.D * gdy.H * gdy.W;
+    const f32x4 mu = *(const f32x4*)(mean + cb * 16 + q * 4), is = *(const f32x4*)(invstd + cb * 16 + q * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (long v = (long)blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2); v < nvox; v += (long)gridDim.x * (kThreads / 4)) {
+        long t = v;
+        const int xx = (int)(t % gdy.W); t /= gdy.W;
+        const int yy = (int)(t % gdy.H); t /= gdy.H;
+        const int dd = (int)(t % gdy.D);
+        const int n = (int)(t / gdy.D);
+        f32x4 dz = *(const f32x4*)(dy + blk_off(gdy, n, cb, dd, yy, xx) + q * 4);
+        if (relu) {
+            const f32x4 yv = *(const f32x4*)(y + blk_off(gy, n, cb, dd, yy, xx) + q * 4);
+            dz.x = yv.x > 0.f ? dz.x : 0.f; dz.y = yv.y > 0.f ? dz.y : 0.f; dz.z = yv.z > 0.f ? dz.z : 0.f; dz.w = yv.w > 0.f ? dz.w : 0.f;
+        }
+        const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + q * 4) - mu) * is;
+        s1 += dz; s2 += dz * xh;
+    }
+    float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) r[k] += __shfl_xor(r[k], m);
+    __shared__ float red[kThreads / 64][4][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[w][lane][k] = r[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int qq = threadIdx.x >> 3, k = threadIdx.x & 7;
+        float v = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
+        atomicAdd(sums + (k >> 2) * gdy.CB * 16 + cb * 16 + qq * 4 + (k & 3), v);
+    }
+}
+
+// draw = gamma * invstd * (dz - sum_dz/M - xhat * sum_dzx/M);  optionally dres (=|+=) dz
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __restrict__ dy, BlkGeom gdy, const float* __restrict__ y,
+                                                                BlkGeom gy, const float* __restrict__ raw, BlkGeom graw,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sums, float invM,
+                                                                int relu, float* __restrict__ draw, BlkGeom gdraw, float* __restrict__ dres,
+                                                                BlkGeom gdres, int dres_accumulate) {
+    const long total = (long)gdy.N * gdy.CB * gdy.D * gdy.H * gdy.W * 4;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int xx = (int)(t % gdy.W); t /= gdy.W;
+        const int yy = (int)(t % gdy.H); t /= gdy.H;
+        const int dd = (int)(t % gdy.D); t /= gdy.D;
+        const int cb = (int)(t % gdy.CB);
+        const int n = (int)(t / gdy.CB);
+        const int c = cb * 16 + q * 4;
+        f32x4 dz = *(const f32x4*)(dy + blk_off(gdy, n, cb, dd, yy, xx) + q * 4);
+        if (relu) {
+            const f32x4 yv = *(const f32x4*)(y + blk_off(gy, n, cb, dd, yy, xx) + q * 4);
+            dz.x = yv.x > 0.f ? dz.x : 0.f; dz.y = yv.y > 0.f ? dz.y : 0.f; dz.z = yv.z > 0.f ? dz.z : 0.f; dz.w = yv.w > 0.f ? dz.w : 0.f;
+        }
+        if (dres) {
+            float* dr = dres + blk_off(gdres, n, cb, dd, yy, xx) + q * 4;
+            *(f32x4*)dr = dres_accumulate ? *(const f32x4*)dr + dz : dz;
+        }
+        const f32x4 is = *(const f32x4*)(invstd + c);
+        const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + q * 4) - *(const f32x4*)(mean + c)) * is;
+        const f32x4 s1 = *(const f32x4*)(sums + c), s2 = *(const f32x4*)(sums + gdy.CB * 16 + c);
+        *(f32x4*)(draw + blk_off(gdraw, n, cb, dd, yy, xx) + q * 4) = *(const f32x4*)(gamma + c) * is * (dz - s1 * invM - xh * s2 * invM);
+    }
+}
+
+// dz only (sites without BN, or the plain residual/ReLU fan-out): dz = dy * [y>0]; used to seed residual gradients
+}  // namespace
+
+extern "C" {
+
+int drc_upsample_softargmin_bwd(const float* cost, const float* grad_disp, float* grad_cost, int N, int Dp, int Hp, int Wp, int D, int H,
+                                int W, int mindisp, void* stream) {
+    if (N < 0 || Dp <= 0 || Hp <= 0 || Wp <= 0 || D <= 0 || H <= 0 || W <= 0 || Dp > 96) return -2;
+    const long total = (long)N * H * W;
+    if (total == 0) return 0;
+    if (!cost || !grad_disp || !grad_cost) return -1;           // grad_cost is zero-filled by the caller
+    const unsigned blocks = (unsigned)((total + kSAThreads - 1) / kSAThreads);
+    hipLaunchKernelGGL(upsample_softargmin_bwd_kernel, dim3(blocks), dim3(kSAThreads), (size_t)2 * Dp * kSAThreads * 4, (hipStream_t)stream,
+                       cost, grad_disp, grad_cost, N, Dp, Hp, Wp, D, H, W, mindisp);
+    return (int)hipGetLastError();
+}
+
+int drc_conv3d_cout1_bwd_data(const float* grad_out, const float* w, float* grad_x_blk, int N, int cb_in, int D, int H, int W,
+                              int accumulate, void* stream) {
+    if (N < 0 || cb_in <= 0 || D <= 0 || H <= 0 || W <= 0) return -2;
+    const long total = (long)N * cb_in * D * H * W * 4;
+    if (total == 0) return 0;
+    if (!grad_out || !w || !grad_x_blk) return -1;
+    hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(grid_for(total, 8192)), dim3(kThreads), 0, (hipStream_t)stream, grad_out, w, grad_x_blk, N,
+                       cb_in, D, H, W, accumulate);
+    return (int)hipGetLastError();
+}
+
+int drc_conv3d_cout1_bwd_weight(const float* x_blk, const float* grad_out, float* grad_w, int N, int cb_in, int D, int H, int W,
+                                void* stream) {
+    if (N < 0 || cb_in <= 0 || D <= 0 || H <= 0 || W <= 0) return -2;
+    const long nvox = (long)N * D * H * W;
+    if (nvox == 0) return 0;
+    if (!x_blk || !grad_out || !grad_w) return -1;              // grad_w [27][cb_in*16] is zero-filled by the caller
+    long chunks = (nvox + 64 * 16 - 1) / (64 * 16);
+    if (chunks > 1024) chunks = 1024;
+    hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((unsigned)chunks, (unsigned)cb_in), dim3(kThreads), 0, (hipStream_t)stream, x_blk, grad_out,
+                       grad_w, N, cb_in, D, H, W);
+    return (int)hipGetLastError();
+}
+
+int drc_bn_bwd_reduce(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
+                      const float* mean, const float* invstd, int relu, float* sums, void* stream) {
+    if (!geom_ok(geom_dy) || !geom_ok(geom_raw) || (relu && !geom_ok(geom_y))) return -2;
+    if (geom_dy[0] == 0) return 0;
+    if (!dy || !raw || !mean || !invstd || !sums || (relu && !y)) return -1;
+    const BlkGeom g = to_geom(geom_dy);
+    const long nvox = (long)g.N * g.D * g.H * g.W;
+    long chunks = (nvox + 64 * 8 - 1) / (64 * 8);
+    if (chunks > 512) chunks = 512;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y,
+                       relu ? to_geom(geom_y) : g, raw, to_geom(geom_raw), mean, invstd, relu, sums);
+    return (int)hipGetLastError();
+}
+
+int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
+                     const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_count, int relu, float* draw,
+                     const int* geom_draw, float* dres, const int* geom_dres, int dres_accumulate, void* stream) {
+    if (!geom_ok(geom_dy) || !geom_ok(geom_raw) || !geom_ok(geom_draw) || (relu && !geom_ok(geom_y)) || (dres && !geom_ok(geom_dres))) return -2;
+    if (geom_dy[0] == 0) return 0;
+    if (!dy || !raw || !mean || !invstd || !gamma || !sums || !draw || (relu && !y)) return -1;
+    const BlkGeom g = to_geom(geom_dy);
+    const long total = (long)g.N * g.CB * g.D * g.H * g.W * 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y, relu ? to_geom(geom_y) : g,
+                       raw, to_geom(geom_raw), mean, invstd, gamma, sums, inv_count, relu, draw, to_geom(geom_draw), dres,
+                       dres ? to_geom(geom_dres) : g, dres_accumulate);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// wgrad.hip -- weight gradients of the tap-grid convolutions on v_mfma_f32_16x16x4_f32 (gfx950 / CDNA4).
+//
+//   gw[ca][cb][t] += sum_{n,o} a[n, ca, in_mul*o + tap_t] * b[n, cb, o]
+//
+// `a` is the tensor the taps slide over, `b` the tensor sampled at the plain positions o:
+//   Conv3d/Conv2d (any stride)      : a = x (layer input),  b = dy   -> gw[ci][co][t]     (weight.grad[co][ci][t])
+//   ConvTranspose3d k3 s2 p1 op1    : a = dy (in_mul = 2),  b = x    -> gw[co][ci][k]     (weight.grad[ci][co][k])
+// Reference: autograd of nn.Conv3d / nn.ConvTranspose3d / nn.Conv2d inside submodule.py:13-22, stackhourglass.py:22-30.
+//
+// GEMM view per tap: [16 a-channels x V] . [V x 16 b-channels], the voxel index is the MFMA k dimension.
+// A wave owns one (depth tap, a-channel block, b-channel block) job and walks its share of the (n, od, row tile, col tile)
+// groups, keeping the nh*nw accumulators of the job in registers; one atomicAdd flush at the end.  Per group it LDS-DMAs
+// the a tile (rows with halo, 16 ch) and the b tile (R x WT voxels, 16 ch) into its own LDS region; 2 waves per SIMD
+// overlap one wave's staging with the other's MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define WG_WAVES 4
+#define WG_MAXM 28   /* k-steps (4 voxels each) per group: R*WT <= 112 */
+
+namespace {
+
+template <int NT>   // taps per depth tap (nh*nw): 1, 2, 4, 9 (49 handled by NT=49 instantiation)
+__global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;   // a-channel (A operand row) / b-channel (B operand column)
+    const int g = lane >> 4;   // k member: voxel 4m+g
+
+    // job = (depth tap di, a block ca, b block cbb)
+    int job = blockIdx.y;
+    const int cbb = job % p.cb_b; job /= p.cb_b;
+    const int ca = job % p.cb_a;
+    const int di = job / p.cb_a;
+
+    const int n_wt = (p.OW + p.WT - 1) / p.WT;
+    const int n_rt = (p.OH + p.R - 1) / p.R;
+    const int groups = p.N * p.OD * n_rt * n_wt;
+    const int workers = gridDim.x * WG_WAVES;
+    const int rows_in = p.in_mul * (p.R - 1) + (p.nh - 1) * p.sh + 1;
+    const int seg_vox = p.in_mul * (p.WT - 1) + (p.nw - 1) * p.sw + 1;
+    const int a_floats = rows_in * seg_vox * 16;
+    const int nslots = p.R * p.WT;
+    const int nm = (nslots + 3) >> 2;
+    float* lds_a = lds_all + wave * (p.lds_bytes_per_wave >> 2);
+    float* lds_b = lds_a + a_floats;
+
+    // per-lane offsets of voxel slot 4m+g inside the a tile (tap (0,0)) and validity of the slot inside the tile
+    int a_off[WG_MAXM];
+    unsigned slot_ok = 0;
+#pragma unroll
+    for (int m = 0; m < WG_MAXM; ++m) {
+        const int s = 4 * m + g;
+        int r = s / p.WT, c = s - r * p.WT;
+        if (s < nslots) slot_ok |= 1u << m; else { r = 0; c = 0; }
+        a_off[m] = (p.in_mul * r * seg_vox + p.in_mul * c) * 16 + j;
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int gid = blockIdx.x * WG_WAVES + wave; gid < groups; gid += workers) {
+        int q = gid;
+        const int wt = q % n_wt; q /= n_wt;
+        const int rt = q % n_rt; q /= n_rt;
+        const int od = q % p.OD;
+        const int n = q / p.OD;
+        const int oh0 = rt * p.R, ow0 = wt * p.WT;
+        // ---- stage the a tile (rows_in x seg_vox x 16 ch) and the b tile (R x WT x 16 ch)
+        const float* asrc = p.a + (int64_t)n * p.a_n_stride + (int64_t)ca * p.a_cb_stride +
+                            (int64_t)(p.in_mul * od + p.dd0 + di * p.sd) * p.a_d_stride +
+                            (int64_t)(p.in_mul * oh0 + p.dh0) * p.a_h_stride + (int64_t)(p.in_mul * ow0 + p.dw0) * 16;
+        const int a_units = seg_vox * 4;
+        for (int r = 0; r < rows_in; ++r)
+            for (int u0 = 0; u0 < a_units; u0 += 64) {
+                const int u = u0 + lane;
+                if (u < a_units)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(asrc + (int64_t)r * p.a_h_stride + u * 4), LDS_PTR(lds_a + r * seg_vox * 16 + u0 * 4), 16, 0, 0);
+            }
+        const float* bsrc = p.b + p.b_off0 + (int64_t)n * p.b_n_stride + (int64_t)cbb * p.b_cb_stride + (int64_t)od * p.b_d_stride +
+                            (int64_t)oh0 * p.b_h_stride + (int64_t)ow0 * 16;
+        const int b_units = p.WT * 4;
+        for (int r = 0; r < p.R; ++r)
+            for (int u0 = 0; u0 < b_units; u0 += 64) {
+                const int u = u0 + lane;
+                if (u < b_units)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(bsrc + (int64_t)r * p.b_h_stride + u * 4), LDS_PTR(lds_b + r * p.WT * 16 + u0 * 4), 16, 0, 0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // slots that fall outside the output grid (ragged last tiles) contribute nothing: zero their b values
+        unsigned ok = slot_ok;
+        if (oh0 + p.R > p.OH || ow0 + p.WT > p.OW) {
+#pragma unroll
+            for (int m = 0; m < WG_MAXM; ++m) {
+                const int s = 4 * m + g;
+                const int r = s / p.WT, c = s - r * p.WT;
+                if (oh0 + r >= p.OH || ow0 + c >= p.OW) ok &= ~(1u << m);
+            }
+        }
+        // ---- accumulate: for every k-step read B once, then one MFMA per tap with the tap-shifted A value
+#pragma unroll
+        for (int m = 0; m < WG_MAXM; ++m) {
+            if (m < nm) {                                   // wave-uniform
+                const float bv = ((ok >> m) & 1u) ? lds_b[(4 * m + g) * 16 + j] : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tb = t / p.nw, tc = t - tb * p.nw;
+                    const float av = lds_a[a_off[m] + (tb * p.sh * seg_vox + tc * p.sw) * 16];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // all LDS reads of this group are consumed by the MFMAs above before the next group's DMA is issued (in-order wave)
+    }
+
+    // ---- flush: D[i = a channel][j = b channel]: lane holds rows 4g..4g+3 of column j
+    const int ntaps = p.nd * p.nh * p.nw;
+    const int cbt = p.cb_b * 16;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tg = di * (p.nh * p.nw) + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ia = ca * 16 + g * 4 + r, ib = cbb * 16 + j;
+            atomicAdd(p.gw + ((int64_t)ia * cbt + ib) * ntaps + tg, acc[t][r]);
+        }
+    }
+}
+
+template <int NT>
+int launch(const drc_wgrad_params& p, hipStream_t s) {
+    const long groups = (long)p.N * p.OD * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
+    const long jobs = (long)p.nd * p.cb_a * p.cb_b;
+    long workers = 8192 / (jobs > 0 ? jobs : 1);            // ~8 waves per SIMD-slot pair across the chip
+    if (workers > groups) workers = groups;
+    if (workers < 1) workers = 1;
+    const size_t lds = (size_t)p.lds_bytes_per_wave * WG_WAVES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((workers + WG_WAVES - 1) / WG_WAVES), (unsigned)jobs, 1);
+    hipLaunchKernelGGL((wgrad_kernel<NT>), grid, dim3(64 * WG_WAVES), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int drc_tapconv_wgrad(const drc_wgrad_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_wgrad_params& p = *pp;
+    if (!p.a || !p.b || !p.gw) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0 || p.cb_a <= 0 || p.cb_b <= 0) return -2;
+    if (p.N == 0) return 0;
+    if ((p.in_mul != 1 && p.in_mul != 2) || p.nd < 1 || p.nh < 1 || p.nw < 1 || p.dd0 < 0 || p.dh0 < 0 || p.dw0 < 0) return -2;
+    if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 112) return -3;
+    const int rows_in = p.in_mul * (p.R - 1) + (p.nh - 1) * p.sh + 1;
+    const int seg_vox = p.in_mul * (p.WT - 1) + (p.nw - 1) * p.sw + 1;
+    const int need = (rows_in * seg_vox + p.R * p.WT) * 64;
+    if (p.lds_bytes_per_wave < need || (p.lds_bytes_per_wave & 15) || (size_t)p.lds_bytes_per_wave * WG_WAVES > 160 * 1024) return -5;
+    hipStream_t s = (hipStream_t)stream;
+    switch (p.nh * p.nw) {
+        case 1: return launch<1>(p, s);
+        case 2: return launch<2>(p, s);
+        case 4: return launch<4>(p, s);
+        case 9: return launch<9>(p, s);
+        case 49: return launch<49>(p, s);
+    }
+    return -4;
+}

@@ -15,7 +15,9 @@ class _Conv:
 
     def __init__(self, conv, bn, device, transposed=False):
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
+        self.conv, self.transposed = conv, transposed
         self.cout = w.shape[1] if transposed else w.shape[0]
+        self.cin = w.shape[0] if transposed else w.shape[1]
         self.w = E.pack_weight(w, transposed)
         cout_pad = self.w.shape[3]
         self.bn = bn
@@ -43,6 +45,7 @@ class PSMNetRuntime:
         self._w = None
         self._ws = {}      # workspaces: key -> dict of tensors/plans
         self._training = False
+        self._tape = None       # list of recorded ops while a differentiable train-mode forward runs
 
     def invalidate(self):
         self._weights_version = None
@@ -128,6 +131,8 @@ class PSMNetRuntime:
         else:
             E.bn_apply(raw, yt, rs, mean, invstd, c.gamma, c.beta, relu)
         ws.setdefault("saved", {})[plan] = (mean, invstd, M)
+        if self._tape is not None:
+            self._tape.append(("site", ws, plan, wname, x, y, res))
 
     # ------------------------------------------------------------------ 3D regressor
     def _ws3d(self, N, Dp, Hp, Wp):
@@ -144,7 +149,7 @@ class PSMNetRuntime:
             raise ValueError(f"cost-volume dims {full} must be divisible by 4 (D,H,W multiples of 16; SURVEY 8)")
         t = {}
         t["cost"] = B(64, *full)
-        for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t"):
+        for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t1", "cls_t2", "cls_t3"):
             t[n] = B(32, *full)
         for k in (1, 2, 3):
             t[f"hg{k}.c1"] = B(64, *half); t[f"hg{k}.pre"] = B(64, *half); t[f"hg{k}.post"] = B(64, *half)
@@ -164,7 +169,7 @@ class PSMNetRuntime:
             p[f"hg{k}.conv4"] = E.plan_conv3d(t[f"hg{k}.c3"], t[f"hg{k}.c4"], 1, 64, True)
             p[f"hg{k}.conv5"] = E.plan_deconv3d(t[f"hg{k}.c4"], t[f"hg{k}.post"], 64, True)
             p[f"hg{k}.conv6"] = E.plan_deconv3d(t[f"hg{k}.post"], t[f"out{k}"], 32, False)
-            p[f"classif{k}.0"] = E.plan_conv3d(t[f"out{k}"], t["cls_t"], 1, 32, True)
+            p[f"classif{k}.0"] = E.plan_conv3d(t[f"out{k}"], t[f"cls_t{k}"], 1, 32, True)
         ws = dict(t=t, p=p, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
         self._ws[key] = ws
         return ws
@@ -192,8 +197,8 @@ class PSMNetRuntime:
             run(f"hg{k}.conv6", hg + ".conv6", f"hg{k}.post", f"out{k}", res="cost0")    # out_k = conv6 + cost0
         prev = None
         for k in (1, 2, 3):
-            run(f"classif{k}.0", f"classif{k}.0", f"out{k}", "cls_t")
-            E.conv3d_cout1(t["cls_t"], W[f"classif{k}.2"], prev, t[f"costk{k}"])             # cumulative heads
+            run(f"classif{k}.0", f"classif{k}.0", f"out{k}", f"cls_t{k}")
+            E.conv3d_cout1(t[f"cls_t{k}"], W[f"classif{k}.2"], prev, t[f"costk{k}"])          # cumulative heads
             prev = t[f"costk{k}"]
         return t["costk1"], t["costk2"], t["costk3"]
 
@@ -214,22 +219,33 @@ class PSMNetRuntime:
 
     def forward_features(self, fl, fr, out_hw, training=False):
         self._training = bool(training)
-        if training and torch.is_grad_enabled() and (fl.requires_grad or any(p.requires_grad for p in self.model.parameters())):
-            raise NotImplementedError("backward through the HIP engine is not built yet: run the train-mode forward under "
-                                      "torch.no_grad() (batch-statistics BN, 3 heads), or train through the reference")
+        params = [p for p in self.model.parameters() if p.requires_grad and not self._is_fe_param(p)]
+        if training and torch.is_grad_enabled() and (fl.requires_grad or fr.requires_grad or params):
+            return _RegressorTrainFn.apply(self, tuple(out_hw), fl, fr, *params)
+        return self._forward_features_impl(fl, fr, out_hw, training)
+
+    def _is_fe_param(self, p):
+        ids = getattr(self, "_fe_ids", None)
+        if ids is None:
+            ids = self._fe_ids = {id(q) for q in self.model.feature_extraction.parameters()}
+        return id(p) in ids
+
+    def _forward_features_impl(self, fl, fr, out_hw, training):
         E.require_gpu(fl, "PSMNet features"); E.require_gpu(fr, "PSMNet features")
         mx, mn = self._check_disp()
         N, C, Hp, Wp = fl.shape
         H, W = out_hw
         if C != 32:
             raise ValueError("feature maps must have 32 channels")
-        disp = torch.empty(N, H, W, dtype=torch.float32, device=self.device)
         if N == 0:
-            return disp            # empty ROI batch (reference: disprcnn3d.py:272-275)
+            z = torch.empty(0, H, W, dtype=torch.float32, device=self.device)
+            return (z, z.clone(), z.clone()) if training else z       # empty ROI batch (reference: disprcnn3d.py:272-275)
         Wt = self._compile()
         ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
         E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
-        return self._heads(self._regress(ws, Wt), N, H, W, mx, mn, training)
+        costs = self._regress(ws, Wt)
+        self._last_train = (ws, Wt, costs, mx, mn, (H, W))
+        return self._heads(costs, N, H, W, mx, mn, training)
 
     # ------------------------------------------------------------------ 2D feature CNN
     def _ws2d(self, N, H, W, side=None):
@@ -366,3 +382,36 @@ class PSMNetRuntime:
             right_view = fv[N * feat.n_stride:]
             E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
         return self._heads(self._regress(ws3, Wt), N, H, W, mx, mn, training)
+
+
+class _RegressorTrainFn(torch.autograd.Function):
+    """Differentiable train-mode pass from the feature boundary: forward on the HIP engine (tape recorded), backward by
+    modeling/psmnet/train.py.  One forward/backward pair per input shape may be in flight (workspaces are reused)."""
+
+    @staticmethod
+    def forward(ctx, rt, out_hw, fl, fr, *params):
+        rt._tape = []
+        rt._need_input_grad = bool(fl.requires_grad or fr.requires_grad)
+        try:
+            preds = rt._forward_features_impl(fl.detach(), fr.detach(), out_hw, True)
+            ctx.tape, ctx.info = rt._tape, rt._last_train
+        finally:
+            rt._tape = None
+        ctx.rt, ctx.params, ctx.need_in = rt, params, rt._need_input_grad
+        ctx.feat_shape = tuple(fl.shape)
+        return preds
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        from .train import RegressorBackward
+        rt = ctx.rt
+        ws, Wt, costs, mx, mn, out_hw = ctx.info
+        bw = RegressorBackward(rt, ws, Wt)
+        rt._need_input_grad = ctx.need_in
+        G = bw.run(ctx.tape, (g1, g2, g3), costs, mx, mn, out_hw)
+        gfl = gfr = None
+        if ctx.need_in:
+            from ... import ops
+            gcost = G.get("cost").to_dense()
+            gfl, gfr = ops.cost_volume_backward(gcost, mx, mn)
+        return (None, None, gfl, gfr) + tuple(bw.pg.get(id(p)) for p in ctx.params)

@@ -194,6 +194,45 @@ int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, f
 int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int* geom_y, const float* res, const int* geom_r,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Backward kernels (autograd of stackhourglass.py:130-174 in the reference).  Data gradients of the MFMA convolutions
+ * reuse drc_tapconv_fwd / drc_tapconv3d_slide_fwd with transformed weights (disprcnn_amd/autograd.py).
+ *   drc_upsample_softargmin_bwd : grad_cost [N,Dp,Hp,Wp] (caller-zeroed) += d disp / d cost * grad_disp [N,H,W]
+ *   drc_conv3d_cout1_bwd_data   : grad of the 32->1 classifier conv w.r.t. its blocked input (assign or accumulate)
+ *   drc_conv3d_cout1_bwd_weight : grad_w [27][cb_in*16] (caller-zeroed) += sum x * grad_out
+ *   drc_bn_bwd_reduce / _apply  : training-mode BatchNorm backward with the ReLU mask and the residual fan-out fused:
+ *        dz = dy*[y>0];  sums = {sum dz, sum dz*xhat};  draw = gamma*invstd*(dz - sums0/M - xhat*sums1/M);  dres (=|+=) dz */
+int drc_upsample_softargmin_bwd(const float* cost, const float* grad_disp, float* grad_cost, int N, int Dp, int Hp, int Wp, int D, int H,
+                                int W, int mindisp, void* stream);
+int drc_conv3d_cout1_bwd_data(const float* grad_out, const float* w, float* grad_x_blk, int N, int cb_in, int D, int H, int W,
+                              int accumulate, void* stream);
+int drc_conv3d_cout1_bwd_weight(const float* x_blk, const float* grad_out, float* grad_w, int N, int cb_in, int D, int H, int W,
+                                void* stream);
+int drc_bn_bwd_reduce(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
+                      const float* mean, const float* invstd, int relu, float* sums, void* stream);
+int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
+                     const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_count, int relu, float* draw,
+                     const int* geom_draw, float* dres, const int* geom_dres, int dres_accumulate, void* stream);
+
+/* Weight gradient of a tap-grid convolution (one Cartesian tap class) on the fp32 MFMA:
+ *   gw[ca][cb][t] += sum_{n,o} a[n, ca, in_mul*o + tap_t] * b[n, cb, o],   t = (td*nh + th)*nw + tw
+ * a: blocked tensor the taps slide over (a_* strides in floats, tap offsets dd0/dh0/dw0 + k*sd/sh/sw in padded coordinates);
+ * b: blocked tensor read at the plain positions o (b_off0 = float offset of logical voxel (0,0,0));
+ * gw: dense fp32 [cb_a*16][cb_b*16][nd*nh*nw], zero-filled by the caller (atomicAdd accumulation).
+ * Conv: a = layer input, b = grad of the conv output.  ConvTranspose k3 s2: a = grad of the output (in_mul = 2), b = input. */
+typedef struct drc_wgrad_params {
+    const float* a;
+    const float* b;
+    float* gw;
+    int64_t a_n_stride, a_cb_stride, a_d_stride, a_h_stride;
+    int64_t b_n_stride, b_cb_stride, b_d_stride, b_h_stride, b_off0;
+    int32_t N, OD, OH, OW;      /* grid of b (positions o) */
+    int32_t in_mul, cb_a, cb_b;
+    int32_t nd, nh, nw, dd0, dh0, dw0, sd, sh, sw;
+    int32_t R, WT, lds_bytes_per_wave;   /* >= ((rows_in*seg_vox) + R*WT) * 64 */
+} drc_wgrad_params;
+int drc_tapconv_wgrad(const drc_wgrad_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,9 +96,50 @@ def test_train_forward_images_vs_reference_golden(dev):
     assert abs(loss.item() - float(z["Bt_loss"])) < 2e-3 * float(z["Bt_loss"])
 
 
-def test_backward_is_refused_loudly(dev):
+def test_backward_from_features_vs_oracle_autograd(dev):
+    """loss.backward() through the HIP engine (BN-train backward, dgrad via the forward engine, MFMA wgrad, classifier /
+    soft-argmin / cost-volume adjoints) vs torch autograd of the CPU oracle.  Tolerance 2e-3 * max|ref| per tensor."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
-    m = PSMNet(48, 0).to(dev).train()
-    fl, fr = synth.synth_features(1, 32, 28, 28, tag="nograd")
+    from disprcnn_amd.utils.loss_utils import PSMLoss
+    sd = state_for("At")
+    m = PSMNet(48, 0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    fl, fr = synth.synth_features(2, 32, 28, 28, tag="bwdA")
+    tgt = synth.hash_uniform("bwd:t", (2, 112, 112), 0.0, 47.0)
+    mask = (synth.hash_uniform("bwd:m", (2, 112, 112), 0.0, 1.0) > 0.3).to(torch.uint8)
+    gl, gr = fl.to(dev).requires_grad_(True), fr.to(dev).requires_grad_(True)
+    preds = m.forward_from_features(gl, gr, (112, 112))
+    loss = PSMLoss()(preds, {"disparity": tgt.to(dev), "mask": mask.to(dev)})
+    loss.backward()
+    # oracle
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+           for k, v in sd.items()}
+    rl, rr = fl.clone().requires_grad_(True), fr.clone().requires_grad_(True)
+    rp = O.psmnet_from_features(sdr, rl, rr, 48, 0, 112, 112, training=True)
+    rloss = O.psm_loss(rp, tgt, mask)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) < 1e-3 * abs(rloss.item())
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, v in sdr.items():
+        if not (torch.is_tensor(v) and v.requires_grad) or k.startswith("feature_extraction"):
+            continue
+        ref = v.grad
+        got = named[k].grad
+        assert got is not None, k
+        scale = ref.abs().max().item() + 1e-12
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+        checked += 1
+    assert checked == 514 - 361 - sum(1 for k in sd if not k.startswith("feature_extraction") and k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+    for got, ref in ((gl.grad, rl.grad), (gr.grad, rr.grad)):
+        assert (got.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-7
+
+
+def test_backward_through_images_is_refused_loudly(dev):
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    m = PSMNet(48, -48).to(dev).train()
+    l, r = synth.synth_images(1, 224, 224, tag="nograd")
     with pytest.raises(NotImplementedError):
-        m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112))
+        m((l.to(dev), r.to(dev)))
