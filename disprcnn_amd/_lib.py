@@ -72,13 +72,15 @@ _SIGS = {
     "drc_roi_align_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "drc_roi_align_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "drc_align_roi_pairs": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P]),
+    "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P, _P]),
     "drc_bn_apply_blocked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "drc_tapconv_wgrad": (_I, [C.POINTER(DrcWgradParams), _P]),
+    "drc_bilinear_up_blocked_bwd": (_I, [_P, _P, _P, _P, _P]),
+    "drc_avgpool2d_blocked_bwd": (_I, [_P, _P, _P, _P, _I, _P]),
     "drc_upsample_softargmin_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv3d_cout1_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv3d_cout1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "drc_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "drc_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "drc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P, _I, _P]),
     "drc_psm_loss_sums": (_I, [_P, _P, _P, _P, _P, C.c_int64, _P, _P]),
     "drc_psm_loss_grad": (_I, [_P, _P, _P, C.c_int64, _P, C.c_float, _P, _P, _P]),

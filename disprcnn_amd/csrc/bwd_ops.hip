@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/disprcnn_hip.h"
+#include "det_reduce.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -21,13 +22,13 @@ inline unsigned grid_for(long work, long cap = 4096) {
     return (unsigned)b;
 }
 
-struct BlkGeom { int N, CB, D, H, W, pd, ph, pw; };
+struct BlkGeom { int N, CB, D, H, W, pd, ph, pw, cb_total, cb_off; };   // CB blocks [cb_off, cb_off+CB) of cb_total
 __device__ __forceinline__ long blk_off(const BlkGeom& g, int n, int cb, int d, int y, int x) {
     const long Wp = g.W + 2 * g.pw, Hp = g.H + 2 * g.ph, Dp = g.D + 2 * g.pd;
-    return ((((long)n * g.CB + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
+    return ((((long)n * g.cb_total + g.cb_off + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
 }
-inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0; }
-inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]}; }
+inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0 && g[9] >= 0 && g[9] + g[1] <= g[8]; }
+inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9]}; }
 
 // ------------------------------------------------------------------------------------------------ a7 backward
 // disp = sum_d p_d * dval_d, p = softmax_d(c_up), c_up = trilinear(cost).  d disp / d c_up[d] = p_d (dval_d - disp).
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void cout1_bwd_data_kernel(const float* _
                                                                   float* __restrict__ gx, int N, int cb_in, int D, int H, int W,
                                                                   int accumulate) {
     const long total = (long)N * cb_in * D * H * W * 4;
-    const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1};
+    const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1, cb_in, 0};
     for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
         long t = idx;
         const int q = (int)(t & 3); t >>= 2;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void cout1_bwd_weight_kernel(const float*
                                                                     float* __restrict__ gw, int N, int cb_in, int D, int H, int W) {
     const int cb = blockIdx.y;
     const int q = threadIdx.x & 3;
-    const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1};
+    const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1, cb_in, 0};
     const long nvox = (long)N * D * H * W;
     f32x4 acc[27];
 #pragma unroll
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void cout1_bwd_weight_kernel(const float*
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __restrict__ dy, BlkGeom gdy, const float* __restrict__ y,
                                                                  BlkGeom gy, const float* __restrict__ raw, BlkGeom graw,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                                 float* __restrict__ sums) {
+                                                                 float* __restrict__ sums, float* scratch) {
     const int cb = blockIdx.y;
     const int q = threadIdx.x & 3;
     const long nvox = (long)gdy.N * gdy.D * gdy.H * gdy.W;
@@ -223,12 +224,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
         for (int k = 0; k < 8; ++k) red[w][lane][k] = r[k];
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        const int qq = threadIdx.x >> 3, k = threadIdx.x & 7;
-        float v = 0.f;
+    const int qq = (threadIdx.x >> 3) & 3, k = threadIdx.x & 7;
+    float v = 0.f;
+    if (threadIdx.x < 32)
         for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
-        atomicAdd(sums + (k >> 2) * gdy.CB * 16 + cb * 16 + qq * 4 + (k & 3), v);
-    }
+    drc_det::finish(v, cb, gdy.CB, cb * 16 + qq * 4 + (k & 3), k >> 2, sums, scratch);
 }
 
 // draw = gamma * invstd * (dz - sum_dz/M - xhat * sum_dzx/M);  optionally dres (=|+=) dz
@@ -261,6 +261,56 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
         const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + q * 4) - *(const f32x4*)(mean + c)) * is;
         const f32x4 s1 = *(const f32x4*)(sums + c), s2 = *(const f32x4*)(sums + gdy.CB * 16 + c);
         *(f32x4*)(draw + blk_off(gdraw, n, cb, dd, yy, xx) + q * 4) = *(const f32x4*)(gamma + c) * is * (dz - s1 * invM - xh * s2 * invM);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ SPP backward (2D)
+// adjoint of bilinear (align_corners=True) upsampling: every fine pixel scatters to its 4 coarse neighbours
+__global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const float* __restrict__ gy, BlkGeom gg, float* __restrict__ gx, BlkGeom gxg) {
+    const long total = (long)gg.N * gg.CB * gg.H * gg.W * 4;
+    const int IH = gxg.H, IW = gxg.W, OH = gg.H, OW = gg.W;
+    const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+    const float sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH); t /= OH;
+        const int cb = (int)(t % gg.CB);
+        const int n = (int)(t / gg.CB);
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < IH - 1), x1 = x0 + (x0 < IW - 1);
+        const float ty = fy - y0, tx = fx - x0;
+        const f32x4 g = *(const f32x4*)(gy + blk_off(gg, n, cb, 0, oy, ox) + q * 4);
+        float* p00 = gx + blk_off(gxg, n, cb, 0, y0, x0) + q * 4;
+        float* p01 = gx + blk_off(gxg, n, cb, 0, y0, x1) + q * 4;
+        float* p10 = gx + blk_off(gxg, n, cb, 0, y1, x0) + q * 4;
+        float* p11 = gx + blk_off(gxg, n, cb, 0, y1, x1) + q * 4;
+        const float w00 = (1.f - ty) * (1.f - tx), w01 = (1.f - ty) * tx, w10 = ty * (1.f - tx), w11 = ty * tx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(p00 + e, g[e] * w00); atomicAdd(p01 + e, g[e] * w01); atomicAdd(p10 + e, g[e] * w10); atomicAdd(p11 + e, g[e] * w11);
+        }
+    }
+}
+
+// adjoint of AvgPool2d(k,k): gx[y,x] += gy[y/k, x/k] / k^2 inside the pooled region
+__global__ __launch_bounds__(kThreads) void avgpool2d_bwd_kernel(const float* __restrict__ gy, BlkGeom gg, float* __restrict__ gx, BlkGeom gxg, int k) {
+    const long total = (long)gxg.N * gxg.CB * gxg.H * gxg.W * 4;
+    const float inv = 1.f / (float)(k * k);
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int q = (int)(t & 3); t >>= 2;
+        const int x = (int)(t % gxg.W); t /= gxg.W;
+        const int y = (int)(t % gxg.H); t /= gxg.H;
+        const int cb = (int)(t % gxg.CB);
+        const int n = (int)(t / gxg.CB);
+        const int oy = y / k, ox = x / k;
+        if (oy >= gg.H || ox >= gg.W) continue;
+        float* dst = gx + blk_off(gxg, n, cb, 0, y, x) + q * 4;
+        *(f32x4*)dst = *(const f32x4*)dst + *(const f32x4*)(gy + blk_off(gg, n, cb, 0, oy, ox) + q * 4) * inv;
     }
 }
 
@@ -306,16 +356,16 @@ int drc_conv3d_cout1_bwd_weight(const float* x_blk, const float* grad_out, float
 }
 
 int drc_bn_bwd_reduce(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
-                      const float* mean, const float* invstd, int relu, float* sums, void* stream) {
+                      const float* mean, const float* invstd, int relu, float* sums, float* scratch, void* stream) {
     if (!geom_ok(geom_dy) || !geom_ok(geom_raw) || (relu && !geom_ok(geom_y))) return -2;
     if (geom_dy[0] == 0) return 0;
-    if (!dy || !raw || !mean || !invstd || !sums || (relu && !y)) return -1;
+    if (!dy || !raw || !mean || !invstd || !sums || !scratch || (relu && !y)) return -1;
     const BlkGeom g = to_geom(geom_dy);
     const long nvox = (long)g.N * g.D * g.H * g.W;
     long chunks = (nvox + 64 * 8 - 1) / (64 * 8);
-    if (chunks > 512) chunks = 512;
+    if (chunks > DRC_BN_MAX_CHUNKS) chunks = DRC_BN_MAX_CHUNKS;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y,
-                       relu ? to_geom(geom_y) : g, raw, to_geom(geom_raw), mean, invstd, relu, sums);
+                       relu ? to_geom(geom_y) : g, raw, to_geom(geom_raw), mean, invstd, relu, sums, scratch);
     return (int)hipGetLastError();
 }
 
@@ -330,6 +380,26 @@ int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const 
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y, relu ? to_geom(geom_y) : g,
                        raw, to_geom(geom_raw), mean, invstd, gamma, sums, inv_count, relu, draw, to_geom(geom_draw), dres,
                        dres ? to_geom(geom_dres) : g, dres_accumulate);
+    return (int)hipGetLastError();
+}
+
+int drc_bilinear_up_blocked_bwd(const float* grad_y, const int* geom_y, float* grad_x, const int* geom_x, void* stream) {
+    if (!geom_ok(geom_y) || !geom_ok(geom_x) || geom_y[0] != geom_x[0] || geom_y[1] != geom_x[1]) return -2;
+    if (geom_y[0] == 0) return 0;
+    if (!grad_y || !grad_x) return -1;                  // grad_x must be zero-filled (or hold earlier contributions)
+    const BlkGeom g = to_geom(geom_y);
+    hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3(grid_for((long)g.N * g.CB * g.H * g.W * 4)), dim3(kThreads), 0, (hipStream_t)stream, grad_y, g,
+                       grad_x, to_geom(geom_x));
+    return (int)hipGetLastError();
+}
+
+int drc_avgpool2d_blocked_bwd(const float* grad_y, const int* geom_y, float* grad_x, const int* geom_x, int k, void* stream) {
+    if (!geom_ok(geom_y) || !geom_ok(geom_x) || geom_y[0] != geom_x[0] || geom_y[1] != geom_x[1] || k <= 0) return -2;
+    if (geom_y[0] == 0) return 0;
+    if (!grad_y || !grad_x) return -1;                  // accumulates into grad_x
+    const BlkGeom g = to_geom(geom_x);
+    hipLaunchKernelGGL(avgpool2d_bwd_kernel, dim3(grid_for((long)g.N * g.CB * g.H * g.W * 4)), dim3(kThreads), 0, (hipStream_t)stream, grad_y,
+                       to_geom(geom_y), grad_x, g, k);
     return (int)hipGetLastError();
 }
 

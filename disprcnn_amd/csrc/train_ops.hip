@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/disprcnn_hip.h"
+#include "det_reduce.h"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -108,16 +109,16 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
 //   bn_bwd_reduce / bn_bwd_apply : the standard BN backward with the ReLU mask and residual fan-out fused
 namespace {
 
-struct BlkGeom { int N, CB, D, H, W, pd, ph, pw; };
+struct BlkGeom { int N, CB, D, H, W, pd, ph, pw, cb_total, cb_off; };   // CB blocks [cb_off, cb_off+CB) of cb_total
 
 __device__ __forceinline__ long blk_off(const BlkGeom& g, int n, int cb, int d, int y, int x) {
     const long Wp = g.W + 2 * g.pw, Hp = g.H + 2 * g.ph, Dp = g.D + 2 * g.pd;
-    return ((((long)n * g.CB + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
+    return ((((long)n * g.cb_total + g.cb_off + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
 }
 
 // grid: (chunks, CB); each block walks a slice of the (n,d,y,x) voxels of one channel block; thread = float4 quad of a voxel
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, BlkGeom g, const float* __restrict__ shift,
-                                                            float* __restrict__ sums /* [2][CB*16] */) {
+                                                            float* __restrict__ sums /* [2][CB*16] */, float* scratch) {
     const int cb = blockIdx.y;
     const int q = threadIdx.x & 3;
     const long nvox = (long)g.N * g.D * g.H * g.W;
@@ -146,13 +147,11 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
         for (int k = 0; k < 8; ++k) red[w][lane][k] = r[k];
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        const int qq = threadIdx.x >> 3, k = threadIdx.x & 7;
-        float v = 0.f;
+    const int qq = (threadIdx.x >> 3) & 3, k = threadIdx.x & 7;
+    float v = 0.f;
+    if (threadIdx.x < 32)
         for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
-        const int c = cb * 16 + qq * 4 + (k & 3);
-        atomicAdd(sums + (k >> 2) * g.CB * 16 + c, v);
-    }
+    drc_det::finish(v, cb, g.CB, cb * 16 + qq * 4 + (k & 3), k >> 2, sums, scratch);
 }
 
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ x, BlkGeom gx, float* __restrict__ y, BlkGeom gy,
@@ -178,23 +177,23 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
     }
 }
 
-inline bool geom_ok(const int* g) { return g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0; }
-inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]}; }
+inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0 && g[9] >= 0 && g[9] + g[1] <= g[8]; }
+inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9]}; }
 
 }  // namespace
 
 extern "C" {
 
-int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, void* stream) {
-    if (!geom8 || !geom_ok(geom8)) return -2;
+int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, float* scratch, void* stream) {
+    if (!geom_ok(geom8)) return -2;
     if (geom8[0] == 0) return 0;
-    if (!x || !sums) return -1;
+    if (!x || !sums || !scratch) return -1;
     const BlkGeom g = to_geom(geom8);
     const long nvox = (long)g.N * g.D * g.H * g.W;
     long chunks = (nvox + (kThreads / 4) * 8 - 1) / ((kThreads / 4) * 8);
     if (chunks < 1) chunks = 1;
-    if (chunks > 512) chunks = 512;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, shift, sums);
+    if (chunks > DRC_BN_MAX_CHUNKS) chunks = DRC_BN_MAX_CHUNKS;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, shift, sums, scratch);
     return (int)hipGetLastError();
 }
 

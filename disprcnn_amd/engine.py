@@ -163,6 +163,24 @@ def taps_deconv3d_k3s2(pad_in=(1, 1, 1)):
     return classes
 
 
+def taps_deconv2d_s2(k, pad_in=(0, 1, 1)):
+    """2D transposed convolution, stride 2, output exactly twice the input -- the data gradient of Conv2d(k, stride 2,
+    pad (k-1)//2) on an even-sized map.  k=3: four output-parity classes (same 1-D pattern as the 3D case);
+    k=1: only the even positions receive a tap (the caller zero-fills the others)."""
+    if k == 1:
+        return [dict(n=(1, 1, 1), first=tuple(pad_in), step=(1, 1, 1), wbase=0, wstep=(0, 0, 0), off=(0, 0, 0))]
+    assert k == 3
+    classes = []
+    for ph_ in (0, 1):
+        for pw_ in (0, 1):
+            par = (ph_, pw_)
+            n = (1,) + tuple(2 if q else 1 for q in par)
+            wbase = sum((2 if q else 1) * ks for q, ks in zip(par, (3, 1)))
+            wstep = (0,) + tuple(-2 * ks if q else 0 for q, ks in zip(par, (3, 1)))
+            classes.append(dict(n=n, first=tuple(pad_in), step=(1, 1, 1), wbase=wbase, wstep=wstep, off=(0,) + par))
+    return classes
+
+
 def class_taps(c):
     """Enumerate (dd, dh, dw, widx) of a tap-grid class (host-side mirror of the kernel's arithmetic)."""
     out = []
@@ -300,6 +318,12 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
     return ConvPlan(x, y, classes, stride, 1, (1, y.H, y.W), cout, relu)
 
 
+def plan_deconv2d(x, y, k, cout, relu=False):
+    """2D transposed conv (k in {1,3}, stride 2) on blocked tensors: y is exactly twice x."""
+    assert x.pd == 0 and x.D == 1 and (y.H, y.W) == (2 * x.H, 2 * x.W) and x.ph >= 1 and x.pw >= 1
+    return ConvPlan(x, y, taps_deconv2d_s2(k, (0, x.ph, x.pw)), 1, 2, (1, x.H, x.W), cout, relu)
+
+
 # ------------------------------------------------------------------------------------------- other ops
 def cost_volume_blocked(left, right, out, lo4, hi4, in_blocked_pad=0):
     """left/right NCHW (or blocked 2D) -> out: Blocked [N,2C,Dp,Hp,Wp] halo 1."""
@@ -325,8 +349,24 @@ def upsample_softargmin(cost, disp, maxdisp, mindisp):
 
 # ------------------------------------------------------------------------------------------- train-mode BatchNorm
 def _geom8(t):
+    """int[10] geometry {N, CB, D, H, W, pd, ph, pw, cb_total, cb_off} of a Blocked tensor or a BlockedSlice of one."""
     import ctypes
-    return (ctypes.c_int * 8)(t.N, t.cb, t.D, t.H, t.W, t.pd, t.ph, t.pw)
+    base = getattr(t, "base", None)
+    return (ctypes.c_int * 10)(t.N, t.cb, t.D, t.H, t.W, t.pd, t.ph, t.pw, base.cb if base is not None else t.cb,
+                                t.cb_off if base is not None else 0)
+
+
+_BN_SCRATCH = {}
+BN_MAX_CHUNKS = 512
+
+
+def bn_scratch(dev, cb):
+    """Partials + ticket words of the fixed-order BatchNorm reductions, one per (device, stream); tickets start (and end) at zero."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, cb)   # ticket offset depends on cb
+    buf = _BN_SCRATCH.get(key)
+    if buf is None:
+        buf = _BN_SCRATCH[key] = torch.zeros(BN_MAX_CHUNKS * cb * 32 + cb, dtype=torch.float32, device=dev)
+    return buf
 
 
 def bn_batch_stats(raw):
@@ -334,13 +374,14 @@ def bn_batch_stats(raw):
     dev = raw.device
     C16 = raw.cb * CB
     M = raw.N * raw.D * raw.H * raw.W
-    sums = torch.zeros(2, C16, dtype=torch.float32, device=dev)
+    sums = torch.empty(2, C16, dtype=torch.float32, device=dev)
     g = _geom8(raw)
-    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, None, _ptr(sums), _stream_ptr(dev))
+    scratch = _ptr(bn_scratch(dev, raw.cb))
+    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, None, _ptr(sums), scratch, _stream_ptr(dev))
     _lib.check(st, "drc_bn_stats_blocked")
     mean = sums[0] / M
-    sums2 = torch.zeros(2, C16, dtype=torch.float32, device=dev)
-    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, _ptr(mean), _ptr(sums2), _stream_ptr(dev))
+    sums2 = torch.empty(2, C16, dtype=torch.float32, device=dev)
+    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, _ptr(mean), _ptr(sums2), scratch, _stream_ptr(dev))
     _lib.check(st, "drc_bn_stats_blocked")
     var = sums2[1] / M
     return mean.contiguous(), var.contiguous(), M

@@ -101,6 +101,8 @@ class PSMNetRuntime:
         rs = t[res] if res else None
         if not self._training or c.bn is None:
             pl.run(t[x], c.w, c.scale, c.shift, t[y], rs)
+            if self._training and self._tape is not None:        # BN-less conv (lastconv.2): still a site of the reverse pass
+                self._tape.append(("site", ws, plan, wname, x, y, res))
             return
         yt = t[y]
         raw = ws.setdefault("raw", {}).get(plan)
@@ -118,18 +120,7 @@ class PSMNetRuntime:
             bn.running_mean.mul_(1 - mom).add_(mean[: c.cout].to(bn.running_mean.device), alpha=mom)
             bn.running_var.mul_(1 - mom).add_(unb.to(bn.running_var.device), alpha=mom)
         relu = bool(pl.p.relu)
-        if isinstance(yt, E.BlockedSlice):                      # concat slices: normalise into a temp, then copy the blocks in
-            tmp = ws["raw"].get(plan + ":y")
-            if tmp is None:
-                tmp = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
-                ws["raw"][plan + ":y"] = tmp
-            E.bn_apply(raw, tmp, rs, mean, invstd, c.gamma, c.beta, relu)
-            from ... import _lib
-            st = _lib.lib().drc_copy_blocks(E._ptr(tmp.storage), E._ptr(yt.base.storage), yt.N, yt.cb, tmp.cb_stride // 16,
-                                            yt.base.cb, yt.cb_off, E._stream_ptr(self.device))
-            _lib.check(st, "drc_copy_blocks")
-        else:
-            E.bn_apply(raw, yt, rs, mean, invstd, c.gamma, c.beta, relu)
+        E.bn_apply(raw, yt, rs, mean, invstd, c.gamma, c.beta, relu)     # yt may be a concat slice (geometry carries cb_off)
         ws.setdefault("saved", {})[plan] = (mean, invstd, M)
         if self._tape is not None:
             self._tape.append(("site", ws, plan, wname, x, y, res))
@@ -358,9 +349,12 @@ class PSMNetRuntime:
 
     def forward_images(self, left, right, training=False):
         self._training = bool(training)
-        if training and torch.is_grad_enabled() and (left.requires_grad or any(p.requires_grad for p in self.model.parameters())):
-            raise NotImplementedError("backward through the HIP engine is not built yet: run the train-mode forward under "
-                                      "torch.no_grad() (batch-statistics BN, 3 heads), or train through the reference")
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if training and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or params):
+            return _PSMNetTrainFn.apply(self, left, right, *params)
+        return self._forward_images_impl(left, right, training)
+
+    def _forward_images_impl(self, left, right, training):
         E.require_gpu(left, "PSMNet input"); E.require_gpu(right, "PSMNet input")
         mx, mn = self._check_disp()
         N, _, H, W = left.shape
@@ -375,13 +369,16 @@ class PSMNetRuntime:
             featL = self._features(self._ws2d(N, H, W, "L"), Wt, left)
             featR = self._features(self._ws2d(N, H, W, "R"), Wt, right)
             E.cost_volume_blocked(featL.storage, featR.storage, ws3["t"]["cost"], mn // 4, mx // 4, featL.ph)
+            self._last_train_2d = (self._ws2d(N, H, W, "L"), self._ws2d(N, H, W, "R"))
         else:
             ws2 = self._ws2d(2 * N, H, W)
             feat = self._features(ws2, Wt, torch.cat((left, right), 0))
             fv = feat.storage
             right_view = fv[N * feat.n_stride:]
             E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
-        return self._heads(self._regress(ws3, Wt), N, H, W, mx, mn, training)
+        costs = self._regress(ws3, Wt)
+        self._last_train = (ws3, Wt, costs, mx, mn, (H, W))
+        return self._heads(costs, N, H, W, mx, mn, training)
 
 
 class _RegressorTrainFn(torch.autograd.Function):
@@ -415,3 +412,34 @@ class _RegressorTrainFn(torch.autograd.Function):
             gcost = G.get("cost").to_dense()
             gfl, gfr = ops.cost_volume_backward(gcost, mx, mn)
         return (None, None, gfl, gfr) + tuple(bw.pg.get(id(p)) for p in ctx.params)
+
+
+class _PSMNetTrainFn(torch.autograd.Function):
+    """Differentiable train-mode PSMNet.forward on image crops (reference stackhourglass.py:106-167): the 2D CNN runs once
+    per view (two tapes), then the regressor; backward = regressor -> cost-volume adjoint -> both 2D passes."""
+
+    @staticmethod
+    def forward(ctx, rt, left, right, *params):
+        rt._tape = []
+        rt._need_input_grad = True          # the cost volume's gradient feeds the 2D CNN
+        try:
+            preds = rt._forward_images_impl(left.detach(), right.detach(), True)
+            ctx.tape, ctx.info, ctx.ws2 = rt._tape, rt._last_train, rt._last_train_2d
+        finally:
+            rt._tape = None
+        ctx.rt, ctx.params = rt, params
+        return preds
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        from .train import FeaturesBackward, RegressorBackward
+        from ... import ops
+        rt = ctx.rt
+        ws3, Wt, costs, mx, mn, out_hw = ctx.info
+        rt._need_input_grad = True
+        bw = RegressorBackward(rt, ws3, Wt)
+        G = bw.run(ctx.tape, (g1, g2, g3), costs, mx, mn, out_hw)
+        gfl, gfr = ops.cost_volume_backward(G.get("cost").to_dense(), mx, mn)
+        for ws2, gfeat in zip(ctx.ws2, (gfl, gfr)):
+            FeaturesBackward(rt, ws2, Wt, bw.pg).run(ctx.tape, gfeat)
+        return (None, None, None) + tuple(bw.pg.get(id(p)) for p in ctx.params)

@@ -33,9 +33,13 @@ class Grads:
         self.have = set()
 
     def get(self, name):
+        ft = self.ws["t"][name]
+        if isinstance(ft, E.BlockedSlice):                       # gradient of a concat slice = slice of the concat's gradient
+            parent = [k for k, v in self.ws["t"].items() if v is ft.base][0]
+            return E.BlockedSlice(self.get(parent), ft.cb_off, ft.C)
         b = self.buf.get(name)
         if b is None:
-            b = _zeros_like_blocked(self.ws["t"][name], self.device)
+            b = _zeros_like_blocked(ft, self.device)
             self.buf[name] = b
         return b
 
@@ -90,77 +94,98 @@ class RegressorBackward:
 
     # ---------------------------------------------------------------- data-gradient plans (cached in the workspace)
     def _dgrad(self, plan_name, c, g_out, g_in):
-        """g_in (=|+=) d/dx of the site's convolution applied to g_out."""
+        """plan + transformed weights computing d/dx of the site's convolution (see module docstring)."""
         cache = self.ws.setdefault("dplans", {})
         fwd = self.ws["p"][plan_name]
-        stride, deconv = fwd.p.in_mul, fwd.p.out_mul == 2
-        key = plan_name
-        ent = cache.get(key)
+        k0 = fwd.p.cls[0]
+        stride, deconv, is3d = fwd.p.in_mul, fwd.p.out_mul == 2, g_out.pd > 0
         wt = c.conv.weight.detach().to(self.dev).float()
+        ent = cache.get(plan_name)
         if ent is None:
-            if deconv:        # ConvTranspose [Cin,Cout,k]: dx = conv_s2(dy, W as Conv[out=Cin,in=Cout])
-                pl = E.plan_conv3d(g_out, g_in, 2, c.cin, False)
-            elif stride == 2:  # dx = conv_transpose(dy, W [in=Cout,out=Cin,k])
-                pl = E.plan_deconv3d(g_out, g_in, c.cin, False)
+            if is3d:
+                if deconv:         # ConvTranspose [Cin,Cout,k]: dx = conv_s2(dy, W read as Conv[out=Cin,in=Cout])
+                    pl = E.plan_conv3d(g_out, g_in, 2, c.cin, False)
+                elif stride == 2:   # dx = conv_transpose(dy, W [in=Cout,out=Cin,k])
+                    pl = E.plan_deconv3d(g_out, g_in, c.cin, False)
+                else:
+                    pl = E.plan_conv3d(g_out, g_in, 1, c.cin, False)
             else:
-                pl = E.plan_conv3d(g_out, g_in, 1, c.cin, False)
+                k, dil = k0.nh, max(k0.sh, 1)
+                if stride == 2:
+                    pl = E.plan_deconv2d(g_out, g_in, k, c.cin, False)
+                else:               # same dilation, flipped kernel, pad' = dil*(k-1) - pad_fwd  (pad_fwd = x.ph - dh0)
+                    pad_fwd = self.ws["t"][self._x_of[plan_name]].ph - k0.dh0
+                    pl = E.plan_conv2d(g_out, g_in, k, 1, dil * (k - 1) - pad_fwd, dil, c.cin, False)
             ent = dict(plan=pl)
-            cache[key] = ent
+            cache[plan_name] = ent
         if deconv:
             wp = E.pack_weight(wt)
         elif stride == 2:
             wp = E.pack_weight(wt, transposed=True)
         else:
-            wp = E.pack_weight(wt.transpose(0, 1).flip(2, 3, 4).contiguous())
+            wp = E.pack_weight(wt.transpose(0, 1).flip(*range(2, wt.dim())).contiguous())
         cp = wp.shape[3]
-        ones, zeros = torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev)
-        return ent["plan"], wp, ones, zeros
+        return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev)
 
-    def site(self, G, plan, wname, x, y, res):
+    _x_of = {}
+
+    def site(self, G, plan, wname, x, y, res, need_dx=True):
         t, c = self.ws["t"], self.W[wname]
         fwd = self.ws["p"][plan]
+        k0 = fwd.p.cls[0]
+        self._x_of[plan] = x
         relu = bool(fwd.p.relu)
         dy = G.get(y)
         assert y in G.have, f"no gradient reached {y}"
-        raw = self.ws["raw"][plan]
-        mean, invstd, M = self.ws["saved"][plan]
         lib, sp = _lib.lib(), E._stream_ptr(self.dev)
-        sums = torch.zeros(2, raw.cb * 16, dtype=torch.float32, device=self.dev)
-        st = lib.drc_bn_bwd_reduce(E._ptr(dy.storage), E._geom8(dy), E._ptr(t[y].storage), E._geom8(t[y]), E._ptr(raw.storage), E._geom8(raw),
-                                   E._ptr(mean), E._ptr(invstd), int(relu), E._ptr(sums), sp)
-        _lib.check(st, "drc_bn_bwd_reduce")
-        draw = self.ws.setdefault("draw", {}).get(plan)
-        if draw is None:
-            draw = _zeros_like_blocked(raw, self.dev)
-            self.ws["draw"][plan] = draw
-        dres, acc = None, 0
-        if res is not None:
-            dres = G.get(res)
-            acc = int(res in G.have)
-            G.have.add(res)
-        st = lib.drc_bn_bwd_apply(E._ptr(dy.storage), E._geom8(dy), E._ptr(t[y].storage), E._geom8(t[y]), E._ptr(raw.storage), E._geom8(raw),
-                                  E._ptr(mean), E._ptr(invstd), E._ptr(c.gamma), E._ptr(sums), 1.0 / M, int(relu), E._ptr(draw.storage),
-                                  E._geom8(draw), E._ptr(dres.storage) if dres is not None else None,
-                                  E._geom8(dres) if dres is not None else None, acc, sp)
-        _lib.check(st, "drc_bn_bwd_apply")
-        self._padd(c.bn.weight, sums[1, : c.cout].clone())
-        self._padd(c.bn.bias, sums[0, : c.cout].clone())
+        xin, yt = t[x], t[y]
+        if c.bn is not None:
+            raw = self.ws["raw"][plan]
+            mean, invstd, M = self.ws["saved"][plan]
+            sums = torch.empty(2, raw.cb * 16, dtype=torch.float32, device=self.dev)
+            st = lib.drc_bn_bwd_reduce(E._ptr(dy.storage), E._geom8(dy), E._ptr(yt.storage), E._geom8(yt), E._ptr(raw.storage), E._geom8(raw),
+                                       E._ptr(mean), E._ptr(invstd), int(relu), E._ptr(sums), E._ptr(E.bn_scratch(self.dev, raw.cb)), sp)
+            _lib.check(st, "drc_bn_bwd_reduce")
+            draw = self.ws.setdefault("draw", {}).get(plan)
+            if draw is None:
+                halo = (1, 1, 1) if raw.pd > 0 else (0, 2, 2)      # 2D: room for the dilated data-gradient taps
+                draw = E.Blocked(raw.N, raw.C, raw.D, raw.H, raw.W, *halo, self.dev)
+                self.ws["draw"][plan] = draw
+            dres, acc = None, 0
+            if res is not None:
+                dres = G.get(res)
+                acc = int(res in G.have)
+                G.have.add(res)
+            st = lib.drc_bn_bwd_apply(E._ptr(dy.storage), E._geom8(dy), E._ptr(yt.storage), E._geom8(yt), E._ptr(raw.storage), E._geom8(raw),
+                                      E._ptr(mean), E._ptr(invstd), E._ptr(c.gamma), E._ptr(sums), 1.0 / M, int(relu), E._ptr(draw.storage),
+                                      E._geom8(draw), E._ptr(dres.storage) if dres is not None else None,
+                                      E._geom8(dres) if dres is not None else None, acc, sp)
+            _lib.check(st, "drc_bn_bwd_apply")
+            self._padd(c.bn.weight, sums[1, : c.cout].clone())
+            self._padd(c.bn.bias, sums[0, : c.cout].clone())
+        else:                       # plain conv (no BN, no activation, no residual): the output gradient is the conv gradient
+            assert not relu and res is None
+            draw = dy
+            if isinstance(draw, E.BlockedSlice) or draw.ph < 1:
+                raise NotImplementedError("BN-less site with an unsupported gradient layout")
         # weight gradient
         deconv = fwd.p.out_mul == 2
-        xin = t[x]
         if deconv:
             cls = dict(n=(3, 3, 3), first=(0, 0, 0), step=(1, 1, 1))            # a = draw (halo 1): padded index 2i + k
             gw = wgrad(draw, xin, cls, 2)                                        # [co][ci][k]
             self._padd(c.conv.weight, gw[: c.cout, : c.cin].permute(1, 0, 2).reshape(c.conv.weight.shape))
         else:
-            cls = dict(n=(3, 3, 3), first=(xin.pd - 1, xin.ph - 1, xin.pw - 1), step=(1, 1, 1))
+            cls = dict(n=(k0.nd, k0.nh, k0.nw), first=(k0.dd0, k0.dh0, k0.dw0), step=(max(k0.sd, 1), max(k0.sh, 1), max(k0.sw, 1)))
             gw = wgrad(xin, draw, cls, fwd.p.in_mul)                             # [ci][co][t]
             self._padd(c.conv.weight, gw[: c.cin, : c.cout].permute(1, 0, 2).reshape(c.conv.weight.shape))
         # data gradient into grads[x]
-        if x != "cost" or self.rt._need_input_grad:
+        if need_dx:
             gx = G.get(x)
             pl, wp, ones, zeros = self._dgrad(plan, c, draw, gx)
-            pl.run(draw, wp, ones, zeros, gx, gx if x in G.have else None)
+            first = x not in G.have
+            if first and pl.p.out_mul == 2 and pl.p.n_classes < (8 if gx.pd > 0 else 4):
+                gx.storage.zero_()                                               # k=1 stride-2: odd positions get no tap
+            pl.run(draw, wp, ones, zeros, gx, None if first else gx)
             G.have.add(x)
 
     def run(self, tape, gpreds, costs, mx, mn, out_hw):
@@ -195,5 +220,44 @@ class RegressorBackward:
         for op in reversed(tape):
             _, ws_, plan, wname, x, y, res = op
             if ws_ is ws:
+                self.site(G, plan, wname, x, y, res, need_dx=(x != "cost" or self.rt._need_input_grad))
+        return G
+
+
+class FeaturesBackward(RegressorBackward):
+    """Reverse pass over the 2D feature CNN of ONE view (reference submodule.py:106-139): lastconv -> SPP branches
+    (bilinear-up adjoint, 1x1 conv+BN site, avg-pool adjoint) -> layer4..layer1 -> firstconv."""
+
+    def __init__(self, rt, ws, W, pg):
+        super().__init__(rt, ws, W)
+        self.pg = pg                 # shared with the regressor / the other view: weights are siamese
+
+    def run(self, tape, gfeat):
+        ws, t, dev = self.ws, self.ws["t"], self.dev
+        G = Grads(ws, dev)
+        lib, sp = _lib.lib(), E._stream_ptr(dev)
+        G.get("feat").from_dense(gfeat)
+        G.have.add("feat")
+        slot = {name: cb_off for name, k, oh, ow, cb_off in ws["spp"]}
+        kk = {name: k for name, k, oh, ow, cb_off in ws["spp"]}
+        skip = ws["skip"]
+        sites = [op for op in tape if op[1] is ws]
+        for op in reversed(sites):
+            _, _, plan, wname, x, y, res = op
+            if plan.startswith("fe.branch"):
+                name = plan[3:]
+                gconv = G.get(name + ".conv")
+                gconv.storage.zero_()
+                gslice = E.BlockedSlice(G.get("cat"), slot[name], 32)
+                st = lib.drc_bilinear_up_blocked_bwd(E._ptr(gslice.storage), E._geom8(gslice), E._ptr(gconv.storage), E._geom8(gconv), sp)
+                _lib.check(st, "drc_bilinear_up_blocked_bwd")
+                G.have.add(name + ".conv")
                 self.site(G, plan, wname, x, y, res)
+                gpool, gskip = G.get(name + ".pool"), G.get(skip)
+                st = lib.drc_avgpool2d_blocked_bwd(E._ptr(gpool.storage), E._geom8(gpool), E._ptr(gskip.storage), E._geom8(gskip), kk[name], sp)
+                _lib.check(st, "drc_avgpool2d_blocked_bwd")
+                continue
+            self.site(G, plan, wname, x, y, res, need_dx=(x != "img"))
+            if plan == "fe.lastconv.0":          # its data gradient filled every channel block of the concat
+                G.have.update(k for k, v in t.items() if isinstance(v, E.BlockedSlice))
         return G

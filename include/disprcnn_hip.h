@@ -186,11 +186,18 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
 
 /* ---------------------------------------------------------------------------------------
  * a2 (train mode). BatchNorm with per-GPU batch statistics on blocked tensors (nn.BatchNorm3d/2d of convbn_3d / convbn,
- * submodule.py:13-22).  geom8 = {N, CB, D, H, W, pd, ph, pw}.
- *   drc_bn_stats_blocked : sums[0][c] += sum (x - shift[c]), sums[1][c] += sum (x - shift[c])^2 over interior voxels
- *                          (caller zeroes sums [2][CB*16]; shift may be NULL; two passes give a cancellation-free variance)
+ * submodule.py:13-22).  Every `geom` argument of the BatchNorm / SPP-backward entry points is
+ * int[10] = {N, CB, D, H, W, pd, ph, pw, cb_total, cb_off}: channel blocks [cb_off, cb_off+CB) of a blocked tensor that
+ * has cb_total blocks (a plain tensor has cb_total = CB, cb_off = 0; a concat slice addresses its parent).
+ *   drc_bn_stats_blocked : sums[0][c] = sum (x - shift[c]), sums[1][c] = sum (x - shift[c])^2 over interior voxels
+ *                          (sums [2][CB*16]; shift may be NULL; two passes give a cancellation-free variance).  The
+ *                          cross-block reduction runs in a fixed order, so the statistics (and with them every ReLU mask
+ *                          downstream) are bit-reproducible run to run.  `scratch`: DRC_BN_SCRATCH_FLOATS(CB) floats whose
+ *                          last CB words (tickets) are zero on entry; they are zero again on exit.  One scratch per stream.
  *   drc_bn_apply_blocked : y = act((x - mean) * invstd * gamma + beta (+ res)), interior only */
-int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, void* stream);
+#define DRC_BN_MAX_CHUNKS 512
+#define DRC_BN_SCRATCH_FLOATS(CB) ((size_t)DRC_BN_MAX_CHUNKS * (CB) * 32 + (CB))
+int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, float* scratch, void* stream);
 int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int* geom_y, const float* res, const int* geom_r,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, void* stream);
 
@@ -209,7 +216,7 @@ int drc_conv3d_cout1_bwd_data(const float* grad_out, const float* w, float* grad
 int drc_conv3d_cout1_bwd_weight(const float* x_blk, const float* grad_out, float* grad_w, int N, int cb_in, int D, int H, int W,
                                 void* stream);
 int drc_bn_bwd_reduce(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
-                      const float* mean, const float* invstd, int relu, float* sums, void* stream);
+                      const float* mean, const float* invstd, int relu, float* sums, float* scratch /* as drc_bn_stats_blocked */, void* stream);
 int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
                      const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_count, int relu, float* draw,
                      const int* geom_draw, float* dres, const int* geom_dres, int dres_accumulate, void* stream);
@@ -232,6 +239,11 @@ typedef struct drc_wgrad_params {
     int32_t R, WT, lds_bytes_per_wave;   /* >= ((rows_in*seg_vox) + R*WT) * 64 */
 } drc_wgrad_params;
 int drc_tapconv_wgrad(const drc_wgrad_params* p, void* stream);
+
+/* Adjoints of the SPP helpers (submodule.py:76-90,120-135): bilinear(align_corners=True) upsampling (atomicAdd scatter
+ * into grad_x) and AvgPool2d(k,k) (gather, accumulates into grad_x). */
+int drc_bilinear_up_blocked_bwd(const float* grad_y, const int* geom_y, float* grad_x, const int* geom_x, void* stream);
+int drc_avgpool2d_blocked_bwd(const float* grad_y, const int* geom_y, float* grad_x, const int* geom_x, int k, void* stream);
 
 #ifdef __cplusplus
 }

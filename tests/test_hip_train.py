@@ -5,6 +5,7 @@ import copy
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import psmnet_oracle as O
 from disprcnn_amd.utils import synth
@@ -137,9 +138,200 @@ def test_backward_from_features_vs_oracle_autograd(dev):
         assert (got.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-7
 
 
-def test_backward_through_images_is_refused_loudly(dev):
+def test_full_psmnet_backward_vs_reference_gradients(dev):
+    """Train step on image crops: loss.backward() through 2D CNN (both views), cost volume and regressor on the HIP engine,
+    against (a) the gradient samples the REFERENCE itself recorded (tests/golden Bt_g:*), (b) the fp64 oracle's autograd
+    for every parameter.
+
+    Tolerances.  This ~90-layer batch-stat-BN net at batch 2 is ill conditioned in fp32: a last-ulp change in one batch
+    statistic flips ReLU masks downstream, and the reference's OWN fp32 gradients sit 2e-3..6e-3 * max|g| away from the fp64
+    restatement of the same graph (measured when the fixture was made).  So: loss to 1e-5 relative; sampled reference
+    gradients to 2e-2 * max|ref|; per-parameter cosine with the fp64 oracle >= 0.995 and median max-norm error <= 2e-2.
+    The per-site tests below pin every backward kernel to 2e-4 on well conditioned single layers."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
-    m = PSMNet(48, -48).to(dev).train()
-    l, r = synth.synth_images(1, 224, 224, tag="nograd")
-    with pytest.raises(NotImplementedError):
-        m((l.to(dev), r.to(dev)))
+    from disprcnn_amd.utils.loss_utils import PSMLoss
+    z = golden_npz()
+    sd = state_for("B")
+    m = PSMNet(48, -48)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    left, right = synth.synth_images(2, 224, 224, tag="caseBtrain")
+    target = synth.hash_uniform("tgt", (2, 224, 224), -48.0, 48.0)
+    mask = (synth.hash_uniform("mask", (2, 224, 224), 0.0, 1.0) > 0.5).to(torch.uint8)
+    preds = m({"left": left.to(dev), "right": right.to(dev)})
+    loss = PSMLoss()(preds, {"disparity": target.to(dev), "mask": mask.to(dev)})
+    loss.backward()
+    assert abs(loss.item() - float(z["Bt_loss"])) < 1e-5 * float(z["Bt_loss"])
+    named = dict(m.named_parameters())
+    for name in ("dres0.0.0.weight", "dres2.conv5.0.weight", "classif3.2.weight", "dres4.conv6.1.weight",
+                 "feature_extraction.lastconv.2.weight"):
+        g = named[name].grad.detach().cpu().reshape(-1)
+        ref = torch.from_numpy(z[f"Bt_g:{name}_val"])
+        got = g[torch.from_numpy(z[f"Bt_g:{name}_idx"])]
+        scale = max(ref.abs().max().item(), float(z[f"Bt_g:{name}_abssum"]) / g.numel())
+        assert (got - ref).abs().max().item() <= 2e-2 * scale + 1e-7, (name, (got - ref).abs().max().item(), scale)
+        assert abs(g.double().abs().sum().item() - float(z[f"Bt_g:{name}_abssum"])) <= 2e-2 * float(z[f"Bt_g:{name}_abssum"])
+    # every parameter vs the oracle's autograd in fp64
+    dt = torch.float64
+    sdr = {k: (v.clone().to(dt).requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))
+               else (v.to(dt) if v.is_floating_point() else v)) for k, v in sd.items()}
+    rp = O.psmnet_forward(sdr, left.to(dt), right.to(dt), 48, -48, training=True)
+    O.psm_loss(rp, target.to(dt), mask).backward()
+    errs = []
+    for k, v in sdr.items():
+        if not (torch.is_tensor(v) and v.requires_grad):
+            continue
+        got = named[k].grad
+        assert got is not None, k
+        got, ref = got.cpu().double().reshape(-1), v.grad.reshape(-1)
+        cos = torch.dot(got, ref).item() / (got.norm().item() * ref.norm().item() + 1e-300)
+        assert cos >= 0.995, (k, cos)
+        errs.append((got - ref).abs().max().item() / (ref.abs().max().item() + 1e-300))
+    errs.sort()
+    assert len(errs) == sum(1 for _ in m.parameters())
+    assert errs[len(errs) // 2] <= 2e-2, errs[len(errs) // 2]
+
+
+def test_spp_adjoints(dev):
+    """drc_bilinear_up_blocked_bwd / drc_avgpool2d_blocked_bwd are the exact adjoints of the forward SPP kernels
+    (reference: autograd of F.interpolate(bilinear, align_corners=True) and AvgPool2d, submodule.py:76-96,128-137):
+    <fwd(x), g> == <x, bwd(g)> to fp32 rounding, at the real branch sizes (56x56 map, pools 8/16/32... -> 7/3/1)."""
+    from disprcnn_amd import _lib, engine as E
+    lib, sp = _lib.lib(), E._stream_ptr(dev)
+    n, H4, W4 = 2, 56, 72
+    for k in (8, 16, 32):
+        oh, ow = H4 // k, W4 // k
+        # bilinear upsample of a 32-channel map into channel blocks 2..3 of a 5-block tensor
+        x = E.Blocked(n, 32, 1, oh, ow, 0, 0, 0, dev)
+        xd = synth.hash_uniform(f"spp{k}:x", (n, 32, 1, oh, ow)).to(dev)
+        x.from_dense(xd)
+        cat = E.Blocked(n, 80, 1, H4, W4, 0, 1, 1, dev)
+        _lib.check(lib.drc_bilinear_up_blocked(E._ptr(x.storage), E._ptr(cat.storage), n, 2, oh, ow, 0, H4, W4, cat.ph, cat.cb, 2, sp), "up")
+        y = cat.to_dense()[:, 32:64]
+        ref = F.interpolate(xd.squeeze(2).cpu(), (H4, W4), mode="bilinear", align_corners=True)
+        assert (y.squeeze(2).cpu() - ref).abs().max().item() < 1e-5
+        gcat = E.Blocked(n, 80, 1, H4, W4, 0, 1, 1, dev)
+        gd = torch.zeros(n, 80, 1, H4, W4, device=dev)
+        gd[:, 32:64] = synth.hash_uniform(f"spp{k}:g", (n, 32, 1, H4, W4)).to(dev)
+        gcat.from_dense(gd)
+        gsl = E.BlockedSlice(gcat, 2, 32)
+        gx = E.Blocked(n, 32, 1, oh, ow, 0, 0, 0, dev)
+        _lib.check(lib.drc_bilinear_up_blocked_bwd(E._ptr(gsl.storage), E._geom8(gsl), E._ptr(gx.storage), E._geom8(gx), sp), "up_bwd")
+        lhs = (y.double() * gd[:, 32:64].double()).sum().item()
+        rhs = (xd.double() * gx.to_dense().double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (k, lhs, rhs)
+        # average pool of a 128-channel slice (blocks 1..8 of a 10-block tensor), adjoint accumulates into the slice
+        src = E.Blocked(n, 160, 1, H4, W4, 0, 2, 2, dev)
+        sdn = synth.hash_uniform(f"spp{k}:s", (n, 160, 1, H4, W4)).to(dev)
+        src.from_dense(sdn)
+        gp = E.Blocked(n, 128, 1, oh, ow, 0, 0, 0, dev)
+        gpd = synth.hash_uniform(f"spp{k}:gp", (n, 128, 1, oh, ow)).to(dev)
+        gp.from_dense(gpd)
+        gsrc = E.Blocked(n, 160, 1, H4, W4, 0, 2, 2, dev)
+        gs = E.BlockedSlice(gsrc, 1, 128)
+        _lib.check(lib.drc_avgpool2d_blocked_bwd(E._ptr(gp.storage), E._geom8(gp), E._ptr(gs.storage), E._geom8(gs), k, sp), "pool_bwd")
+        pooled = F.avg_pool2d(sdn[:, 16:144].squeeze(2).cpu(), k, k)
+        lhs = (pooled.double() * gpd.squeeze(2).cpu().double()).sum().item()
+        gfull = gsrc.to_dense()
+        rhs = (sdn[:, 16:144].double() * gfull[:, 16:144].double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (k, lhs, rhs)
+        assert gfull[:, :16].abs().max().item() == 0.0 and gfull[:, 144:].abs().max().item() == 0.0
+
+
+SITES = [  # kind, cin, cout, k, stride, pad, dil, dims, relu, with_res
+    ("conv3d", 64, 32, 3, 1, 1, 1, (6, 12, 20), True, False),
+    ("conv3d", 32, 32, 3, 1, 1, 1, (4, 10, 12), False, True),
+    ("conv3d", 32, 64, 3, 2, 1, 1, (8, 12, 16), True, False),
+    ("deconv3d", 64, 64, 3, 2, 1, 1, (3, 6, 8), False, True),
+    ("deconv3d", 64, 32, 3, 2, 1, 1, (4, 6, 10), False, False),
+    ("conv2d", 3, 32, 3, 2, 1, 1, (24, 40), True, False),
+    ("conv2d", 32, 64, 3, 2, 1, 1, (20, 28), True, False),
+    ("conv2d", 32, 64, 1, 2, 0, 1, (20, 28), False, False),
+    ("conv2d", 64, 128, 1, 1, 0, 1, (10, 14), False, False),
+    ("conv2d", 128, 128, 3, 1, 2, 2, (10, 14), False, True),
+    ("conv2d", 320, 128, 3, 1, 1, 1, (8, 12), True, False),
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,stride,pad,dil,dims,relu,with_res", SITES)
+def test_site_backward_vs_torch_autograd(dev, kind, cin, cout, k, stride, pad, dil, dims, relu, with_res):
+    """One conv + batch-stat BN (+res) (+ReLU) site: forward and every gradient (input, residual, conv weight, gamma, beta)
+    against torch autograd in fp64 (reference layers: submodule.py:13-22, stackhourglass.py:22-30).  Single sites are
+    well conditioned, so the tolerance is fp32 rounding: 2e-4 * max|ref|."""
+    import torch.nn as nn
+    from disprcnn_amd import engine as E
+    from disprcnn_amd.modeling.psmnet.runtime import PSMNetRuntime, _Conv
+    from disprcnn_amd.modeling.psmnet.train import RegressorBackward, Grads
+    n = 2
+    tag = f"S{kind}{cin}{cout}{k}{stride}{dil}"
+    is3d = kind != "conv2d"
+    if kind == "conv3d":
+        conv = nn.Conv3d(cin, cout, 3, stride, 1, bias=False)
+    elif kind == "deconv3d":
+        conv = nn.ConvTranspose3d(cin, cout, 3, 2, 1, output_padding=1, bias=False)
+    else:
+        conv = nn.Conv2d(cin, cout, k, stride, pad, dil, bias=False)
+    bn = nn.BatchNorm3d(cout) if is3d else nn.BatchNorm2d(cout)
+    with torch.no_grad():
+        conv.weight.copy_(synth.hash_uniform(tag + ":w", tuple(conv.weight.shape), -0.1, 0.1))
+        bn.weight.copy_(synth.hash_uniform(tag + ":g", (cout,), 0.5, 1.5))
+        bn.bias.copy_(synth.hash_uniform(tag + ":b", (cout,), -0.5, 0.5))
+    x = synth.hash_uniform(tag + ":x", (n, cin) + dims)
+    # fp64 reference
+    c64, b64 = __import__("copy").deepcopy(conv).double(), __import__("copy").deepcopy(bn).double()
+    x64 = x.double().requires_grad_(True)
+    raw64 = c64(x64)
+    r64 = synth.hash_uniform(tag + ":r", tuple(raw64.shape)).double().requires_grad_(True) if with_res else None
+    y64 = b64.train()(raw64)
+    if with_res:
+        y64 = y64 + r64
+    if relu:
+        y64 = torch.relu(y64)
+    gy = synth.hash_uniform(tag + ":gy", tuple(y64.shape))
+    (y64 * gy.double()).sum().backward()
+    # HIP site
+    odims = tuple(raw64.shape[2:])
+    if is3d:
+        mk = lambda c, d: E.Blocked(n, c, d[0], d[1], d[2], 1, 1, 1, dev)
+    else:
+        halo = max(pad, 1)
+        mk = lambda c, d: E.Blocked(n, c, 1, d[0], d[1], 0, halo, halo, dev)
+    t = {"x": mk(cin, dims), "y": mk(cout, odims)}
+    t["x"].from_dense(x.to(dev) if is3d else x.to(dev).unsqueeze(2))
+    if with_res:
+        t["r"] = mk(cout, odims)
+        t["r"].from_dense(r64.detach().float().to(dev) if is3d else r64.detach().float().to(dev).unsqueeze(2))
+    if kind == "conv3d":
+        plan = E.plan_conv3d(t["x"], t["y"], stride, cout, relu)
+    elif kind == "deconv3d":
+        plan = E.plan_deconv3d(t["x"], t["y"], cout, relu)
+    else:
+        plan = E.plan_conv2d(t["x"], t["y"], k, stride, pad, dil, cout, relu)
+    ws = {"t": t, "p": {"s": plan}}
+    rt = PSMNetRuntime.__new__(PSMNetRuntime)
+    rt.device, rt._training, rt._tape, rt._need_input_grad = dev, True, [], True
+    W = {"s": _Conv(conv, bn, dev, kind == "deconv3d")}
+    rt._site(ws, W, "s", "s", "x", "y", "r" if with_res else None)
+    got_y = t["y"].to_dense().cpu()
+    got_y = got_y if is3d else got_y.squeeze(2)
+    assert (got_y.double() - y64.detach()).abs().max().item() <= 1e-4 * y64.abs().max().item()
+    bw = RegressorBackward(rt, ws, W)
+    G = Grads(ws, dev)
+    G.get("y").from_dense(gy.to(dev) if is3d else gy.to(dev).unsqueeze(2))
+    G.have.add("y")
+    bw.site(G, "s", "s", "x", "y", "r" if with_res else None)
+    torch.cuda.synchronize()
+
+    def chk(got, ref, what):
+        s = ref.abs().max().item()
+        e = (got.double().cpu() - ref).abs().max().item()
+        assert e <= 2e-4 * s + 1e-9, (what, e, s)
+
+    gx = G.get("x").to_dense()
+    chk(gx if is3d else gx.squeeze(2), x64.grad, "dx")
+    if with_res:
+        gr = G.get("r").to_dense()
+        chk(gr if is3d else gr.squeeze(2), r64.grad, "dres")
+    chk(bw.pg[id(conv.weight)], c64.weight.grad, "dw")
+    chk(bw.pg[id(bn.weight)], b64.weight.grad, "dgamma")
+    chk(bw.pg[id(bn.bias)], b64.bias.grad, "dbeta")
