@@ -25,7 +25,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 template <int VT, int CT>
-__global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_tapconv_params p, const int seg_len) {
+__global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_tapconv_params p) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -35,27 +35,24 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
     const drc_tap_class cls = p.cls[0];
     const int n_wt = (p.OW + p.WT - 1) / p.WT;
     const int n_rt = (p.OH + p.R - 1) / p.R;
-    const int cols = p.N * n_rt * n_wt;            // columns = (n, row tile, col tile); the wave walks all OD slices
-    int cid = blockIdx.x * SLIDE_WAVES + wave;
-    if (cid >= cols) return;                       // wave-uniform; no workgroup barrier in this kernel
-    const int wt = cid % n_wt; cid /= n_wt;
-    const int rt = cid % n_rt;
-    const int n = cid / n_rt;
-    const int oh0 = rt * p.R, ow0 = wt * p.WT;
-    const int ct0 = blockIdx.y * CT;
+    const int cols = p.N * n_rt * n_wt;            // columns = (n, row tile, col tile) of one cout group
     const int D = p.OD;
-    // depth segment of this wave: outputs od in [od_lo, od_hi); it reads input slices od_lo-1 .. od_hi (clipped to the volume)
-    const int od_lo = blockIdx.z * seg_len;
-    const int od_hi = od_lo + seg_len < D ? od_lo + seg_len : D;
-    const int din_lo = od_lo > 0 ? od_lo - 1 : 0;
-    const int din_hi = od_hi < D ? od_hi : D - 1;      // inclusive
-
+    // Work units are output slices, linearised as (cout group, column, od).  Every wave takes an equal contiguous share
+    // [ucur, u1) of them, so the SIMDs finish together whatever N is; a share that crosses a column boundary is walked as
+    // two depth segments (each re-stages its neighbouring input slices).
+    const long units = (long)(p.cout_pad / 16 / CT) * cols * D;
+    const long workers = (long)gridDim.x * SLIDE_WAVES;
+    const long wid = (long)blockIdx.x * SLIDE_WAVES + wave;
+    long ucur = units * wid / workers;
+    const long u1 = units * (wid + 1) / workers;
     const int rows_in = p.R + 2;
     const int seg_vox = p.WT + 2;
-    const int seg_floats = seg_vox * 8;
-    const int seg_units = seg_vox * 2;
+    const int seg_units = seg_vox * 2;             // 16-byte units per tile row
+    const int ppr = (seg_units + 63) >> 6;         // LDS-DMA pieces (64 lanes x 16 B) per tile row
+    const int seg_floats = ppr * 256;              // LDS row stride: whole pieces, the tail of the last one is padding
+    const int pieces = rows_in * ppr;
     const int buf_floats = rows_in * seg_floats;
-    float* lds = lds_all + wave * (p.lds_bytes_per_wave >> 2);
+    float* lds = lds_all + wave * (2 * buf_floats);
     const int nslots = p.R * p.WT;
 
     int lane_off[VT];
@@ -64,47 +61,36 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
         const int s = vt * 16 + j;
         int r = s / p.WT, c = s - r * p.WT;
         if (s >= nslots) { r = 0; c = 0; }
-        lane_off[vt] = (r * seg_vox + c) * 8 + g * 2;
+        lane_off[vt] = r * seg_floats + c * 8 + g * 2;
     }
 
-    // input origin of the column at padded depth index 0 (row oh0+dh0, col ow0+dw0)
-    const float* xcol = p.x + (int64_t)n * p.x_n_stride + (int64_t)(oh0 + cls.dh0) * p.x_h_stride + (int64_t)(ow0 + cls.dw0) * 16;
     const int n_pc = p.cb_in * 2;                  // (channel block, half) phases per input slice
 
-    // LDS-DMA rows [r0,r1) of the tile (input slice d_in, phase pc) into tile buffer bufi
-    auto stage_rows = [&](int d_in, int pc, int bufi, int r0, int r1) {
-        const int h = pc & 1, cb = pc >> 1;
-        const float* src = xcol + (int64_t)cb * p.x_cb_stride + (int64_t)(d_in + cls.dd0 + 1) * p.x_d_stride + h * 8;   // real slice d_in sits at padded depth d_in + dd0 + 1
-        float* dst = lds + bufi * buf_floats;
-        for (int r = r0; r < r1; ++r) {
-            const float* srow = src + (int64_t)r * p.x_h_stride;
-            float* drow = dst + r * seg_floats;
-            for (int u0 = 0; u0 < seg_units; u0 += 64) {
-                const int u = u0 + lane;
-                if (u < seg_units)
-                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(srow + (u >> 1) * 16 + (u & 1) * 4), LDS_PTR(drow + u0 * 4), 16, 0, 0);
-            }
-        }
-    };
-    const int rows_per_step = (rows_in + 7) / 8;   // 9 taps per phase: rows go out during taps 0..7
+    // per-segment state (set at the top of the segment loop)
+    const float* xcol;     // input origin of the column at padded depth index 0 (row oh0+dh0, col ow0+dw0)
+    const float* wlane;    // weights: packed [widx = (kd*3+kh)*3+kw][cb*2+half][cout_pad][8]
+    int n, oh0, ow0, ct0, od_lo, od_hi, din_lo, din_hi;
 
-    // weights: packed [widx = (kd*3+kh)*3+kw][cb*2+half][cout_pad][8]
-    const float* wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 8 + g * 2;
+    // LDS-DMA of piece q of the tile (input slice d_in, phase pc) into tile buffer bufi.  Always exactly one instruction
+    // with all 64 lanes active (tail lanes re-read the row's last unit into the row padding), so that the compiler can
+    // count it: the wait for the next step's weights becomes vmcnt(#pieces issued after them) instead of vmcnt(0), and a
+    // piece has two tap steps to land instead of one.
+    auto stage_piece = [&](int d_in, int pc, int bufi, int q) {
+        const int h = pc & 1, cb = pc >> 1;
+        const int r = q / ppr, part = q - r * ppr;
+        int u = part * 64 + lane;
+        u = u < seg_units ? u : seg_units - 1;
+        const float* src = xcol + (int64_t)cb * p.x_cb_stride + (int64_t)(d_in + cls.dd0 + 1) * p.x_d_stride + h * 8 +   // real slice d_in sits at padded depth d_in + dd0 + 1
+                           (int64_t)r * p.x_h_stride + (u >> 1) * 16 + (u & 1) * 4;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds + bufi * buf_floats + r * seg_floats + part * 256), 16, 0, 0);
+    };
+    const bool two_pieces = pieces > 9;            // 9 tap steps per phase, one or two pieces per step
+
     const int64_t w_half_stride = (int64_t)p.cout_pad * 8;
     const int64_t w_tap_stride = w_half_stride * n_pc;
 
     f32x4 bn_sc[CT], bn_sh[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
-        bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
-    }
-
     f32x4 acc0[VT][CT], acc1[VT][CT], acc2[VT][CT];   // three output slices in flight
-#pragma unroll
-    for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) { acc0[vt][ct] = acc1[vt][ct] = acc2[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // epilogue of output slice od from accumulator set ACC, then clear the set
 #define SLIDE_EPILOGUE(OD, ACC)                                                                        \
@@ -136,32 +122,41 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
 
     // weights of step (pc, tap t) for the three depth taps: widx = (dd*3+kh)*3+kw = dd*9 + t
     f32x2 wA[3][CT], wB[3][CT], bA[VT], bB[VT];
+    // The weight loads are raw asm so that the compiler does not count them: it would otherwise put s_waitcnt vmcnt(0) in
+    // front of the first MFMA of every tap step, which also waits for the LDS-DMA piece issued one step earlier (HBM
+    // latency > one step).  Issue order inside a step is weights, then the piece(s); the step that uses the weights
+    // waits with vmcnt(#pieces), so a piece has two steps to land.  Nothing may read W between load_w and SLIDE_WWAIT.
     auto load_w = [&](f32x2 (&W)[3][CT], int pc, int t) {
         const float* wp = wlane + (int64_t)t * w_tap_stride + (int64_t)pc * w_half_stride;
 #pragma unroll
-        for (int dd = 0; dd < 3; ++dd)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) W[dd][ct] = *(const f32x2*)(wp + (int64_t)dd * 9 * w_tap_stride + ct * 128);
+        for (int dd = 0; dd < 3; ++dd) {
+            const float* wd = wp + (int64_t)dd * 9 * w_tap_stride;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(W[dd][0]) : "v"(wd));
+            if (CT == 2) asm volatile("global_load_dwordx2 %0, %1, off offset:512" : "=v"(W[dd][CT - 1]) : "v"(wd));
+        }
     };
+#define SLIDE_WWAIT()                                                                                  \
+    {                                                                                                  \
+        if (two_pieces) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                               \
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                          \
+    }
 
     int bufsel = 0;
-    stage_rows(din_lo, 0, 0, 0, rows_in);
-    load_w(wA, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
 // one tap step of input slice d_in: accumulate into (dd=0 -> A0 if v0), (dd=1 -> A1 if v1), (dd=2 -> A2 if v2).
 // Interior slices (v1) issue the prefetch behind the first MFMAs of the dd=1 block; the two edge slices of a depth
 // segment (v1 false) prefetch first and accept the wait.
 #define SLIDE_PREFETCH(T, W_LD, B_LD)                                                                  \
-        if (st_on) {                                                                                   \
-            const int r0_ = (T) * rows_per_step;                                                       \
-            if (r0_ < rows_in) stage_rows(st_d, st_pc, bufsel ^ 1, r0_, r0_ + rows_per_step < rows_in ? r0_ + rows_per_step : rows_in); \
-        }                                                                                              \
         {                                                                                              \
             const bool in_ph_ = (T) + 1 < 9;                                                           \
             const int tn_ = in_ph_ ? (T) + 1 : 0;                                                      \
             load_w(W_LD, in_ph_ ? pc : nx_pc, tn_);                                                    \
-            const int to_ = in_ph_ ? ((tn_ / 3) * seg_vox + (tn_ % 3)) * 8 : 0;                        \
+            {   /* steps beyond the last piece re-stage an earlier one (same bytes): the count stays static */ \
+                const int q_ = two_pieces ? 2 * (T) : (T);                                             \
+                stage_piece(st_d, st_pc, bufsel ^ 1, q_ < pieces ? q_ : q_ - pieces);                  \
+                if (two_pieces) stage_piece(st_d, st_pc, bufsel ^ 1, q_ + 1 < pieces ? q_ + 1 : q_ + 1 - pieces); \
+            }                                                                                          \
+            const int to_ = in_ph_ ? (tn_ / 3) * seg_floats + (tn_ % 3) * 8 : 0;                       \
             _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x2*)(buf + lane_off[vt] + to_); \
         }
 
@@ -169,6 +164,8 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
     {                                                                                                  \
         /* first tile row of the dd=1 block is unconditional: it carries the operand wait; on the two edge slices  \
            of a depth segment (v1 false) it feeds a set that is cleared before its next use */          \
+        if ((T) > 0) SLIDE_WWAIT()   /* step 0's weights landed behind the vmcnt(0) that closed the previous phase */ \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
         _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
             A1[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[1][ct][0], B_USE[0][0], A1[0][ct], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                             \
@@ -192,8 +189,8 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
         for (int pc = 0; pc < n_pc; ++pc) {                                                            \
             const float* buf = lds + bufsel * buf_floats;                                              \
             const bool last_pc = pc + 1 == n_pc;                                                       \
-            const bool st_on = !last_pc || (d_in + 1 <= din_hi);                                       \
-            const int st_d = last_pc ? d_in + 1 : d_in, st_pc = last_pc ? 0 : pc + 1;                  \
+            const int st_d = last_pc && d_in + 1 <= din_hi ? d_in + 1 : d_in;   /* after the last slice: harmless re-stage */ \
+            const int st_pc = last_pc ? 0 : pc + 1;                                                    \
             const int nx_pc = st_pc;                                                                   \
             _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) bA[vt] = *(const f32x2*)(buf + lane_off[vt]); \
             for (int t = 0; t < 8; t += 2) {                                                           \
@@ -201,9 +198,10 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
                 SLIDE_STEP(t + 1, wB, bB, wA, bA, A0, A1, A2)                                          \
             }                                                                                          \
             SLIDE_STEP(8, wA, bA, wB, bB, A0, A1, A2)                                                  \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
             _Pragma("unroll") for (int dd = 0; dd < 3; ++dd)                                           \
                 _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) wA[dd][ct] = wB[dd][ct];             \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
             bufsel ^= 1;                                                                               \
         }                                                                                              \
         if (v2) SLIDE_EPILOGUE(d_in - 1, A2)                                                           \
@@ -213,17 +211,50 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
 
     // output od lives in set (od mod 3): slice d_in feeds dd0 -> set (d_in+1)%3, dd1 -> d_in%3, dd2 -> (d_in+2)%3.
     // The loop is unrolled by 3 so the sets rotate without runtime indexing; it starts at the right phase for din_lo.
-    for (int d_in = din_lo - din_lo % 3;;) {
-        if (d_in >= din_lo) SLIDE_SLICE(acc1, acc0, acc2)
-        if (++d_in > din_hi) break;
-        if (d_in >= din_lo) SLIDE_SLICE(acc2, acc1, acc0)
-        if (++d_in > din_hi) break;
-        if (d_in >= din_lo) SLIDE_SLICE(acc0, acc2, acc1)
-        if (++d_in > din_hi) break;
+#pragma unroll 1
+    while (ucur < u1) {
+        // ---- segment setup: column, cout group and depth range [od_lo, od_hi); input slices od_lo-1 .. od_hi clipped to the volume
+        {
+            const long colid = ucur / D;
+            od_lo = (int)(ucur - colid * D);
+            od_hi = (long)od_lo + (u1 - ucur) < D ? od_lo + (int)(u1 - ucur) : D;
+            ucur += od_hi - od_lo;
+            int cid = (int)(colid % cols);
+            ct0 = (int)(colid / cols) * CT;
+            const int wt = cid % n_wt; cid /= n_wt;
+            const int rt = cid % n_rt;
+            n = cid / n_rt;
+            oh0 = rt * p.R; ow0 = wt * p.WT;
+            din_lo = od_lo > 0 ? od_lo - 1 : 0;
+            din_hi = od_hi < D ? od_hi : D - 1;      // inclusive
+            xcol = p.x + (int64_t)n * p.x_n_stride + (int64_t)(oh0 + cls.dh0) * p.x_h_stride + (int64_t)(ow0 + cls.dw0) * 16;
+            wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 8 + g * 2;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
+                bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
+            }
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) { acc0[vt][ct] = acc1[vt][ct] = acc2[vt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int q = 0; q < pieces; ++q) stage_piece(din_lo, 0, bufsel, q);
+            load_w(wA, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int d_in = din_lo - din_lo % 3;;) {
+            if (d_in >= din_lo) SLIDE_SLICE(acc1, acc0, acc2)
+            if (++d_in > din_hi) break;
+            if (d_in >= din_lo) SLIDE_SLICE(acc2, acc1, acc0)
+            if (++d_in > din_hi) break;
+            if (d_in >= din_lo) SLIDE_SLICE(acc0, acc2, acc1)
+            if (++d_in > din_hi) break;
+        }
     }
 #undef SLIDE_SLICE
 #undef SLIDE_STEP
 #undef SLIDE_PREFETCH
+#undef SLIDE_WWAIT
 #undef SLIDE_MFMA
 #undef SLIDE_EPILOGUE
 }
@@ -231,29 +262,27 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
 template <int VT, int CT>
 int launch(const drc_tapconv_params& p, hipStream_t stream) {
     const long cols = (long)p.N * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
-    const size_t lds = (size_t)p.lds_bytes_per_wave * SLIDE_WAVES;
+    const int ppr = (2 * (p.WT + 2) + 63) / 64;
+    const size_t lds = (size_t)2 * (p.R + 2) * ppr * 1024 * SLIDE_WAVES;      // two tile buffers per wave, rows padded to whole 1 KiB pieces
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)tapslide_kernel<VT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    // depth segments: one wave per column when that already fills the SIMDs, otherwise split D (each segment re-stages
-    // its two neighbouring slices) until every SIMD has a wave; segments stay >= 3 slices long
+    // equal shares of output slices for every resident wave slot; shares stay >= 3 slices so the re-staged seam slices
+    // (two per segment) remain a small part of a wave's work
     static int occ_blocks = 0;   // per-instantiation, idempotent
     if (!occ_blocks) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tapslide_kernel<VT, CT>, 64 * SLIDE_WAVES, lds) != hipSuccess || nb < 1) nb = 1;
         occ_blocks = nb;
     }
-    const long waves = cols * (p.cout_pad / 16 / CT);
-    const long slots = 256L * SLIDE_WAVES * occ_blocks;
-    int nseg = (int)(slots / (waves > 0 ? waves : 1));
-    if (nseg < 1) nseg = 1;
-    if (nseg > p.OD / 3) nseg = p.OD / 3 > 0 ? p.OD / 3 : 1;
-    const int seg_len = (p.OD + nseg - 1) / nseg;
-    nseg = (p.OD + seg_len - 1) / seg_len;
-    dim3 grid((unsigned)((cols + SLIDE_WAVES - 1) / SLIDE_WAVES), (unsigned)(p.cout_pad / 16 / CT), (unsigned)nseg);
-    hipLaunchKernelGGL((tapslide_kernel<VT, CT>), grid, dim3(64 * SLIDE_WAVES), lds, stream, p, seg_len);
+    const long units = cols * (p.cout_pad / 16 / CT) * p.OD;
+    long workers = 256L * SLIDE_WAVES * occ_blocks;
+    if (workers > units / 3) workers = units / 3;
+    if (workers < SLIDE_WAVES) workers = SLIDE_WAVES;
+    dim3 grid((unsigned)((workers + SLIDE_WAVES - 1) / SLIDE_WAVES), 1, 1);
+    hipLaunchKernelGGL((tapslide_kernel<VT, CT>), grid, dim3(64 * SLIDE_WAVES), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -286,8 +315,8 @@ extern "C" int drc_tapconv3d_slide_fwd(const drc_tapconv_params* pp, int cout_ti
     if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 ||
         k.sw != 1 || k.wbase != 0 || k.wsd != 9 || k.wsh != 3 || k.wsw != 1)
         return -4;
-    const int need = (p.R + 2) * (p.WT + 2) * 32 * 2;
-    if (p.lds_bytes_per_wave < need || (p.lds_bytes_per_wave & 15) || (size_t)p.lds_bytes_per_wave * SLIDE_WAVES > 160 * 1024) return -5;
+    const int ppr = (2 * (p.WT + 2) + 63) / 64;
+    if ((p.R + 2) * ppr > 18 || (size_t)2 * (p.R + 2) * ppr * 1024 * SLIDE_WAVES > 160 * 1024) return -5;   // <= 2 pieces per tap step
     const int ct = p.cout_pad / 16;
     const int CT = cout_tiles_per_wave;
     if ((CT != 1 && CT != 2) || ct % CT) return -2;

@@ -257,11 +257,12 @@ class ConvPlan:
             CT //= 2
         self.kname = "tapconv_kernel<%d,%d>" % (nvt, CT)
         if slide:
-            # the sliding-window kernel runs one long-lived wave per (column, depth segment of >= 3 slices): use it
-            # only when that still yields enough waves to fill the 1024 SIMDs (measured cross-over, tools/exp_conv.py)
+            # the sliding-window kernel gives every resident wave an equal share (>= 3 output slices) of the
+            # (cout group, column, slice) units: use it only when that still yields enough waves to fill the 1024 SIMDs
+            # (measured cross-over, tools/exp_conv.py)
             self.slide_ct = SLIDE["ct"] if ct % SLIDE["ct"] == 0 else 1
             cols = x.N * (-(-OH // R)) * (-(-OW // WT))
-            if OD < 6 or cols * (ct // self.slide_ct) * max(1, OD // 3) < 700:
+            if OD < 6 or cols * (ct // self.slide_ct) * OD // 3 < 700:
                 self.slide = False
             else:
                 self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)

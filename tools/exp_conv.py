@@ -34,6 +34,8 @@ if __name__ == "__main__":
         E.SLIDE["enabled"] = os.environ["SLIDE"] != "0"
     if os.environ.get("SLIDE_SLOTS"):
         E.SLIDE["max_slots"] = int(os.environ["SLIDE_SLOTS"])
+    if os.environ.get("MAX_SLOTS"):
+        E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
     if os.environ.get("SLIDE_CT"):
         E.SLIDE["ct"] = int(os.environ["SLIDE_CT"])
     run(N, 32, 32, (12, 28, 28))
