@@ -222,6 +222,7 @@ class ConvPlan:
     def __init__(self, x, y, classes, in_mul, out_mul, grid_dhw, cout, relu, slide=False):
         p = DrcTapconvParams()
         self.slide = slide
+        self.fused_deconv = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -288,7 +289,10 @@ class ConvPlan:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        if self.slide:
+        if self.fused_deconv:
+            st = _lib.lib().drc_deconv3d_k3s2_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_deconv3d_k3s2_fwd")
+        elif self.slide:
             st = _lib.lib().drc_tapconv3d_slide_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_tapconv3d_slide_fwd")
         else:
@@ -307,9 +311,40 @@ def plan_conv3d(x, y, stride, cout, relu):
     return ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu, slide=(stride == 1 and SLIDE["enabled"]))
 
 
+FUSED_DECONV = {"enabled": True}
+
+
+DECONV_TILE = None    # development override (tools/exp_conv.py)
+
+
+def choose_tile_deconv(H, W):
+    """Input tile (R, WT) of the fused transposed-conv kernel.  Measured on MI355X (tools/exp_conv.py, 14x14 and 7x7 maps):
+    tiles of 4 voxel-tiles (49..64 slots, one cout tile per wave) beat smaller ones even with more MFMA padding, because a
+    tap step then carries 16 MFMAs; among those the least padding wins."""
+    if DECONV_TILE:
+        return DECONV_TILE
+    best = None
+    for r in range(1, H + 1):
+        for wt in range(1, W + 1):
+            if r * wt > 64 or -(-((r + 1) * (wt + 1) * 2) // 64) > 5:      # 8 classes x 4 voxel tiles of accumulators
+                continue
+            nvt = -(-(r * wt) // 16)
+            waste = (-(-H // r)) * (-(-W // wt)) * nvt * 16 / (H * W)
+            key = (nvt == 4 and waste <= 1.35, -round(waste, 3), wt, r * wt)
+            if best is None or key > best[0]:
+                best = (key, r, wt)
+    return best[1], best[2]
+
+
 def plan_deconv3d(x, y, cout, relu):
     assert (x.pd, x.ph, x.pw) == (1, 1, 1) and (y.D, y.H, y.W) == (2 * x.D, 2 * x.H, 2 * x.W)
-    return ConvPlan(x, y, taps_deconv3d_k3s2(), 1, 2, (x.D, x.H, x.W), cout, relu)
+    pl = ConvPlan(x, y, taps_deconv3d_k3s2(), 1, 2, (x.D, x.H, x.W), cout, relu)
+    if FUSED_DECONV["enabled"]:
+        pl.fused_deconv = True
+        pl.p.R, pl.p.WT = choose_tile_deconv(x.H, x.W)
+        nvt = -(-(pl.p.R * pl.p.WT) // 16)
+        pl.kname = "tapdeconv_kernel<%d,%d>" % (nvt, 2 if nvt <= 3 and (pl.p.cout_pad // 16) % 2 == 0 else 1)
+    return pl
 
 
 def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):

@@ -120,6 +120,14 @@ int drc_tapconv_fwd(const drc_tapconv_params* p, void* stream);
  * lds_bytes_per_wave >= 2*(R+2)*(WT+2)*32.  cout_tiles_per_wave in {1,2} must divide cout_pad/16. */
 int drc_tapconv3d_slide_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* ConvTranspose3d(k3, s2, p1, op1) (+BN, +residual, +ReLU) -- hourglass.conv5/conv6 (stackhourglass.py:22-30) and the data
+ * gradient of the stride-2 Conv3d layers -- with the 8 output-parity classes fused: a wave stages an (R+1) x (WT+1) tile
+ * of input slices i and i+1 once per 8-channel phase and runs all 27 taps on it.  Takes the same parameter block as
+ * drc_tapconv_fwd with the classes of the transposed convolution (in_mul = 1, out_mul = 2, OD/OH/OW = INPUT grid, cls[0].dd0/
+ * dh0/dw0 = input halo); only x/w/scale/shift/res/y, the strides, N, OD, OH, OW, cb_in, cout_pad, R, WT, relu are read.
+ * Needs R*WT <= 112 and ceil((R+1)*(WT+1)*2/64) <= 9.  Results equal drc_tapconv_fwd's up to the fp32 summation order. */
+int drc_deconv3d_k3s2_fwd(const drc_tapconv_params* p, void* stream);
+
 /* Final classifier conv Conv3d(32->1,k3,p1,bias=False) (stackhourglass.py:78-88 `classifN[2]`)
  * with the cumulative head add (`+ cost_{k-1}`, :142-144) fused.
  *   x : blocked [N][cb_in][D+2][H+2][W+2][16];  w : [27][cb_in*16];  out,res : dense [N,D,H,W] */
@@ -203,7 +211,8 @@ int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int*
 
 /* ---------------------------------------------------------------------------------------
  * Backward kernels (autograd of stackhourglass.py:130-174 in the reference).  Data gradients of the MFMA convolutions
- * reuse drc_tapconv_fwd / drc_tapconv3d_slide_fwd with transformed weights (disprcnn_amd/autograd.py).
+ * reuse drc_tapconv_fwd / drc_tapconv3d_slide_fwd / drc_deconv3d_k3s2_fwd with transformed weights
+ * (disprcnn_amd/modeling/psmnet/train.py).
  *   drc_upsample_softargmin_bwd : grad_cost [N,Dp,Hp,Wp] (caller-zeroed) += d disp / d cost * grad_disp [N,H,W]
  *   drc_conv3d_cout1_bwd_data   : grad of the 32->1 classifier conv w.r.t. its blocked input (assign or accumulate)
  *   drc_conv3d_cout1_bwd_weight : grad_w [27][cb_in*16] (caller-zeroed) += sum x * grad_out

@@ -34,6 +34,10 @@ if __name__ == "__main__":
         E.SLIDE["enabled"] = os.environ["SLIDE"] != "0"
     if os.environ.get("SLIDE_SLOTS"):
         E.SLIDE["max_slots"] = int(os.environ["SLIDE_SLOTS"])
+    if os.environ.get("DC_TILE"):
+        E.DECONV_TILE = tuple(int(v) for v in os.environ["DC_TILE"].split(","))
+        run(N, 64, 32, (6, 14, 14), deconv=True)
+        sys.exit(0)
     if os.environ.get("MAX_SLOTS"):
         E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
     if os.environ.get("SLIDE_CT"):
