@@ -47,7 +47,7 @@ __device__ constexpr int set_dw(int s) { return (s & 1); }
 #define DC_MAXP 5   /* LDS-DMA pieces per slice tile */
 
 template <int VT, int CT>
-__global__ __launch_bounds__(64 * DC_WAVES) void tapdeconv_kernel(const drc_tapconv_params p) {
+__global__ __launch_bounds__(64 * DC_WAVES, 2) void tapdeconv_kernel(const drc_tapconv_params p) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
