@@ -19,12 +19,16 @@ def _sources():
     return [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
 
 
+def _headers():
+    return [os.path.join(HERE, "..", "..", "include", "disprcnn_hip.h")] + \
+        [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".h")]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = _sources() + [os.path.join(HERE, "..", "..", "include", "disprcnn_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _sources() + _headers())
 
 
 def build(force=False, verbose=True):
@@ -33,8 +37,7 @@ def build(force=False, verbose=True):
     objs = []
     for src in _sources():
         obj = src[:-4] + ".o"
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "..", "include", "disprcnn_hip.h"))):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in [src] + _headers()):
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

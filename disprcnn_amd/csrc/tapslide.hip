@@ -68,21 +68,27 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
 
     // per-segment state (set at the top of the segment loop)
     const float* xcol;     // input origin of the column at padded depth index 0 (row oh0+dh0, col ow0+dw0)
-    const float* wlane;    // weights: packed [widx = (kd*3+kh)*3+kw][cb*2+half][cout_pad][8]
+    unsigned wlane_off;    // per-lane byte offset into the packed weights [widx = (kd*3+kh)*3+kw][cb*2+half][cout_pad][8]
     int n, oh0, ow0, ct0, od_lo, od_hi, din_lo, din_hi;
 
     // LDS-DMA of piece q of the tile (input slice d_in, phase pc) into tile buffer bufi.  Always exactly one instruction
-    // with all 64 lanes active (tail lanes re-read the row's last unit into the row padding), so that the compiler can
-    // count it: the wait for the next step's weights becomes vmcnt(#pieces issued after them) instead of vmcnt(0), and a
-    // piece has two tap steps to land instead of one.
-    auto stage_piece = [&](int d_in, int pc, int bufi, int q) {
-        const int h = pc & 1, cb = pc >> 1;
-        const int r = q / ppr, part = q - r * ppr;
-        int u = part * 64 + lane;
+    // with all 64 lanes active (tail lanes re-read the row's last unit into the row padding): the count of pieces issued
+    // after a step's weight loads is static, so the step that uses those weights waits with vmcnt(#pieces) and a piece
+    // has two tap steps to land.  Address = wave-uniform row origin (SALU) + per-lane byte offset (two precomputed VGPRs).
+    const unsigned lane_src = (unsigned)(((lane >> 1) * 16 + (lane & 1) * 4) * 4);          // lane's 16-byte unit inside a full piece
+    unsigned lane_src_last;                                                                 // same for the last (clamped) piece of a row
+    {
+        int u = (ppr - 1) * 64 + lane;
         u = u < seg_units ? u : seg_units - 1;
-        const float* src = xcol + (int64_t)cb * p.x_cb_stride + (int64_t)(d_in + cls.dd0 + 1) * p.x_d_stride + h * 8 +   // real slice d_in sits at padded depth d_in + dd0 + 1
-                           (int64_t)r * p.x_h_stride + (u >> 1) * 16 + (u & 1) * 4;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds + bufi * buf_floats + r * seg_floats + part * 256), 16, 0, 0);
+        lane_src_last = (unsigned)((((u >> 1) * 16 + (u & 1) * 4) - (ppr - 1) * 512) * 4);
+    }
+    const unsigned ppr_magic = (65536u + ppr - 1) / ppr;                                    // q / ppr for q < 64
+    auto stage_piece = [&](int d_in, int pc, int bufi, int q) __attribute__((always_inline)) {
+        const int r = (int)(((unsigned)q * ppr_magic) >> 16), part = q - r * ppr;
+        const char* sb = (const char*)(xcol + (int64_t)(pc >> 1) * p.x_cb_stride + (int64_t)(d_in + cls.dd0 + 1) * p.x_d_stride + (pc & 1) * 8 +   // real slice d_in sits at padded depth d_in + dd0 + 1
+                                       (int64_t)r * p.x_h_stride + part * 512);
+        const unsigned vo = part == ppr - 1 ? lane_src_last : lane_src;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sb + vo), LDS_PTR(lds + bufi * buf_floats + r * seg_floats + part * 256), 16, 0, 0);
     };
     const bool two_pieces = pieces > 9;            // 9 tap steps per phase, one or two pieces per step
 
@@ -126,13 +132,14 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
     // front of the first MFMA of every tap step, which also waits for the LDS-DMA piece issued one step earlier (HBM
     // latency > one step).  Issue order inside a step is weights, then the piece(s); the step that uses the weights
     // waits with vmcnt(#pieces), so a piece has two steps to land.  Nothing may read W between load_w and SLIDE_WWAIT.
-    auto load_w = [&](f32x2 (&W)[3][CT], int pc, int t) {
-        const float* wp = wlane + (int64_t)t * w_tap_stride + (int64_t)pc * w_half_stride;
+    const unsigned ts32 = (unsigned)(w_tap_stride * 4), hs32 = (unsigned)(w_half_stride * 4);
+    auto load_w = [&](f32x2 (&W)[3][CT], int pc, int t) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)t * ts32 + (unsigned)pc * hs32;
 #pragma unroll
         for (int dd = 0; dd < 3; ++dd) {
-            const float* wd = wp + (int64_t)dd * 9 * w_tap_stride;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(W[dd][0]) : "v"(wd));
-            if (CT == 2) asm volatile("global_load_dwordx2 %0, %1, off offset:512" : "=v"(W[dd][CT - 1]) : "v"(wd));
+            const unsigned vo = wlane_off + (so + (unsigned)dd * 9u * ts32);
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(W[dd][0]) : "v"(vo), "s"(p.w));
+            if (CT == 2) asm volatile("global_load_dwordx2 %0, %1, %2 offset:512" : "=v"(W[dd][CT - 1]) : "v"(vo), "s"(p.w));
         }
     };
 #define SLIDE_WWAIT()                                                                                  \
@@ -144,21 +151,32 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
     int bufsel = 0;
 
 // one tap step of input slice d_in: accumulate into (dd=0 -> A0 if v0), (dd=1 -> A1 if v1), (dd=2 -> A2 if v2).
-// Interior slices (v1) issue the prefetch behind the first MFMAs of the dd=1 block; the two edge slices of a depth
-// segment (v1 false) prefetch first and accept the wait.
-#define SLIDE_PREFETCH(T, W_LD, B_LD)                                                                  \
+// The memory instructions of the step (next step's weights, one or two LDS-DMA pieces, next step's B fragments) are pinned
+// between MFMA runs of the dd=1 block so that they issue in the MFMA shadow (the wave issues in order: an instruction
+// placed behind the last MFMA of a run costs its issue time, one placed between two MFMAs is free).  Edge slices of a depth
+// segment (v1 false) issue them back to back.
+#define SLIDE_CH_W(T, W_LD)                                                                            \
+        {                                                                                              \
+            const bool in_ph_ = (T) + 1 < 9;                                                           \
+            load_w(W_LD, in_ph_ ? pc : nx_pc, in_ph_ ? (T) + 1 : 0);                                   \
+        }
+#define SLIDE_CH_DMA(T)                                                                                \
+        {   /* steps beyond the last piece re-stage an earlier one (same bytes): the count stays static */ \
+            const int q_ = two_pieces ? 2 * (T) : (T);                                                 \
+            stage_piece(st_d, st_pc, bufsel ^ 1, q_ < pieces ? q_ : q_ - pieces);                      \
+            if (two_pieces) stage_piece(st_d, st_pc, bufsel ^ 1, q_ + 1 < pieces ? q_ + 1 : q_ + 1 - pieces); \
+        }
+#define SLIDE_CH_B(T, B_LD)                                                                            \
         {                                                                                              \
             const bool in_ph_ = (T) + 1 < 9;                                                           \
             const int tn_ = in_ph_ ? (T) + 1 : 0;                                                      \
-            load_w(W_LD, in_ph_ ? pc : nx_pc, tn_);                                                    \
-            {   /* steps beyond the last piece re-stage an earlier one (same bytes): the count stays static */ \
-                const int q_ = two_pieces ? 2 * (T) : (T);                                             \
-                stage_piece(st_d, st_pc, bufsel ^ 1, q_ < pieces ? q_ : q_ - pieces);                  \
-                if (two_pieces) stage_piece(st_d, st_pc, bufsel ^ 1, q_ + 1 < pieces ? q_ + 1 : q_ + 1 - pieces); \
-            }                                                                                          \
             const int to_ = in_ph_ ? (tn_ / 3) * seg_floats + (tn_ % 3) * 8 : 0;                       \
             _Pragma("unroll") for (int vt = 0; vt < VT; ++vt) B_LD[vt] = *(const f32x2*)(buf + lane_off[vt] + to_); \
         }
+#define SLIDE_RUN(ACC, W, B, V0, V1, KK)                                                               \
+    _Pragma("unroll") for (int vt = (V0); vt < (V1); ++vt)                                             \
+        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
+            ACC[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[ct][KK], B[vt][KK], ACC[vt][ct], 0, 0, 0);
 
 #define SLIDE_STEP(T, W_USE, B_USE, W_LD, B_LD, A0, A1, A2)                                            \
     {                                                                                                  \
@@ -166,15 +184,27 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
            of a depth segment (v1 false) it feeds a set that is cleared before its next use */          \
         if ((T) > 0) SLIDE_WWAIT()   /* step 0's weights landed behind the vmcnt(0) that closed the previous phase */ \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                              \
-            A1[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[1][ct][0], B_USE[0][0], A1[0][ct], 0, 0, 0); \
+        SLIDE_RUN(A1, W_USE[1], B_USE, 0, 1, 0)                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        SLIDE_PREFETCH(T, W_LD, B_LD)                                                                  \
         if (v1) {                                                                                      \
-            _Pragma("unroll") for (int vt = 1; vt < VT; ++vt)                                          \
-                _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                      \
-                    A1[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(W_USE[1][ct][0], B_USE[vt][0], A1[vt][ct], 0, 0, 0); \
-            SLIDE_MFMA(A1, W_USE[1], B_USE, 1)                                                         \
+            SLIDE_RUN(A1, W_USE[1], B_USE, 1, 2, 0)                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            SLIDE_CH_W(T, W_LD)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            SLIDE_RUN(A1, W_USE[1], B_USE, 2, VT > 4 ? 4 : VT, 0)                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            SLIDE_CH_DMA(T)                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            SLIDE_RUN(A1, W_USE[1], B_USE, VT > 4 ? 4 : VT, VT, 0)                                     \
+            SLIDE_RUN(A1, W_USE[1], B_USE, 0, 1, 1)                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            SLIDE_CH_B(T, B_LD)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+            SLIDE_RUN(A1, W_USE[1], B_USE, 1, VT, 1)                                                   \
+        } else {                                                                                       \
+            SLIDE_CH_W(T, W_LD)                                                                        \
+            SLIDE_CH_DMA(T)                                                                            \
+            SLIDE_CH_B(T, B_LD)                                                                        \
         }                                                                                              \
         if (v0) { SLIDE_MFMA(A0, W_USE[0], B_USE, 0) SLIDE_MFMA(A0, W_USE[0], B_USE, 1) }              \
         if (v2) { SLIDE_MFMA(A2, W_USE[2], B_USE, 0) SLIDE_MFMA(A2, W_USE[2], B_USE, 1) }              \
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
             din_lo = od_lo > 0 ? od_lo - 1 : 0;
             din_hi = od_hi < D ? od_hi : D - 1;      // inclusive
             xcol = p.x + (int64_t)n * p.x_n_stride + (int64_t)(oh0 + cls.dh0) * p.x_h_stride + (int64_t)(ow0 + cls.dw0) * 16;
-            wlane = p.w + ((int64_t)(ct0 * 16 + j)) * 8 + g * 2;
+            wlane_off = (unsigned)(((ct0 * 16 + j) * 8 + g * 2) * 4);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
@@ -253,7 +283,10 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
     }
 #undef SLIDE_SLICE
 #undef SLIDE_STEP
-#undef SLIDE_PREFETCH
+#undef SLIDE_CH_W
+#undef SLIDE_CH_DMA
+#undef SLIDE_CH_B
+#undef SLIDE_RUN
 #undef SLIDE_WWAIT
 #undef SLIDE_MFMA
 #undef SLIDE_EPILOGUE
