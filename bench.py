@@ -218,7 +218,51 @@ def main():
                     "stereo_pairs_per_s": round(1.0 / tp, 2), "ms_per_pair": round(tp * 1e3, 2), "backbone_ms": round(tbb * 1e3, 2),
                     "backbone_tflops": round(250.3e9 / tbb / 1e12, 2),
                     "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
-                del mB, bb, det
+                del bb, det
+                # ---- extra: one TRAIN step of the disparity stage (reference: PSMNet.train() + PSMLoss, trainer.do_train): forward with
+                # per-GPU batch-stat BatchNorm, 3-head smooth-L1 loss, full backward (dgrad + MFMA wgrad) on the HIP engine, gradient
+                # sync (GradientSync: a no-op at world size 1); 64 ROI pairs of Config A from the feature boundary, and 8 ROI crops of
+                # Config B through the 2D CNN as well
+                from disprcnn_amd.utils.loss_utils import PSMLoss
+                from disprcnn_amd.utils.comm import GradientSync
+                tr = {}
+                for tag, mdl, nroi in (("config_a_from_features_64roi", model, 64), ("config_b_full_psmnet_8roi", mB, 8)):
+                    mdl.train()
+                    sync = GradientSync(mdl.parameters())
+                    if tag.startswith("config_a"):
+                        fl_, fr_ = synth.synth_features(nroi, 32, 28, 28, tag="trainA")
+                        fl_, fr_ = fl_.to(dev), fr_.to(dev)
+                        tgt = synth.hash_uniform("trainA:t", (nroi, 112, 112), 0.0, 47.0).to(dev)
+                        fwd = lambda: mdl.forward_from_features(fl_, fr_, (112, 112))
+                        fl3 = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * nroi
+                    else:
+                        li, ri = synth.synth_images(nroi, 224, 224, tag="trainB")
+                        li, ri = li.to(dev), ri.to(dev)
+                        tgt = synth.hash_uniform("trainB:t", (nroi, 224, 224), -47.0, 47.0).to(dev)
+                        fwd = lambda: mdl({"left": li, "right": ri})
+                        fl3 = FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * nroi
+                    msk = torch.ones_like(tgt, dtype=torch.uint8)
+                    crit = PSMLoss()
+
+                    def train_step():
+                        for p_ in mdl.parameters():
+                            p_.grad = None
+                        loss = crit(fwd(), {"disparity": tgt, "mask": msk})
+                        loss.backward()
+                        sync()
+                        return loss
+                    for _ in range(2):
+                        train_step()
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    for _ in range(3):
+                        train_step()
+                    torch.cuda.synchronize(); tt = (time.perf_counter() - t1) / 3
+                    tr[tag] = {"ms_per_step": round(tt * 1e3, 2), "roi_pairs_per_s": round(nroi / tt, 1),
+                               "regressor_tflops_fwd_bwd": round(3 * fl3 / tt / 1e12, 2)}
+                    mdl.eval()
+                tr["workload"] = "forward (batch-stat BN) + PSMLoss + backward + gradient sync; regressor FLOPs counted as 3x forward"
+                extra["train_step"] = tr
+                del mB
             except Exception as ex:  # report, never hide
                 extra["config_b_full_psmnet"] = extra.get("config_b_full_psmnet") or {"error": repr(ex)}
                 extra["extra_error"] = repr(ex)

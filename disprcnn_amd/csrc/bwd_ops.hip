@@ -8,6 +8,7 @@
 
 #include "../../include/disprcnn_hip.h"
 #include "det_reduce.h"
+#include "blocked_walk.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -22,11 +23,8 @@ inline unsigned grid_for(long work, long cap = 4096) {
     return (unsigned)b;
 }
 
-struct BlkGeom { int N, CB, D, H, W, pd, ph, pw, cb_total, cb_off; };   // CB blocks [cb_off, cb_off+CB) of cb_total
-__device__ __forceinline__ long blk_off(const BlkGeom& g, int n, int cb, int d, int y, int x) {
-    const long Wp = g.W + 2 * g.pw, Hp = g.H + 2 * g.ph, Dp = g.D + 2 * g.pd;
-    return ((((long)n * g.cb_total + g.cb_off + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
-}
+using drc_blk::BlkGeom;
+using drc_blk::blk_off;
 inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0 && g[9] >= 0 && g[9] + g[1] <= g[8]; }
 inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9]}; }
 
@@ -195,23 +193,17 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
                                                                  float* __restrict__ sums, float* scratch) {
     const int cb = blockIdx.y;
     const int q = threadIdx.x & 3;
-    const long nvox = (long)gdy.N * gdy.D * gdy.H * gdy.W;
     const f32x4 mu = *(const f32x4*)(mean + cb * 16 + q * 4), is = *(const f32x4*)(invstd + cb * 16 + q * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (long v = (long)blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2); v < nvox; v += (long)gridDim.x * (kThreads / 4)) {
-        long t = v;
-        const int xx = (int)(t % gdy.W); t /= gdy.W;
-        const int yy = (int)(t % gdy.H); t /= gdy.H;
-        const int dd = (int)(t % gdy.D);
-        const int n = (int)(t / gdy.D);
-        f32x4 dz = *(const f32x4*)(dy + blk_off(gdy, n, cb, dd, yy, xx) + q * 4);
+    drc_blk::walk_rows<kThreads>(gdy, [&](int n, int dd, int yy, int xx, int qq) {
+        f32x4 dz = *(const f32x4*)(dy + blk_off(gdy, n, cb, dd, yy, xx) + qq * 4);
         if (relu) {
-            const f32x4 yv = *(const f32x4*)(y + blk_off(gy, n, cb, dd, yy, xx) + q * 4);
+            const f32x4 yv = *(const f32x4*)(y + blk_off(gy, n, cb, dd, yy, xx) + qq * 4);
             dz.x = yv.x > 0.f ? dz.x : 0.f; dz.y = yv.y > 0.f ? dz.y : 0.f; dz.z = yv.z > 0.f ? dz.z : 0.f; dz.w = yv.w > 0.f ? dz.w : 0.f;
         }
-        const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + q * 4) - mu) * is;
+        const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + qq * 4) - mu) * is;
         s1 += dz; s2 += dz * xh;
-    }
+    });
     float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -238,16 +230,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums, float invM,
                                                                 int relu, float* __restrict__ draw, BlkGeom gdraw, float* __restrict__ dres,
                                                                 BlkGeom gdres, int dres_accumulate) {
-    const long total = (long)gdy.N * gdy.CB * gdy.D * gdy.H * gdy.W * 4;
-    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
-        long t = idx;
-        const int q = (int)(t & 3); t >>= 2;
-        const int xx = (int)(t % gdy.W); t /= gdy.W;
-        const int yy = (int)(t % gdy.H); t /= gdy.H;
-        const int dd = (int)(t % gdy.D); t /= gdy.D;
-        const int cb = (int)(t % gdy.CB);
-        const int n = (int)(t / gdy.CB);
-        const int c = cb * 16 + q * 4;
+    const int cb = blockIdx.y;
+    const int c = cb * 16 + (threadIdx.x & 3) * 4;
+    const f32x4 is = *(const f32x4*)(invstd + c), mu = *(const f32x4*)(mean + c), ga = *(const f32x4*)(gamma + c);
+    const f32x4 s1 = *(const f32x4*)(sums + c), s2 = *(const f32x4*)(sums + gdy.CB * 16 + c);
+    drc_blk::walk_rows<kThreads>(gdy, [&](int n, int dd, int yy, int xx, int q) {
         f32x4 dz = *(const f32x4*)(dy + blk_off(gdy, n, cb, dd, yy, xx) + q * 4);
         if (relu) {
             const f32x4 yv = *(const f32x4*)(y + blk_off(gy, n, cb, dd, yy, xx) + q * 4);
@@ -257,11 +244,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
             float* dr = dres + blk_off(gdres, n, cb, dd, yy, xx) + q * 4;
             *(f32x4*)dr = dres_accumulate ? *(const f32x4*)dr + dz : dz;
         }
-        const f32x4 is = *(const f32x4*)(invstd + c);
-        const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + q * 4) - *(const f32x4*)(mean + c)) * is;
-        const f32x4 s1 = *(const f32x4*)(sums + c), s2 = *(const f32x4*)(sums + gdy.CB * 16 + c);
-        *(f32x4*)(draw + blk_off(gdraw, n, cb, dd, yy, xx) + q * 4) = *(const f32x4*)(gamma + c) * is * (dz - s1 * invM - xh * s2 * invM);
-    }
+        const f32x4 xh = (*(const f32x4*)(raw + blk_off(graw, n, cb, dd, yy, xx) + q * 4) - mu) * is;
+        *(f32x4*)(draw + blk_off(gdraw, n, cb, dd, yy, xx) + q * 4) = ga * is * (dz - s1 * invM - xh * s2 * invM);
+    });
 }
 
 
@@ -364,6 +349,7 @@ int drc_bn_bwd_reduce(const float* dy, const int* geom_dy, const float* y, const
     const long nvox = (long)g.N * g.D * g.H * g.W;
     long chunks = (nvox + 64 * 8 - 1) / (64 * 8);
     if (chunks > DRC_BN_MAX_CHUNKS) chunks = DRC_BN_MAX_CHUNKS;
+    if (chunks > (long)g.N * g.D * g.H) chunks = (long)g.N * g.D * g.H;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y,
                        relu ? to_geom(geom_y) : g, raw, to_geom(geom_raw), mean, invstd, relu, sums, scratch);
     return (int)hipGetLastError();
@@ -376,8 +362,12 @@ int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const 
     if (geom_dy[0] == 0) return 0;
     if (!dy || !raw || !mean || !invstd || !gamma || !sums || !draw || (relu && !y)) return -1;
     const BlkGeom g = to_geom(geom_dy);
-    const long total = (long)g.N * g.CB * g.D * g.H * g.W * 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y, relu ? to_geom(geom_y) : g,
+    const long rows = (long)g.N * g.D * g.H;
+    long chunks = (rows * g.W * 4 + kThreads * 4 - 1) / (kThreads * 4);
+    if (chunks > 2048) chunks = 2048;
+    if (chunks > rows) chunks = rows;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, dy, g, y, relu ? to_geom(geom_y) : g,
                        raw, to_geom(geom_raw), mean, invstd, gamma, sums, inv_count, relu, draw, to_geom(geom_draw), dres,
                        dres ? to_geom(geom_dres) : g, dres_accumulate);
     return (int)hipGetLastError();

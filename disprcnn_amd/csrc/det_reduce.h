@@ -12,7 +12,7 @@
 
 namespace drc_det {
 
-// called by all threads of the block; `v` is meaningful for threadIdx.x < 32: moment k>>2... see callers (index = threadIdx.x)
+// called by all (>= 256) threads of the block; `v`, c_index and moment are those of thread threadIdx.x < 32 (ignored elsewhere)
 __device__ __forceinline__ void finish(float v, int cb, int CB, int c_index, int moment, float* __restrict__ sums, float* scratch) {
     __shared__ unsigned s_last;
     float* part = scratch;
@@ -24,10 +24,21 @@ __device__ __forceinline__ void finish(float v, int cb, int CB, int c_index, int
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    if (threadIdx.x < 32) {
-        const volatile float* pv = part;
+    // fixed-order sum of the gridDim.x partials: 8 groups of 32 threads take the chunks i = grp, grp+8, ... (independent
+    // coherent loads, so they pipeline), then the 8 group sums are added in group order
+    __shared__ float s_grp[8][32];
+    const int grp = threadIdx.x >> 5, k = threadIdx.x & 31;
+    if (grp < 8) {
         float t = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) t += pv[((size_t)i * CB + cb) * 32 + threadIdx.x];
+        for (unsigned i = grp; i < gridDim.x; i += 8)
+            t += __hip_atomic_load(part + ((size_t)i * CB + cb) * 32 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_grp[grp][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += s_grp[i][threadIdx.x];
         sums[moment * CB * 16 + c_index] = t;
     }
     if (threadIdx.x == 0) tickets[cb] = 0u;

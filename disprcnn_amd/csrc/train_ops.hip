@@ -7,6 +7,7 @@
 
 #include "../../include/disprcnn_hip.h"
 #include "det_reduce.h"
+#include "blocked_walk.h"
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -109,31 +110,21 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
 //   bn_bwd_reduce / bn_bwd_apply : the standard BN backward with the ReLU mask and residual fan-out fused
 namespace {
 
-struct BlkGeom { int N, CB, D, H, W, pd, ph, pw, cb_total, cb_off; };   // CB blocks [cb_off, cb_off+CB) of cb_total
+using drc_blk::BlkGeom;
+using drc_blk::blk_off;
 
-__device__ __forceinline__ long blk_off(const BlkGeom& g, int n, int cb, int d, int y, int x) {
-    const long Wp = g.W + 2 * g.pw, Hp = g.H + 2 * g.ph, Dp = g.D + 2 * g.pd;
-    return ((((long)n * g.cb_total + g.cb_off + cb) * Dp + (d + g.pd)) * Hp + (y + g.ph)) * Wp * 16 + (long)(x + g.pw) * 16;
-}
-
-// grid: (chunks, CB); each block walks a slice of the (n,d,y,x) voxels of one channel block; thread = float4 quad of a voxel
+// grid: (chunks, CB); each block walks a contiguous run of rows of one channel block; thread = float4 quad of a voxel
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, BlkGeom g, const float* __restrict__ shift,
                                                             float* __restrict__ sums /* [2][CB*16] */, float* scratch) {
     const int cb = blockIdx.y;
     const int q = threadIdx.x & 3;
-    const long nvox = (long)g.N * g.D * g.H * g.W;
     f32x4_t sh = {0.f, 0.f, 0.f, 0.f};
     if (shift) sh = *(const f32x4_t*)(shift + cb * 16 + q * 4);
     f32x4_t s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (long v = (long)blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2); v < nvox; v += (long)gridDim.x * (kThreads / 4)) {
-        long t = v;
-        const int xx = (int)(t % g.W); t /= g.W;
-        const int yy = (int)(t % g.H); t /= g.H;
-        const int dd = (int)(t % g.D);
-        const int n = (int)(t / g.D);
-        const f32x4_t val = *(const f32x4_t*)(x + blk_off(g, n, cb, dd, yy, xx) + q * 4) - sh;
+    drc_blk::walk_rows<kThreads>(g, [&](int n, int dd, int yy, int xx, int qq) {
+        const f32x4_t val = *(const f32x4_t*)(x + blk_off(g, n, cb, dd, yy, xx) + qq * 4) - sh;   // qq == q: W*4 is a multiple of 4
         s1 += val; s2 += val * val;
-    }
+    });
     // reduce over the 16 voxel-lanes that share this quad inside the wave, then across waves through LDS
     float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
@@ -154,27 +145,21 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
     drc_det::finish(v, cb, g.CB, cb * 16 + qq * 4 + (k & 3), k >> 2, sums, scratch);
 }
 
+// grid: (chunks, CB)
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ x, BlkGeom gx, float* __restrict__ y, BlkGeom gy,
                                                             const float* __restrict__ res, BlkGeom gr, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu) {
-    const long total = (long)gx.N * gx.CB * gx.D * gx.H * gx.W * 4;
-    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
-        long t = idx;
-        const int q = (int)(t & 3); t >>= 2;
-        const int xx = (int)(t % gx.W); t /= gx.W;
-        const int yy = (int)(t % gx.H); t /= gx.H;
-        const int dd = (int)(t % gx.D); t /= gx.D;
-        const int cb = (int)(t % gx.CB);
-        const int n = (int)(t / gx.CB);
-        const int c = cb * 16 + q * 4;
-        const f32x4_t m = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
-        const f32x4_t ga = *(const f32x4_t*)(gamma + c), be = *(const f32x4_t*)(beta + c);
+    const int cb = blockIdx.y;
+    const int c = cb * 16 + (threadIdx.x & 3) * 4;
+    const f32x4_t m = *(const f32x4_t*)(mean + c), is = *(const f32x4_t*)(invstd + c);
+    const f32x4_t ga = *(const f32x4_t*)(gamma + c), be = *(const f32x4_t*)(beta + c);
+    drc_blk::walk_rows<kThreads>(gx, [&](int n, int dd, int yy, int xx, int q) {
         f32x4_t v = (*(const f32x4_t*)(x + blk_off(gx, n, cb, dd, yy, xx) + q * 4) - m) * is * ga + be;
         if (res) v += *(const f32x4_t*)(res + blk_off(gr, n, cb, dd, yy, xx) + q * 4);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *(f32x4_t*)(y + blk_off(gy, n, cb, dd, yy, xx) + q * 4) = v;
-    }
+    });
 }
 
 inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0 && g[9] >= 0 && g[9] + g[1] <= g[8]; }
@@ -193,6 +178,7 @@ int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, f
     long chunks = (nvox + (kThreads / 4) * 8 - 1) / ((kThreads / 4) * 8);
     if (chunks < 1) chunks = 1;
     if (chunks > DRC_BN_MAX_CHUNKS) chunks = DRC_BN_MAX_CHUNKS;
+    if (chunks > (long)g.N * g.D * g.H) chunks = (long)g.N * g.D * g.H;
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, shift, sums, scratch);
     return (int)hipGetLastError();
 }
@@ -206,9 +192,13 @@ int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int*
     if (geom_x[0] == 0) return 0;
     if (!x || !y || !mean || !invstd || !gamma || !beta) return -1;
     const BlkGeom gx = to_geom(geom_x), gy = to_geom(geom_y), gr = res ? to_geom(geom_r) : gx;
-    const long total = (long)gx.N * gx.CB * gx.D * gx.H * gx.W * 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total * 1)), dim3(kThreads), 0, (hipStream_t)stream, x, gx, y, gy, res, gr, mean, invstd,
-                       gamma, beta, relu);
+    const long rows = (long)gx.N * gx.D * gx.H;
+    long chunks = ((long)rows * gx.W * 4 + kThreads * 4 - 1) / (kThreads * 4);
+    if (chunks > 2048) chunks = 2048;
+    if (chunks > rows) chunks = rows;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)chunks, (unsigned)gx.CB), dim3(kThreads), 0, (hipStream_t)stream, x, gx, y, gy, res, gr,
+                       mean, invstd, gamma, beta, relu);
     return (int)hipGetLastError();
 }
 

@@ -140,7 +140,9 @@ template <int NT>
 int launch(const drc_wgrad_params& p, hipStream_t s) {
     const long groups = (long)p.N * p.OD * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
     const long jobs = (long)p.nd * p.cb_a * p.cb_b;
-    long workers = 8192 / (jobs > 0 ? jobs : 1);            // ~8 waves per SIMD-slot pair across the chip
+    // one wave per SIMD across all jobs: every extra wave adds a full set of atomicAdd flushes onto the same few addresses
+    // (measured on the Config-A train step: 8192 waves 60 ms, 1024 waves 41 ms)
+    long workers = 1024 / (jobs > 0 ? jobs : 1);
     if (workers > groups) workers = groups;
     if (workers < 1) workers = 1;
     const size_t lds = (size_t)p.lds_bytes_per_wave * WG_WAVES;

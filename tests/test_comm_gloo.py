@@ -24,6 +24,14 @@ def _worker(rank, world, port, n_rois, q):
         comm.synchronize()
         full = comm.all_gather_rows(local)
         red = comm.reduce_dict({"loss": torch.tensor(float(rank + 1))})
+        # train step: per-rank gradients averaged by one flat all-reduce; a parameter that got no gradient on one rank
+        # (e.g. an empty ROI shard) still takes part
+        w = torch.nn.Parameter(torch.zeros(5)); b = torch.nn.Parameter(torch.zeros(2, 3)); frozen = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        w.grad = torch.full((5,), float(rank + 1))
+        if rank == 0:
+            b.grad = torch.full((2, 3), 4.0)
+        comm.GradientSync([w, b, frozen])()
+        assert torch.allclose(w.grad, torch.full((5,), 1.5)) and torch.allclose(b.grad, torch.full((2, 3), 2.0)) and frozen.grad is None
         q.put((rank, lo, hi, full[:, 0, 0].tolist(), float(red["loss"])))
     finally:
         dist.destroy_process_group()
@@ -58,6 +66,9 @@ def test_empty_shard_is_handled():
 
 def test_single_process_fallbacks():
     assert comm.get_world_size() == 1 and comm.get_rank() == 0 and comm.is_main_process()
+    w = torch.nn.Parameter(torch.ones(3)); w.grad = torch.full((3,), 2.0)
+    comm.GradientSync([w])()                                    # world size 1: gradients untouched, no collective
+    assert torch.equal(w.grad, torch.full((3,), 2.0))
     comm.synchronize()
     t = torch.arange(6.).view(2, 3)
     assert torch.equal(comm.all_gather_rows(t), t)
