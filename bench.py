@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rois", type=int, default=128, help="ROI pairs per step per GPU")
+    ap.add_argument("--rois", type=int, default=256, help="ROI pairs per step per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Config-B extra measurement")
     args = ap.parse_args()

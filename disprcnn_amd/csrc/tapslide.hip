@@ -312,7 +312,7 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     }
     const long units = cols * (p.cout_pad / 16 / CT) * p.OD;
     long workers = 256L * SLIDE_WAVES * occ_blocks;
-    if (workers > units / 3) workers = units / 3;
+    if (workers > units / 3) workers = units / 3 > workers / 2 ? units / 3 : (units < workers ? units : workers);   // small volumes: shares down to one slice
     if (workers < SLIDE_WAVES) workers = SLIDE_WAVES;
     dim3 grid((unsigned)((workers + SLIDE_WAVES - 1) / SLIDE_WAVES), 1, 1);
     hipLaunchKernelGGL((tapslide_kernel<VT, CT>), grid, dim3(64 * SLIDE_WAVES), lds, stream, p);

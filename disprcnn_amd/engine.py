@@ -16,7 +16,7 @@ SLACK_FLOATS = 1 << 16          # over-read room behind every blocked tensor (ra
 LDS_PER_WAVE_MAX = 38 * 1024    # 4 waves/block -> 152 KiB of the 160 KiB LDS
 MAX_SLOTS = 112                 # 7 voxel tiles of 16
 TIMING = None                   # bench.py sets this to a list to collect (kernel name, flops, start_evt, end_evt)
-SLIDE = {"enabled": True, "max_slots": 112, "ct": 2}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
+SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
 
 
 def _stream_ptr(device):
@@ -223,6 +223,7 @@ class ConvPlan:
         p = DrcTapconvParams()
         self.slide = slide
         self.fused_deconv = False
+        self.down = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -263,7 +264,7 @@ class ConvPlan:
             # (measured cross-over, tools/exp_conv.py)
             self.slide_ct = SLIDE["ct"] if ct % SLIDE["ct"] == 0 else 1
             cols = x.N * (-(-OH // R)) * (-(-OW // WT))
-            if OD < 6 or cols * (ct // self.slide_ct) * OD // 3 < 700:
+            if OD < SLIDE["min_od"] or cols * (ct // self.slide_ct) * OD // SLIDE["min_share"] < 700:
                 self.slide = False
             else:
                 self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)
@@ -289,7 +290,10 @@ class ConvPlan:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        if self.fused_deconv:
+        if self.down:
+            st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv3d_k3s2_fwd")
+        elif self.fused_deconv:
             st = _lib.lib().drc_deconv3d_k3s2_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_deconv3d_k3s2_fwd")
         elif self.slide:
@@ -304,11 +308,47 @@ class ConvPlan:
             TIMING.append((self.kname, self.flops, e0, e1))
 
 
+DOWN = {"enabled": True, "tile": None}     # stride-2 kernel on parity-split tiles (tapdown.hip); "tile" = development override
+
+
+def choose_tile_down(OH, OW):
+    """Output tile (R, WT) of the stride-2 kernel: least MFMA padding, then the largest tile (more MFMAs per staged
+    byte and per weight load; measured on the 14x14 and 7x7 maps, tools/exp_conv.py), then the widest rows."""
+    if DOWN["tile"]:
+        return DOWN["tile"]
+    best = None
+    for r in range(1, OH + 1):
+        for wt in range(1, OW + 1):
+            if r * wt > MAX_SLOTS:
+                continue
+            vox = (r + 1) * (wt + 1) + (r + 1) * wt + r * (wt + 1) + r * wt
+            if -(-(vox * 2) // 64) > 18:
+                continue
+            nvt = -(-(r * wt) // 16)
+            waste = (-(-OH // r)) * (-(-OW // wt)) * nvt * 16 / (OH * OW)
+            key = (-round(waste, 2), r * wt, wt)
+            if best is None or key > best[0]:
+                best = (key, r, wt)
+    return best[1], best[2]
+
+
 def plan_conv3d(x, y, stride, cout, relu):
     """Conv3d(k3,pad1,stride) on a blocked tensor with halo 1."""
     assert (x.pd, x.ph, x.pw) == (1, 1, 1)
     classes = taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
-    return ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu, slide=(stride == 1 and SLIDE["enabled"]))
+    pl = ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu, slide=(stride == 1 and SLIDE["enabled"]))
+    if stride == 2 and DOWN["enabled"]:
+        pl.down = True
+        pl.p.R, pl.p.WT = choose_tile_down(y.H, y.W)
+        nvt = -(-(pl.p.R * pl.p.WT) // 16)
+        ct = pl.p.cout_pad // 16
+        tiles = x.N * y.D * (-(-y.H // pl.p.R)) * (-(-y.W // pl.p.WT))
+        CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
+        while CT > 1 and (nvt * CT > 28 or tiles * (ct // CT) < 2048):     # keep >= 2 groups per SIMD
+            CT //= 2
+        pl.down_ct = CT
+        pl.kname = "tapdown_kernel<%d,%d>" % (nvt, CT)
+    return pl
 
 
 FUSED_DECONV = {"enabled": True}

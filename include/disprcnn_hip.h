@@ -128,6 +128,13 @@ int drc_tapconv3d_slide_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave
  * Needs R*WT <= 112 and ceil((R+1)*(WT+1)*2/64) <= 9.  Results equal drc_tapconv_fwd's up to the fp32 summation order. */
 int drc_deconv3d_k3s2_fwd(const drc_tapconv_params* p, void* stream);
 
+/* Conv3d(k3, stride 2, pad 1) (+BN, +residual, +ReLU) -- hourglass.conv1/conv3 (stackhourglass.py:9-16) and the data gradient
+ * of the transposed convolutions -- on parity-split LDS tiles: per phase the four (row parity, column parity) planes of the
+ * needed input rows are staged as dense unit-stride tiles, so every tap is a conflict-free B fragment.  Takes the parameter
+ * block of drc_tapconv_fwd for the single 3x3x3 class with in_mul = 2.  cout_tiles_per_wave in {1,2,4} must divide
+ * cout_pad/16; ceil(R*WT/16) * cout_tiles_per_wave <= 28; the tile's four planes must fit 18 LDS-DMA pieces. */
+int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* Final classifier conv Conv3d(32->1,k3,p1,bias=False) (stackhourglass.py:78-88 `classifN[2]`)
  * with the cumulative head add (`+ cost_{k-1}`, :142-144) fused.
  *   x : blocked [N][cb_in][D+2][H+2][W+2][16];  w : [27][cb_in*16];  out,res : dense [N,D,H,W] */

@@ -93,6 +93,7 @@ LAYERS = [  # cin, cout, stride, transposed, dims
     (64, 64, 2, False, (6, 14, 14)), (64, 64, 1, False, (3, 7, 7)), (64, 64, 1, True, (3, 7, 7)),
     (64, 32, 1, True, (6, 14, 14)), (32, 32, 1, False, (2, 56, 56)), (16, 48, 1, False, (2, 5, 9)),
     (16, 48, 1, True, (2, 5, 9)), (32, 32, 1, True, (3, 12, 28)), (64, 64, 1, True, (1, 4, 4)), (24, 16, 1, True, (3, 9, 30)),
+    (16, 48, 2, False, (6, 10, 18)), (32, 32, 2, False, (4, 8, 60)), (64, 64, 2, False, (2, 2, 2)), (24, 16, 2, False, (4, 24, 56)),
 ]
 
 

@@ -34,12 +34,19 @@ if __name__ == "__main__":
         E.SLIDE["enabled"] = os.environ["SLIDE"] != "0"
     if os.environ.get("SLIDE_SLOTS"):
         E.SLIDE["max_slots"] = int(os.environ["SLIDE_SLOTS"])
+    if os.environ.get("DN_TILE"):
+        E.DOWN["tile"] = tuple(int(v) for v in os.environ["DN_TILE"].split(","))
+        run(N, 32, 64, (12, 28, 28), stride=2)
+        run(N, 64, 64, (6, 14, 14), stride=2)
+        sys.exit(0)
     if os.environ.get("DC_TILE"):
         E.DECONV_TILE = tuple(int(v) for v in os.environ["DC_TILE"].split(","))
         run(N, 64, 32, (6, 14, 14), deconv=True)
         sys.exit(0)
     if os.environ.get("MAX_SLOTS"):
         E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
+    if os.environ.get("SLIDE_MIN_OD"):
+        E.SLIDE["min_od"] = int(os.environ["SLIDE_MIN_OD"]); E.SLIDE["min_share"] = 1
     if os.environ.get("SLIDE_CT"):
         E.SLIDE["ct"] = int(os.environ["SLIDE_CT"])
     run(N, 32, 32, (12, 28, 28))
