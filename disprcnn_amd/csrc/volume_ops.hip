@@ -449,6 +449,9 @@ inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
 
+extern "C" int drc_conv3d_cout1_mfma_try(const float* x, const float* w, const float* res, float* out, int N, int cb_in, int D, int H, int W,
+                                         void* stream);   // cout1_mfma.hip
+
 extern "C" {
 
 const char* drc_version(void) { return "disprcnn_hip gfx950 abi1"; }
@@ -511,6 +514,10 @@ int drc_conv3d_cout1_fwd(const float* x, const float* w, const float* res, float
     const long total = (long)N * D * H * W * 4;
     if (total == 0) return 0;
     if (!x || !w || !out) return -1;
+    {   // 32 input channels (the reference's classifier): 1x1x1 GEMM on the MFMA + shifted sum (cout1_mfma.hip)
+        const int st = drc_conv3d_cout1_mfma_try(x, w, res, out, N, cb_in, D, H, W, stream);
+        if (st != 1) return st;
+    }
     // sliding-window kernel when a wave's R x W tile (<= 128 voxels, 2 per lane) and its two LDS tiles fit; else the direct one
     int R = 128 / (W > 0 ? W : 1);
     if (R > H) R = H;

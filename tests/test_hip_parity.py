@@ -132,6 +132,25 @@ def test_conv2d_layer_vs_oracle(dev, cin, cout, k, stride, pad, dil, hw):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("n,dims", [(3, (12, 28, 28)), (2, (6, 56, 56)), (2, (5, 9, 13)), (1, (1, 3, 112)), (2, (3, 30, 7))])
+def test_classifier_conv_cout1_vs_oracle(dev, n, dims):
+    """Conv3d(32->1, k3, p1, bias=False) + cumulative head add (stackhourglass.py:78-88,142-144): the MFMA 1x1x1-GEMM +
+    shifted-sum kernel (and its scalar fallback shapes) vs F.conv3d; 2e-5 * max|ref| + 1e-5."""
+    from disprcnn_amd import engine as E
+    x = synth.hash_uniform(f"c1{dims}:x", (n, 32) + dims)
+    w = synth.hash_uniform("c1:w", (1, 32, 3, 3, 3), -0.1, 0.1)
+    res = synth.hash_uniform(f"c1{dims}:r", (n,) + dims)
+    ref = F.conv3d(x, w, None, 1, 1)[:, 0] + res
+    xb = E.Blocked(n, 32, *dims, 1, 1, 1, dev)
+    xb.from_dense(x.to(dev))
+    out = torch.empty(n, *dims, device=dev)
+    E.conv3d_cout1(xb, E.pack_weight_cout1(w.to(dev)), res.to(dev), out)
+    _close(out, ref)
+    out2 = torch.empty(n, *dims, device=dev)
+    E.conv3d_cout1(xb, E.pack_weight_cout1(w.to(dev)), None, out2)           # no head add
+    _close(out2, ref - res)
+
+
 def test_upsample_softargmin_vs_oracle(dev):
     from disprcnn_amd import ops
     for (dp, hp, wp, mx, mn) in [(12, 28, 28, 48, 0), (24, 56, 56, 48, -48), (12, 28, 28, 24, -24)]:
