@@ -67,6 +67,7 @@ _SIGS = {
     "drc_conv3d_cout1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drc_upsample_softargmin_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_avgpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_avgpool2d_blocked_slice": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_bilinear_up_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_bilinear_resize_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_maxpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

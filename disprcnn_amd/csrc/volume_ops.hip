@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_kernel(const f
 // SPP helpers on blocked 2D tensors (submodule.py:76-90, :120-135).
 // One wave per pooled output voxel: 16 window positions x 4 channel quads per step, shuffle-reduce.
 __global__ __launch_bounds__(64) void avgpool2d_blocked_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int CB, int H,
-                                                               int W, int px, int k, int OH, int OW, int py) {
+                                                               int W, int px, int k, int OH, int OW, int py, int x_cb_total, int x_cb_off) {
     long t = blockIdx.x;
     const int ow = (int)(t % OW); t /= OW;
     const int oh = (int)(t % OH); t /= OH;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void avgpool2d_blocked_kernel(const float* __re
     const int n = (int)(t / CB);
     const int lane = threadIdx.x, q = lane & 3, p0 = lane >> 2;
     const long iW = W + 2 * px, iH = H + 2 * px;
-    const float* xb = x + (((long)n * CB + cb) * iH + (oh * k + px)) * iW * 16 + (long)(ow * k + px) * 16 + q * 4;
+    const float* xb = x + (((long)n * x_cb_total + x_cb_off + cb) * iH + (oh * k + px)) * iW * 16 + (long)(ow * k + px) * 16 + q * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int p = p0; p < k * k; p += 16) {
         const int r = p / k, c = p - r * k;
@@ -560,7 +560,19 @@ int drc_avgpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W,
     const long blocks = (long)N * CB * OH * OW;
     if (blocks == 0) return 0;
     if (!x || !y) return -1;
-    hipLaunchKernelGGL(avgpool2d_blocked_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, x, y, N, CB, H, W, px, k, OH, OW, py);
+    hipLaunchKernelGGL(avgpool2d_blocked_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, x, y, N, CB, H, W, px, k, OH, OW, py, CB, 0);
+    return done();
+}
+
+int drc_avgpool2d_blocked_slice(const float* x, float* y, int N, int CB, int H, int W, int px, int k, int OH, int OW, int py, int x_cb_total,
+                                int x_cb_off, void* stream) {
+    if (N < 0 || CB <= 0 || H <= 0 || W <= 0 || k <= 0 || OH <= 0 || OW <= 0 || OH * k > H || OW * k > W) return -2;
+    if (x_cb_off < 0 || x_cb_off + CB > x_cb_total) return -2;
+    const long blocks = (long)N * CB * OH * OW;
+    if (blocks == 0) return 0;
+    if (!x || !y) return -1;
+    hipLaunchKernelGGL(avgpool2d_blocked_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, x, y, N, CB, H, W, px, k, OH, OW, py,
+                       x_cb_total, x_cb_off);
     return done();
 }
 

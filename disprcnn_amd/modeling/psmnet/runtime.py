@@ -335,17 +335,10 @@ class PSMNetRuntime:
         return t["feat"]
 
     def _avgpool_slice(self, lib, skip, pool, k, oh, ow, sp):
-        """AvgPool2d(k,k) of output_skip, which lives in channel blocks 4..11 of the 20-block concat tensor:
-        pool each image's slice separately (the kernel assumes dense [N][CB] packing of its input)."""
+        """AvgPool2d(k,k) of output_skip, which lives in channel blocks 4..11 of the 20-block concat tensor."""
         base = skip.base
-        st = 0
-        for n in range(base.N):
-            xin = base.storage.data_ptr() + 4 * (n * base.n_stride + skip.cb_off * base.cb_stride)
-            yout = pool.storage.data_ptr() + 4 * (n * pool.n_stride)
-            st = lib.drc_avgpool2d_blocked(xin, yout, 1, skip.cb, base.H, base.W, base.ph, k, oh, ow, 0, sp)
-            if st:
-                return st
-        return st
+        return lib.drc_avgpool2d_blocked_slice(E._ptr(base.storage), E._ptr(pool.storage), base.N, skip.cb, base.H, base.W, base.ph, k, oh, ow, 0,
+                                               base.cb, skip.cb_off, sp)
 
     def forward_images(self, left, right, training=False):
         self._training = bool(training)

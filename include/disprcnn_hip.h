@@ -155,6 +155,10 @@ int drc_upsample_softargmin_fwd(const float* cost, float* disp, int N, int Dp, i
  * slice of the concatenated 320-channel tensor). */
 int drc_avgpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W, int px,
                           int k, int OH, int OW, int py, void* stream);
+/* same, reading channel blocks [x_cb_off, x_cb_off+CB) of an input that has x_cb_total blocks (output_skip lives inside
+ * the 320-channel concat tensor) */
+int drc_avgpool2d_blocked_slice(const float* x, float* y, int N, int CB, int H, int W, int px, int k, int OH, int OW, int py,
+                                int x_cb_total, int x_cb_off, void* stream);
 int drc_bilinear_up_blocked(const float* x, float* y, int N, int CB, int IH, int IW, int px,
                             int OH, int OW, int py, int y_cb_total, int y_cb_off, void* stream);
 /* a12 helpers (ResNet-FPN): bilinear resize with either align_corners convention (the fork's FPN top-down path uses

@@ -1,0 +1,31 @@
+"""Development tool: Config B (16 ROI crops 224x224, D=96, full PSMNet) and the R-50-FPN trunk, for rocprofv3 --kernel-trace."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from types import SimpleNamespace as NS
+from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+from disprcnn_amd.modeling.backbone import build_backbone
+from disprcnn_amd.utils import synth
+dev = torch.device("cuda:0")
+what = os.environ.get("WHAT", "psm")
+if what == "psm":
+    m = PSMNet(48, -48)
+    m.load_state_dict(synth.synth_state_dict(m.state_dict()), strict=True)
+    m = m.to(dev).eval()
+    l, r = synth.synth_images(16, 224, 224, tag="benchB")
+    l, r = l.to(dev), r.to(dev)
+    f = lambda: m((l, r))
+else:
+    bb = build_backbone(NS(MODEL=NS(BACKBONE=NS(CONV_BODY="R-50-FPN"), RESNETS=NS(BACKBONE_OUT_CHANNELS=256, RES2_OUT_CHANNELS=256))))
+    bb.load_state_dict(synth.synth_backbone_state(bb.state_dict()))
+    bb = bb.to(dev).eval()
+    pair = synth.hash_uniform("benchpair", (2, 3, 375, 1242), 0.0, 1.0).to(dev)
+    f = lambda: bb(pair)
+with torch.no_grad():
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+print(what, "ms", (time.perf_counter() - t0) / 5 * 1e3)
