@@ -114,6 +114,34 @@ def pack_weight(w, transposed=False):
     return wp.view(K, cb, 2, 8, cout_pad).permute(0, 1, 2, 4, 3).contiguous()
 
 
+POINTWISE = {"enabled": True}      # 1x1 Conv2d through the LDS-free GEMM kernel (pointwise.hip)
+
+
+def is_pointwise(weight_shape, transposed=False):
+    """True for the weights of a 1x1 Conv2d, which the pointwise kernel takes in its own packing."""
+    return POINTWISE["enabled"] and len(weight_shape) == 4 and tuple(weight_shape[2:]) == (1, 1) and not transposed
+
+
+def pack_weight_pw(w):
+    """[Cout,Cin,1,1] -> [cb_in][cout_pad][16] fp32 contiguous: lane (cout, g) of the MFMA A operand reads channels 4g..4g+3
+    of a 16-channel block as one float4 (1 KiB per 16 couts)."""
+    cout, cin = w.shape[:2]
+    cb = (cin + CB - 1) // CB
+    cout_pad = (cout + CB - 1) // CB * CB
+    wp = torch.zeros(cb * CB, cout_pad, dtype=torch.float32, device=w.device)
+    wp[:cin, :cout] = w.reshape(cout, cin).t()
+    return wp.view(cb, CB, cout_pad).permute(0, 2, 1).contiguous()
+
+
+def pack_conv_weight(w, transposed=False):
+    """The packing the engine's plan for this convolution expects (pointwise for 1x1 Conv2d, tap layout otherwise)."""
+    return pack_weight_pw(w) if is_pointwise(w.shape, transposed) else pack_weight(w, transposed)
+
+
+def cout_pad_of(cout):
+    return (cout + CB - 1) // CB * CB
+
+
 def pack_weight_cout1(w):
     """Conv3d(Cin->1,k3) weight [1,Cin,3,3,3] -> [27][cb*16]."""
     cin = w.shape[1]
@@ -224,6 +252,7 @@ class ConvPlan:
         self.slide = slide
         self.fused_deconv = False
         self.down = False
+        self.pointwise = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -290,7 +319,12 @@ class ConvPlan:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        if self.down:
+        if (w.dim() == 3) != self.pointwise:
+            raise ValueError("weights are not in the packing this plan expects (engine.pack_conv_weight)")
+        if self.pointwise:
+            st = _lib.lib().drc_conv2d_k1_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_conv2d_k1_fwd")
+        elif self.down:
             st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_fwd")
         elif self.fused_deconv:
@@ -391,7 +425,15 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
     """Conv2d(k,stride,pad,dilation) on blocked 2D tensors (D=1, pd=0)."""
     assert x.pd == 0 and x.D == 1
     classes = taps_conv((1, k, k), (1, dilation, dilation), (0, pad, pad), (0, x.ph, x.pw))
-    return ConvPlan(x, y, classes, stride, 1, (1, y.H, y.W), cout, relu)
+    pl = ConvPlan(x, y, classes, stride, 1, (1, y.H, y.W), cout, relu)
+    if k == 1 and POINTWISE["enabled"]:
+        pl.pointwise = True
+        ct = pl.p.cout_pad // 16
+        tiles = -(-(x.N * y.H * y.W) // 16)
+        vc = (4, 4) if ct % 4 == 0 and tiles // 4 * (ct // 4) >= 2048 else (4, 2) if ct % 2 == 0 and tiles // 4 * (ct // 2) >= 2048 else \
+            (2, 2) if ct % 2 == 0 else (2, 1)
+        pl.kname = "pointwise_kernel<%d,%d>" % vc
+    return pl
 
 
 def plan_deconv2d(x, y, k, cout, relu=False):

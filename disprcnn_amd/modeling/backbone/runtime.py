@@ -9,8 +9,8 @@ from ... import engine as E
 class _Site:
     def __init__(self, conv, bn, device):
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
-        self.w = E.pack_weight(w)
-        cp = self.w.shape[3]
+        self.w = E.pack_conv_weight(w)
+        cp = E.cout_pad_of(w.shape[0])
         if bn is not None:
             self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
                                                bn.running_mean.detach().to(device).float(), bn.running_var.detach().to(device).float(),

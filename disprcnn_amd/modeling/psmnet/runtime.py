@@ -18,8 +18,8 @@ class _Conv:
         self.conv, self.transposed = conv, transposed
         self.cout = w.shape[1] if transposed else w.shape[0]
         self.cin = w.shape[0] if transposed else w.shape[1]
-        self.w = E.pack_weight(w, transposed)
-        cout_pad = self.w.shape[3]
+        self.w = E.pack_conv_weight(w, transposed)
+        cout_pad = E.cout_pad_of(self.cout)
         self.bn = bn
         self.unit_scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
         self.zero_shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)

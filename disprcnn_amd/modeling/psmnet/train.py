@@ -123,8 +123,9 @@ class RegressorBackward:
         elif stride == 2:
             wp = E.pack_weight(wt, transposed=True)
         else:
-            wp = E.pack_weight(wt.transpose(0, 1).flip(*range(2, wt.dim())).contiguous())
-        cp = wp.shape[3]
+            wtf = wt.transpose(0, 1).flip(*range(2, wt.dim())).contiguous()
+            wp = E.pack_weight_pw(wtf) if ent["plan"].pointwise else E.pack_weight(wtf)
+        cp = ent["plan"].p.cout_pad
         return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev)
 
     _x_of = {}

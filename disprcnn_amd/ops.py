@@ -84,8 +84,8 @@ def conv2d_bn(x, weight, scale, shift, stride=1, pad=1, dilation=1, relu=False, 
     yb = E.Blocked(n, cout, 1, oh, ow, 0, 1, 1, dev)
     rb = E.Blocked(n, cout, 1, oh, ow, 0, 2, 2, dev).from_dense(residual) if residual is not None else None
     plan = E.plan_conv2d(xb, yb, k, stride, pad, dilation, cout, relu)
-    wp = E.pack_weight(weight.to(dev).float())
-    cp = wp.shape[3]
+    wp = E.pack_conv_weight(weight.to(dev).float())
+    cp = E.cout_pad_of(cout)
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale; sh[:cout] = shift
     plan.run(xb, wp, sc, sh, yb, rb)

@@ -135,6 +135,12 @@ int drc_deconv3d_k3s2_fwd(const drc_tapconv_params* p, void* stream);
  * cout_pad/16; ceil(R*WT/16) * cout_tiles_per_wave <= 28; the tile's four planes must fit 18 LDS-DMA pieces. */
 int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* Conv2d(k1, stride 1 or 2, pad 0) (+BN/bias, +residual, +ReLU) as a register-blocked MFMA GEMM with both operands read
+ * straight from global memory (no LDS): the 1x1 convolutions of ResNet-50-FPN (backbone/resnet.py, backbone/fpn.py) and of the
+ * PSMNet feature CNN (submodule.py).  Parameter block of drc_tapconv_fwd for the single 1x1 class (OD = 1); the weights are
+ * packed [cb_in][cout_pad][16] (engine.pack_weight_pw), NOT in the tap layout. */
+int drc_conv2d_k1_fwd(const drc_tapconv_params* p, void* stream);
+
 /* Final classifier conv Conv3d(32->1,k3,p1,bias=False) (stackhourglass.py:78-88 `classifN[2]`)
  * with the cumulative head add (`+ cost_{k-1}`, :142-144) fused.
  *   x : blocked [N][cb_in][D+2][H+2][W+2][16];  w : [27][cb_in*16];  out,res : dense [N,D,H,W] */

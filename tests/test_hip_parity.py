@@ -119,7 +119,9 @@ def test_conv3d_layer_vs_oracle(dev, cin, cout, stride, transposed, dims):
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [(3, 32, 3, 2, 1, 1, (64, 80)), (32, 32, 3, 1, 1, 1, (40, 56)),
                                                          (32, 64, 1, 2, 0, 1, (40, 56)), (128, 128, 3, 1, 2, 2, (28, 28)),
-                                                         (320, 128, 3, 1, 1, 1, (12, 20)), (128, 32, 1, 1, 0, 1, (3, 3))])
+                                                         (320, 128, 3, 1, 1, 1, (12, 20)), (128, 32, 1, 1, 0, 1, (3, 3)),
+                                                         (256, 64, 1, 1, 0, 1, (47, 80)), (24, 40, 1, 1, 0, 1, (5, 7)),
+                                                         (64, 256, 1, 2, 0, 1, (31, 45)), (512, 128, 1, 1, 0, 1, (24, 78))])
 def test_conv2d_layer_vs_oracle(dev, cin, cout, k, stride, pad, dil, hw):
     from disprcnn_amd import ops
     x = synth.hash_uniform(f"C{cin}{cout}{k}:x", (2, cin) + hw)
@@ -130,6 +132,9 @@ def test_conv2d_layer_vs_oracle(dev, cin, cout, k, stride, pad, dil, hw):
     got = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, pad, dil, False, None, in_halo=max(pad, 1))
     assert got.shape == ref.shape
     _close(got, ref)
+    res = synth.hash_uniform(f"C{cin}{cout}{k}:r", tuple(ref.shape))                      # + residual + ReLU (Bottleneck conv3)
+    got = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, pad, dil, True, res.to(dev), in_halo=max(pad, 1))
+    _close(got, F.relu(ref + res))
 
 
 @pytest.mark.parametrize("n,dims", [(3, (12, 28, 28)), (2, (6, 56, 56)), (2, (5, 9, 13)), (1, (1, 3, 112)), (2, (3, 30, 7))])
