@@ -253,6 +253,7 @@ class ConvPlan:
         self.fused_deconv = False
         self.down = False
         self.pointwise = False
+        self.tap2d = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -324,6 +325,9 @@ class ConvPlan:
         if self.pointwise:
             st = _lib.lib().drc_conv2d_k1_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_conv2d_k1_fwd")
+        elif self.tap2d:
+            st = _lib.lib().drc_conv2d_k3_fwd(C.byref(p), self.tap2d_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv2d_k3_fwd")
         elif self.down:
             st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_fwd")
@@ -421,11 +425,46 @@ def plan_deconv3d(x, y, cout, relu):
     return pl
 
 
+TAP2D = {"enabled": True, "tile": None}     # 3x3 stride-1 Conv2d kernel with explicit waits (tap2d.hip)
+
+
+def choose_tile_2d(OH, OW, dil):
+    """Output tile (R, WT) of the 3x3 Conv2d kernel: least MFMA padding, then the largest tile, then the widest rows; the
+    (R+2d) x (WT+2d) input tile must fit 18 LDS-DMA pieces."""
+    if TAP2D["tile"]:
+        return TAP2D["tile"]
+    best = None
+    for r in range(1, min(OH, MAX_SLOTS) + 1):
+        for wt in range(1, min(OW, MAX_SLOTS // r) + 1):
+            if -(-((r + 2 * dil) * (wt + 2 * dil) * 2) // 64) > 18:
+                continue
+            nvt = -(-(r * wt) // 16)
+            waste = (-(-OH // r)) * (-(-OW // wt)) * nvt * 16 / (OH * OW)
+            halo = (r + 2 * dil) * (wt + 2 * dil) / (r * wt)          # staged voxels per output voxel
+            key = (-round(waste + 0.15 * halo, 1), r * wt, wt)
+            if best is None or key > best[0]:
+                best = (key, r, wt)
+    return (best[1], best[2]) if best else None
+
+
 def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
     """Conv2d(k,stride,pad,dilation) on blocked 2D tensors (D=1, pd=0)."""
     assert x.pd == 0 and x.D == 1
     classes = taps_conv((1, k, k), (1, dilation, dilation), (0, pad, pad), (0, x.ph, x.pw))
     pl = ConvPlan(x, y, classes, stride, 1, (1, y.H, y.W), cout, relu)
+    if k == 3 and stride == 1 and pad == dilation and TAP2D["enabled"]:
+        tile = choose_tile_2d(y.H, y.W, dilation)
+        if tile is not None:
+            pl.tap2d = True
+            pl.p.R, pl.p.WT = tile
+            nvt = -(-(tile[0] * tile[1]) // 16)
+            ct = pl.p.cout_pad // 16
+            tiles = x.N * (-(-y.H // tile[0])) * (-(-y.W // tile[1]))
+            CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
+            while CT > 1 and (nvt * CT > 20 or tiles * (ct // CT) < 2048):      # no spills; keep >= 2 groups per SIMD
+                CT //= 2
+            pl.tap2d_ct = CT
+            pl.kname = "tap2d_kernel<%d,%d>" % (nvt, CT)
     if k == 1 and POINTWISE["enabled"]:
         pl.pointwise = True
         ct = pl.p.cout_pad // 16

@@ -135,6 +135,12 @@ int drc_deconv3d_k3s2_fwd(const drc_tapconv_params* p, void* stream);
  * cout_pad/16; ceil(R*WT/16) * cout_tiles_per_wave <= 28; the tile's four planes must fit 18 LDS-DMA pieces. */
 int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* Conv2d(k3, stride 1, dilation d, pad d) (+BN/bias, +residual, +ReLU): the 3x3 convolutions of the PSMNet feature CNN
+ * (submodule.py:60-139) and of ResNet-50-FPN, with the wait protocol of drc_conv3d_k3s2_fwd (dense LDS-DMA tile, static piece
+ * count, uncounted weight loads, two waves per SIMD).  Parameter block of drc_tapconv_fwd for the single 1x3x3 class
+ * (OD = 1, tap spacing = dilation); cout_tiles_per_wave in {1,2,4}; (R+2d)*(WT+2d) voxels must fit 18 LDS-DMA pieces. */
+int drc_conv2d_k3_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* Conv2d(k1, stride 1 or 2, pad 0) (+BN/bias, +residual, +ReLU) as a register-blocked MFMA GEMM with both operands read
  * straight from global memory (no LDS): the 1x1 convolutions of ResNet-50-FPN (backbone/resnet.py, backbone/fpn.py) and of the
  * PSMNet feature CNN (submodule.py).  Parameter block of drc_tapconv_fwd for the single 1x1 class (OD = 1); the weights are
