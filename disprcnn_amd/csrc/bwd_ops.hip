@@ -30,68 +30,84 @@ inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[
 
 // ------------------------------------------------------------------------------------------------ a7 backward
 // disp = sum_d p_d * dval_d, p = softmax_d(c_up), c_up = trilinear(cost).  d disp / d c_up[d] = p_d (dval_d - disp).
-// One thread per output pixel: recompute the LDS column of bilinear-resampled coarse slices, fold the D fine gradients
-// back onto the coarse slices (lerp weights), then scatter the D' values to the 4 bilinear neighbours with atomicAdd.
-constexpr int kSAThreads = 128;
+// One thread per output pixel, one block per 8 x 16 pixel tile of an image: recompute the LDS column of bilinear-resampled
+// coarse slices, fold the D fine gradients back onto the coarse slices (lerp weights), add the D' values onto the tile's coarse
+// footprint (a few cells x D', LDS atomics), then flush the footprint with one global atomicAdd per cell -- 20x fewer global
+// atomics than scattering from every pixel.
+constexpr int kSAThreads = 128, kSATX = 16, kSATY = 8;
 __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ gdisp,
                                                                              float* __restrict__ gcost, int N, int Dp, int Hp, int Wp,
-                                                                             int D, int H, int W, int mindisp) {
-    extern __shared__ float sm[];                      // cz [Dp][T] then gz [Dp][T]
+                                                                             int D, int H, int W, int mindisp, int CH, int CW) {
+    extern __shared__ float sm[];                      // cz [Dp][T], gz [Dp][T], footprint [Dp][CH][CW]
     float* cz = sm;
     float* gz = sm + Dp * kSAThreads;
-    const long total = (long)N * H * W;
-    const long idx = (long)blockIdx.x * kSAThreads + threadIdx.x;
-    if (idx >= total) return;
-    long t = idx;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int n = (int)(t / H);
+    float* fp = gz + Dp * kSAThreads;
+    const int tiles_x = (W + kSATX - 1) / kSATX, tiles_y = (H + kSATY - 1) / kSATY;
+    int bt = blockIdx.x;
+    const int bx = bt % tiles_x; bt /= tiles_x;
+    const int by = bt % tiles_y;
+    const int n = bt / tiles_y;
+    const int x = bx * kSATX + (threadIdx.x % kSATX), y = by * kSATY + (threadIdx.x / kSATX);
+    const bool live = x < W && y < H;
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
     const float sd = D > 1 ? (float)(Dp - 1) / (float)(D - 1) : 0.f;
-    const float fy = sy * y, fx = sx * x;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
-    const float ty = fy - y0, tx = fx - x0;
-    const float* c = cost + (long)n * Dp * Hp * Wp;
-    float m = -INFINITY;
-    for (int k = 0; k < Dp; ++k) {
-        const float* s = c + (long)k * Hp * Wp;
-        const float a = s[y0 * Wp + x0] * (1.f - tx) + s[y0 * Wp + x1] * tx;
-        const float b = s[y1 * Wp + x0] * (1.f - tx) + s[y1 * Wp + x1] * tx;
-        const float v = a * (1.f - ty) + b * ty;
-        cz[k * kSAThreads + threadIdx.x] = v;
-        gz[k * kSAThreads + threadIdx.x] = 0.f;
-        m = fmaxf(m, v);
+    const int cy0 = (int)(sy * (by * kSATY)), cx0 = (int)(sx * (bx * kSATX));     // footprint origin (coarse)
+    for (int i = threadIdx.x; i < Dp * CH * CW; i += kSAThreads) fp[i] = 0.f;
+    __syncthreads();
+    if (live) {
+        const float fy = sy * y, fx = sx * x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
+        const float ty = fy - y0, tx = fx - x0;
+        const float* c = cost + (long)n * Dp * Hp * Wp;
+        float m = -INFINITY;
+        for (int k = 0; k < Dp; ++k) {
+            const float* s = c + (long)k * Hp * Wp;
+            const float a = s[y0 * Wp + x0] * (1.f - tx) + s[y0 * Wp + x1] * tx;
+            const float b = s[y1 * Wp + x0] * (1.f - tx) + s[y1 * Wp + x1] * tx;
+            const float v = a * (1.f - ty) + b * ty;
+            cz[k * kSAThreads + threadIdx.x] = v;
+            gz[k * kSAThreads + threadIdx.x] = 0.f;
+            m = fmaxf(m, v);
+        }
+        float se = 0.f, sde = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float fd = sd * d;
+            const int k0 = (int)fd;
+            const int k1 = k0 + (k0 < Dp - 1);
+            const float td = fd - k0;
+            const float e = expf(cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td - m);
+            se += e; sde = fmaf(e, (float)(mindisp + d), sde);
+        }
+        const float disp = sde / se, g = gdisp[((long)n * H + y) * W + x] / se;
+        for (int d = 0; d < D; ++d) {
+            const float fd = sd * d;
+            const int k0 = (int)fd;
+            const int k1 = k0 + (k0 < Dp - 1);
+            const float td = fd - k0;
+            const float e = expf(cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td - m);
+            const float gv = g * e * ((float)(mindisp + d) - disp);
+            gz[k0 * kSAThreads + threadIdx.x] += gv * (1.f - td);
+            gz[k1 * kSAThreads + threadIdx.x] += gv * td;
+        }
+        const int ly0 = y0 - cy0, ly1 = y1 - cy0, lx0 = x0 - cx0, lx1 = x1 - cx0;   // inside [0,CH) x [0,CW) by construction
+        for (int k = 0; k < Dp; ++k) {
+            const float v = gz[k * kSAThreads + threadIdx.x];
+            float* f = fp + k * CH * CW;
+            atomicAdd(f + ly0 * CW + lx0, v * (1.f - ty) * (1.f - tx));
+            atomicAdd(f + ly0 * CW + lx1, v * (1.f - ty) * tx);
+            atomicAdd(f + ly1 * CW + lx0, v * ty * (1.f - tx));
+            atomicAdd(f + ly1 * CW + lx1, v * ty * tx);
+        }
     }
-    float se = 0.f, sde = 0.f;
-    for (int d = 0; d < D; ++d) {
-        const float fd = sd * d;
-        const int k0 = (int)fd;
-        const int k1 = k0 + (k0 < Dp - 1);
-        const float td = fd - k0;
-        const float e = expf(cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td - m);
-        se += e; sde = fmaf(e, (float)(mindisp + d), sde);
-    }
-    const float disp = sde / se, g = gdisp[idx] / se;
-    for (int d = 0; d < D; ++d) {
-        const float fd = sd * d;
-        const int k0 = (int)fd;
-        const int k1 = k0 + (k0 < Dp - 1);
-        const float td = fd - k0;
-        const float e = expf(cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td - m);
-        const float gv = g * e * ((float)(mindisp + d) - disp);
-        gz[k0 * kSAThreads + threadIdx.x] += gv * (1.f - td);
-        gz[k1 * kSAThreads + threadIdx.x] += gv * td;
-    }
+    __syncthreads();
     float* gc = gcost + (long)n * Dp * Hp * Wp;
-    for (int k = 0; k < Dp; ++k) {
-        const float v = gz[k * kSAThreads + threadIdx.x];
-        float* s = gc + (long)k * Hp * Wp;
-        atomicAdd(s + y0 * Wp + x0, v * (1.f - ty) * (1.f - tx));
-        atomicAdd(s + y0 * Wp + x1, v * (1.f - ty) * tx);
-        atomicAdd(s + y1 * Wp + x0, v * ty * (1.f - tx));
-        atomicAdd(s + y1 * Wp + x1, v * ty * tx);
+    for (int i = threadIdx.x; i < Dp * CH * CW; i += kSAThreads) {
+        const int k = i / (CH * CW), r = i - k * CH * CW;
+        const int yy = cy0 + r / CW, xx = cx0 + r % CW;
+        const float v = fp[i];
+        if (v != 0.f && yy < Hp && xx < Wp) atomicAdd(gc + ((long)k * Hp + yy) * Wp + xx, v);
     }
 }
 
@@ -310,9 +326,13 @@ int drc_upsample_softargmin_bwd(const float* cost, const float* grad_disp, float
     const long total = (long)N * H * W;
     if (total == 0) return 0;
     if (!cost || !grad_disp || !grad_cost) return -1;           // grad_cost is zero-filled by the caller
-    const unsigned blocks = (unsigned)((total + kSAThreads - 1) / kSAThreads);
-    hipLaunchKernelGGL(upsample_softargmin_bwd_kernel, dim3(blocks), dim3(kSAThreads), (size_t)2 * Dp * kSAThreads * 4, (hipStream_t)stream,
-                       cost, grad_disp, grad_cost, N, Dp, Hp, Wp, D, H, W, mindisp);
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const int CH = (int)(sy * (kSATY - 1)) + 3, CW = (int)(sx * (kSATX - 1)) + 3;    // coarse cells an 8 x 16 tile can touch (+ rounding slack)
+    const size_t lds = ((size_t)2 * Dp * kSAThreads + (size_t)Dp * CH * CW) * 4;
+    if (lds > 64 * 1024) return -2;
+    const long blocks = (long)N * ((H + kSATY - 1) / kSATY) * ((W + kSATX - 1) / kSATX);
+    hipLaunchKernelGGL(upsample_softargmin_bwd_kernel, dim3((unsigned)blocks), dim3(kSAThreads), lds, (hipStream_t)stream,
+                       cost, grad_disp, grad_cost, N, Dp, Hp, Wp, D, H, W, mindisp, CH, CW);
     return (int)hipGetLastError();
 }
 

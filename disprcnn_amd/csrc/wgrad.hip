@@ -158,6 +158,8 @@ int launch(const drc_wgrad_params& p, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* stream);   // wgrad_slide.hip
+
 extern "C" int drc_tapconv_wgrad(const drc_wgrad_params* pp, void* stream) {
     if (!pp) return -1;
     const drc_wgrad_params& p = *pp;
@@ -165,6 +167,10 @@ extern "C" int drc_tapconv_wgrad(const drc_wgrad_params* pp, void* stream) {
     if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0 || p.cb_a <= 0 || p.cb_b <= 0) return -2;
     if (p.N == 0) return 0;
     if ((p.in_mul != 1 && p.in_mul != 2) || p.nd < 1 || p.nh < 1 || p.nw < 1 || p.dd0 < 0 || p.dh0 < 0 || p.dw0 < 0) return -2;
+    {   // stride-1 3x3x3: sliding depth window, all 27 taps per wave
+        const int st = drc_tapconv_wgrad_slide_try(pp, stream);
+        if (st != 1) return st;
+    }
     if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 112) return -3;
     const int rows_in = p.in_mul * (p.R - 1) + (p.nh - 1) * p.sh + 1;
     const int seg_vox = p.in_mul * (p.WT - 1) + (p.nw - 1) * p.sw + 1;

@@ -1,0 +1,193 @@
+// wgrad_slide.hip -- weight gradient of the stride-1 3x3x3 convolutions with a sliding depth window (gfx950 / CDNA4).
+//
+//   gw[ca][cb][t] += sum_{n,o} a[n, ca, o + tap_t] * b[n, cb, o]        a = layer input x, b = gradient of the conv output
+//   reference: autograd of the nn.Conv3d layers of stackhourglass.py:63-88 / :7-20 (dres0/1, classifN[0], hourglass conv2/conv4)
+//
+// wgrad.hip gives a wave one depth tap and 9 accumulators and re-stages the a and b tiles for every (n, od) group with the
+// latency exposed: 13 MFMAs per staged KiB.  Here a wave owns one 16x16 channel-block pair and ALL 27 taps (27 accumulator
+// tiles) and walks the depth of a column (n, row tile): per output slice it stages ONE new a slice (ring of three) and the b
+// tile, both one slice ahead of the MFMAs, and runs 27 * (R*WT/4) MFMAs on them -- 3x the MFMAs per staged byte, no exposed
+// staging inside a column, one atomicAdd flush per wave at the very end.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define WS_WAVES 4
+#define WS_PA 10     /* LDS-DMA pieces of an a slice tile: (R+2)*(WT+2)*4 units of 16 B */
+#define WS_PB 6      /* pieces of a b tile: R*WT*4 units */
+#define WS_MAXK 16   /* k-steps (4 voxels each): R*WT <= 64 */
+
+namespace {
+
+__global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wgrad_params p, int R, int WT) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;   // a-channel (A operand row) / b-channel (B operand column)
+    const int g = lane >> 4;   // k member: voxel 4m+g
+
+    const int cbb = blockIdx.y % p.cb_b, ca = blockIdx.y / p.cb_b;
+    const int D = p.OD, H = p.OH, W = p.OW;
+    const int n_wt = (W + WT - 1) / WT, n_rt = (H + R - 1) / R;
+    const int cols = p.N * n_rt * n_wt;
+    const int workers = gridDim.x * WS_WAVES;
+    const int seg = WT + 2, rows_a = R + 2;
+    const int units_a = rows_a * seg * 4, units_b = R * WT * 4;
+    const int pieces_a = (units_a + 63) >> 6, pieces_b = (units_b + 63) >> 6;
+    const int a_floats = pieces_a * 256, b_floats = pieces_b * 256;
+    float* lds_a = lds_all + wave * (3 * a_floats + 2 * b_floats);     // ring of three a slices
+    float* lds_b = lds_a + 3 * a_floats;                               // two b tiles
+    const int nslots = R * WT, nk = (nslots + 3) >> 2;
+    const unsigned mag_a = ((1u << 20) + seg * 4 - 1) / (seg * 4), mag_b = ((1u << 20) + WT * 4 - 1) / (WT * 4);
+
+    // per-lane offsets of voxel slot 4m+g inside an a slice tile (tap (0,0)), and its (row, col)
+    int a_off[WS_MAXK];
+#pragma unroll
+    for (int m = 0; m < WS_MAXK; ++m) {
+        const int s = 4 * m + g;
+        int r = s / WT, c = s - r * WT;
+        if (s >= nslots) { r = 0; c = 0; }
+        a_off[m] = (r * seg + c) * 16 + j;
+    }
+
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    unsigned poff_a[WS_PA], poff_b[WS_PB];
+    for (int col = blockIdx.x * WS_WAVES + wave; col < cols; col += workers) {
+        int q = col;
+        const int wt = q % n_wt; q /= n_wt;
+        const int rt = q % n_rt;
+        const int n = q / n_rt;
+        const int oh0 = rt * R, ow0 = wt * WT;
+        const int nr = H - oh0 < R ? H - oh0 : R, nc = W - ow0 < WT ? W - ow0 : WT;   // valid rows / columns (ragged tiles)
+        // per-lane global byte offsets of the pieces (all lanes active; outside a ragged tile's needed rows / columns: a valid neighbour)
+#pragma unroll
+        for (int k = 0; k < WS_PA; ++k) {
+            int u = k * 64 + lane;
+            u = u < units_a ? u : units_a - 1;
+            int r = (int)(((unsigned)u * mag_a) >> 20);
+            int cu = u - r * seg * 4;
+            int vx = cu >> 2;
+            r = r < nr + 1 ? r : nr + 1;
+            vx = vx < nc + 1 ? vx : nc + 1;
+            poff_a[k] = (unsigned)((r * (int)p.a_h_stride + vx * 16 + (cu & 3) * 4) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < WS_PB; ++k) {
+            int u = k * 64 + lane;
+            u = u < units_b ? u : units_b - 1;
+            int r = (int)(((unsigned)u * mag_b) >> 20);
+            int cu = u - r * WT * 4;
+            int vx = cu >> 2;
+            r = r < nr - 1 ? r : nr - 1;
+            vx = vx < nc - 1 ? vx : nc - 1;
+            poff_b[k] = (unsigned)((r * (int)p.b_h_stride + vx * 16 + (cu & 3) * 4) * 4);
+        }
+        // voxels of the tile outside the output grid contribute nothing: their b value is forced to zero
+        unsigned okmask = 0;
+#pragma unroll
+        for (int m = 0; m < WS_MAXK; ++m) {
+            const int s = 4 * m + g;
+            const int r = s / WT, c = s - r * WT;
+            if (s < nslots && r < nr && c < nc) okmask |= 1u << m;
+        }
+        const char* abase = (const char*)(p.a + (int64_t)n * p.a_n_stride + (int64_t)ca * p.a_cb_stride + (int64_t)p.dd0 * p.a_d_stride +
+                                          (int64_t)(oh0 + p.dh0) * p.a_h_stride + (int64_t)(ow0 + p.dw0) * 16);
+        const char* bbase = (const char*)(p.b + p.b_off0 + (int64_t)n * p.b_n_stride + (int64_t)cbb * p.b_cb_stride + (int64_t)oh0 * p.b_h_stride +
+                                          (int64_t)ow0 * 16);
+        const int64_t a_ds = p.a_d_stride * 4, b_ds = p.b_d_stride * 4;
+        auto stage_a = [&](int ps) __attribute__((always_inline)) {       // padded depth slice ps of a -> ring slot ps % 3
+            float* dst = lds_a + (ps % 3) * a_floats;
+            const char* sb = abase + (int64_t)ps * a_ds;
+#pragma unroll
+            for (int k = 0; k < WS_PA; ++k)
+                if (k < pieces_a) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sb + poff_a[k]), LDS_PTR(dst + k * 256), 16, 0, 0);
+        };
+        auto stage_b = [&](int od) __attribute__((always_inline)) {
+            float* dst = lds_b + (od & 1) * b_floats;
+            const char* sb = bbase + (int64_t)od * b_ds;
+#pragma unroll
+            for (int k = 0; k < WS_PB; ++k)
+                if (k < pieces_b) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sb + poff_b[k]), LDS_PTR(dst + k * 256), 16, 0, 0);
+        };
+
+        // all LDS reads of the previous column are consumed (in-order wave) before its tiles are overwritten
+        stage_a(0); stage_a(1); stage_a(2); stage_b(0);
+        for (int od = 0; od < D; ++od) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a[od+2] and b[od] (issued one slice ago) have landed
+            const float* bt = lds_b + (od & 1) * b_floats;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float* at = lds_a + ((od + kd) % 3) * a_floats;
+#pragma unroll
+                for (int m = 0; m < WS_MAXK; ++m) {
+                    if (m < nk) {                                      // wave-uniform
+                        const float bv = ((okmask >> m) & 1u) ? bt[(4 * m + g) * 16 + j] : 0.f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const float av = at[a_off[m] + ((t / 3) * seg + (t % 3)) * 16];
+                            acc[kd * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[kd * 9 + t], 0, 0, 0);
+                        }
+                    }
+                }
+                if (kd == 0 && od + 1 < D) {   // slot od % 3 is free now: stage the slice after next into it, and the next b tile
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_a(od + 3);
+                    stage_b(od + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // ---- flush: D[i = a channel][j = b channel]: lane holds rows 4g..4g+3 of column j
+    const int cbt = p.cb_b * 16;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ia = ca * 16 + g * 4 + r, ib = cbb * 16 + j;
+            atomicAdd(p.gw + ((int64_t)ia * cbt + ib) * 27 + t, acc[t][r]);
+        }
+}
+
+}  // namespace
+
+// returns 1 if the shape is not handled here (caller uses the generic kernel), 0 on launch, or a hipError_t
+extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* stream) {
+    const drc_wgrad_params& p = *pp;
+    if (p.in_mul != 1 || p.nd != 3 || p.nh != 3 || p.nw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1 || p.OD < 2) return 1;
+    // tile: rows as wide as the map up to 32 columns, R*WT <= 64 voxels (16 k-steps)
+    const int parts = (p.OW + 31) / 32;
+    const int WT = (p.OW + parts - 1) / parts;
+    int R = 64 / WT;
+    if (R > p.OH) R = p.OH;
+    if (R < 1) return 1;
+    while (R > 1 && p.OH % R && (p.OH + R - 1) / R * R - p.OH > R / 2) --R;
+    const int pieces_a = ((R + 2) * (WT + 2) * 4 + 63) / 64, pieces_b = (R * WT * 4 + 63) / 64;
+    if (pieces_a > WS_PA || pieces_b > WS_PB || R * WT > 4 * WS_MAXK) return 1;
+    const size_t lds = (size_t)WS_WAVES * (3 * pieces_a + 2 * pieces_b) * 1024;
+    if (lds > 160 * 1024) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wgrad_slide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long cols = (long)p.N * ((p.OH + R - 1) / R) * ((p.OW + WT - 1) / WT);
+    const long jobs = (long)p.cb_a * p.cb_b;
+    long workers = 1024 / (jobs > 0 ? jobs : 1);            // one wave per SIMD across all jobs (atomicAdd flushes per wave)
+    if (workers > cols) workers = cols;
+    if (workers < 1) workers = 1;
+    dim3 grid((unsigned)((workers + WS_WAVES - 1) / WS_WAVES), (unsigned)jobs, 1);
+    hipLaunchKernelGGL(wgrad_slide_kernel, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

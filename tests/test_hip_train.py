@@ -344,3 +344,23 @@ def test_site_backward_vs_torch_autograd(dev, kind, cin, cout, k, stride, pad, d
     chk(bw.pg[id(conv.weight)], c64.weight.grad, "dw")
     chk(bw.pg[id(bn.weight)], b64.weight.grad, "dgamma")
     chk(bw.pg[id(bn.bias)], b64.bias.grad, "dbeta")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 28, 28, 48, 0, 112, 112), (1, 6, 5, 7, 24, -24, 20, 28), (2, 3, 9, 11, 12, 0, 33, 41)])
+def test_upsample_softargmin_backward_vs_oracle_autograd(dev, shape):
+    """d disp / d cost of the fused trilinear(align_corners) + softmax + soft-argmin head (stackhourglass.py:169-173) vs torch
+    autograd of the oracle in fp64, incl. output sizes that are not multiples of the kernel's 8 x 16 pixel tiles."""
+    from disprcnn_amd import _lib, engine as E
+    n, dp, hp, wp, ndisp, mn, H, W = shape
+    cost = synth.hash_uniform(f"sab{shape}", (n, dp, hp, wp), -2.0, 2.0)
+    gd = synth.hash_uniform(f"sabg{shape}", (n, H, W), -1.0, 1.0)
+    c64 = cost.double().requires_grad_(True)
+    pred = O.upsample_softargmin(c64.unsqueeze(1), mn + ndisp, mn, H, W)
+    (pred * gd.double()).sum().backward()
+    g = torch.zeros(n, dp, hp, wp, device=dev)
+    cost_d, gd_d = cost.to(dev), gd.to(dev)                      # keep the device tensors alive across the launch
+    st = _lib.lib().drc_upsample_softargmin_bwd(E._ptr(cost_d), E._ptr(gd_d), E._ptr(g), n, dp, hp, wp, ndisp, H, W, mn,
+                                                E._stream_ptr(dev))
+    _lib.check(st, "drc_upsample_softargmin_bwd")
+    ref = c64.grad
+    assert (g.cpu().double() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7
