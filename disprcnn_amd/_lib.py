@@ -62,6 +62,7 @@ _SIGS = {
     "drc_blocked_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_tapconv_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_tapconv3d_slide_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_tapconv3d_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_deconv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv2d_k1_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),

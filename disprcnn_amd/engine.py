@@ -16,7 +16,7 @@ SLACK_FLOATS = 1 << 16          # over-read room behind every blocked tensor (ra
 LDS_PER_WAVE_MAX = 38 * 1024    # 4 waves/block -> 152 KiB of the 160 KiB LDS
 MAX_SLOTS = 112                 # 7 voxel tiles of 16
 TIMING = None                   # bench.py sets this to a list to collect (kernel name, flops, start_evt, end_evt)
-SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
+SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1, "min_units": 700}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
 
 
 def _stream_ptr(device):
@@ -131,6 +131,20 @@ def pack_weight_pw(w):
     wp = torch.zeros(cb * CB, cout_pad, dtype=torch.float32, device=w.device)
     wp[:cin, :cout] = w.reshape(cout, cin).t()
     return wp.view(cb, CB, cout_pad).permute(0, 2, 1).contiguous()
+
+
+def pack_weight_t16(w, transposed=False):
+    """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) -> [K taps][cb_in][cout_pad][16] fp32 contiguous: the packing of the
+    LDS-free kernels, whose lane (cout, g) reads channels 4g..4g+3 of a 16-channel block as one float4."""
+    if transposed:
+        w = w.transpose(0, 1)
+    cout, cin = w.shape[:2]
+    K = int(math.prod(w.shape[2:]))
+    cb = (cin + CB - 1) // CB
+    cout_pad = (cout + CB - 1) // CB * CB
+    wp = torch.zeros(K, cb * CB, cout_pad, dtype=torch.float32, device=w.device)
+    wp[:, :cin, :cout] = w.reshape(cout, cin, K).permute(2, 1, 0)
+    return wp.view(K, cb, CB, cout_pad).permute(0, 1, 3, 2).contiguous()
 
 
 def pack_conv_weight(w, transposed=False):
@@ -254,6 +268,7 @@ class ConvPlan:
         self.down = False
         self.pointwise = False
         self.tap2d = False
+        self.direct = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -294,13 +309,17 @@ class ConvPlan:
             # (measured cross-over, tools/exp_conv.py)
             self.slide_ct = SLIDE["ct"] if ct % SLIDE["ct"] == 0 else 1
             cols = x.N * (-(-OH // R)) * (-(-OW // WT))
-            if OD < SLIDE["min_od"] or cols * (ct // self.slide_ct) * OD // SLIDE["min_share"] < 700:
+            if OD < SLIDE["min_od"] or cols * (ct // self.slide_ct) * OD // SLIDE["min_share"] < SLIDE["min_units"]:
                 self.slide = False
             else:
                 self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)
 
-    def run(self, x, w, scale, shift, y, res=None, relu=None):
+    def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
         p = self.p
+        if self.direct and self.slide:
+            if w16 is None:
+                raise ValueError("this plan runs the LDS-free kernel: pass w16 = engine.pack_weight_t16(weight)")
+            w = w16
         relu_saved = p.relu
         if relu is not None:
             p.relu = int(relu)
@@ -322,7 +341,10 @@ class ConvPlan:
             e0.record(torch.cuda.current_stream(self.device))
         if (w.dim() == 3) != self.pointwise:
             raise ValueError("weights are not in the packing this plan expects (engine.pack_conv_weight)")
-        if self.pointwise:
+        if self.direct and self.slide:
+            st = _lib.lib().drc_tapconv3d_direct_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_tapconv3d_direct_fwd")
+        elif self.pointwise:
             st = _lib.lib().drc_conv2d_k1_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_conv2d_k1_fwd")
         elif self.tap2d:
@@ -346,6 +368,7 @@ class ConvPlan:
             TIMING.append((self.kname, self.flops, e0, e1))
 
 
+DIRECT = {"enabled": True}    # stride-1 3x3x3 convs through the LDS-free sliding kernel (tapdirect.hip) instead of tapslide.hip
 DOWN = {"enabled": True, "tile": None}     # stride-2 kernel on parity-split tiles (tapdown.hip); "tile" = development override
 
 
@@ -375,6 +398,9 @@ def plan_conv3d(x, y, stride, cout, relu):
     assert (x.pd, x.ph, x.pw) == (1, 1, 1)
     classes = taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
     pl = ConvPlan(x, y, classes, stride, 1, (y.D, y.H, y.W), cout, relu, slide=(stride == 1 and SLIDE["enabled"]))
+    if pl.slide and DIRECT["enabled"]:
+        pl.direct = True
+        pl.kname = pl.kname.replace("tapslide", "tapdirect")
     if stride == 2 and DOWN["enabled"]:
         pl.down = True
         pl.p.R, pl.p.WT = choose_tile_down(y.H, y.W)

@@ -19,6 +19,8 @@ class _Conv:
         self.cout = w.shape[1] if transposed else w.shape[0]
         self.cin = w.shape[0] if transposed else w.shape[1]
         self.w = E.pack_conv_weight(w, transposed)
+        # stride-1 3x3x3 layers may run on the LDS-free kernel, which reads weights in its own packing
+        self.w16 = E.pack_weight_t16(w) if (w.dim() == 5 and not transposed and tuple(conv.stride) == (1, 1, 1)) else None
         cout_pad = E.cout_pad_of(self.cout)
         self.bn = bn
         self.unit_scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
@@ -100,7 +102,7 @@ class PSMNetRuntime:
         pl = p[plan]
         rs = t[res] if res else None
         if not self._training or c.bn is None:
-            pl.run(t[x], c.w, c.scale, c.shift, t[y], rs)
+            pl.run(t[x], c.w, c.scale, c.shift, t[y], rs, w16=c.w16)
             if self._training and self._tape is not None:        # BN-less conv (lastconv.2): still a site of the reverse pass
                 self._tape.append(("site", ws, plan, wname, x, y, res))
             return
@@ -109,7 +111,7 @@ class PSMNetRuntime:
         if raw is None:
             raw = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
             ws["raw"][plan] = raw
-        pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False)
+        pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False, w16=c.w16)
         mean, var, M = E.bn_batch_stats(raw)
         invstd = torch.rsqrt(var + c.bn.eps)
         bn = c.bn

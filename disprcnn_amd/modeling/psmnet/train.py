@@ -118,6 +118,7 @@ class RegressorBackward:
                     pl = E.plan_conv2d(g_out, g_in, k, 1, dil * (k - 1) - pad_fwd, dil, c.cin, False)
             ent = dict(plan=pl)
             cache[plan_name] = ent
+        w16 = None
         if deconv:
             wp = E.pack_weight(wt)
         elif stride == 2:
@@ -125,8 +126,10 @@ class RegressorBackward:
         else:
             wtf = wt.transpose(0, 1).flip(*range(2, wt.dim())).contiguous()
             wp = E.pack_weight_pw(wtf) if ent["plan"].pointwise else E.pack_weight(wtf)
+            if ent["plan"].direct and ent["plan"].slide:
+                w16 = E.pack_weight_t16(wtf)
         cp = ent["plan"].p.cout_pad
-        return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev)
+        return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev), w16
 
     _x_of = {}
 
@@ -182,11 +185,11 @@ class RegressorBackward:
         # data gradient into grads[x]
         if need_dx:
             gx = G.get(x)
-            pl, wp, ones, zeros = self._dgrad(plan, c, draw, gx)
+            pl, wp, ones, zeros, w16 = self._dgrad(plan, c, draw, gx)
             first = x not in G.have
             if first and pl.p.out_mul == 2 and pl.p.n_classes < (8 if gx.pd > 0 else 4):
                 gx.storage.zero_()                                               # k=1 stride-2: odd positions get no tap
-            pl.run(draw, wp, ones, zeros, gx, None if first else gx)
+            pl.run(draw, wp, ones, zeros, gx, None if first else gx, w16=w16)
             G.have.add(x)
 
     def run(self, tape, gpreds, costs, mx, mn, out_hw):

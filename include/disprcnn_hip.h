@@ -120,6 +120,12 @@ int drc_tapconv_fwd(const drc_tapconv_params* p, void* stream);
  * lds_bytes_per_wave >= 2*(R+2)*(WT+2)*32.  cout_tiles_per_wave in {1,2} must divide cout_pad/16. */
 int drc_tapconv3d_slide_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* The same stride-1 3x3x3 convolution with the same sliding depth window, but with both MFMA operands read straight from
+ * global memory (no LDS): the B fragment of tap (kh,kw) is one coalesced float4 per lane (16 channels = four MFMA k-steps).
+ * Weights are packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16), NOT in the tap layout of drc_tapconv_fwd;
+ * R, WT as for drc_tapconv3d_slide_fwd (lds_bytes_per_wave is ignored). */
+int drc_tapconv3d_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* ConvTranspose3d(k3, s2, p1, op1) (+BN, +residual, +ReLU) -- hourglass.conv5/conv6 (stackhourglass.py:22-30) and the data
  * gradient of the stride-2 Conv3d layers -- with the 8 output-parity classes fused: a wave stages an (R+1) x (WT+1) tile
  * of input slices i and i+1 once per 8-channel phase and runs all 27 taps on it.  Takes the same parameter block as

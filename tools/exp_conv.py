@@ -16,14 +16,15 @@ def run(N, cin, cout, dims, stride=1, deconv=False, reps=20):
     plan = E.plan_deconv3d(x, y, cout, True) if deconv else E.plan_conv3d(x, y, stride, cout, True)
     w = torch.randn((cin, cout, 3, 3, 3) if deconv else (cout, cin, 3, 3, 3), device=dev) * 0.05
     wp = E.pack_weight(w, deconv)
+    w16 = E.pack_weight_t16(w, deconv) if plan.direct else None
     sc = torch.ones(wp.shape[3], device=dev); sh = torch.zeros(wp.shape[3], device=dev)
     for _ in range(3):
-        plan.run(x, wp, sc, sh, y)
+        plan.run(x, wp, sc, sh, y, w16=w16)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        plan.run(x, wp, sc, sh, y)
+        plan.run(x, wp, sc, sh, y, w16=w16)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"{os.environ.get('DRC_LIB','default').split('/')[-1]:28s} N={N} {cin}->{cout} {dims} s{stride} dc={deconv} {plan.kname} R={plan.p.R} WT={plan.p.WT}: {us:8.1f} us  {plan.flops/us/1e6:6.1f} TF")
@@ -45,6 +46,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if os.environ.get("MAX_SLOTS"):
         E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
+    if os.environ.get("DIRECT"):
+        E.DIRECT["enabled"] = os.environ["DIRECT"] != "0"
     if os.environ.get("SLIDE_MIN_OD"):
         E.SLIDE["min_od"] = int(os.environ["SLIDE_MIN_OD"]); E.SLIDE["min_share"] = 1
     if os.environ.get("SLIDE_CT"):
