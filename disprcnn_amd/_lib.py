@@ -65,6 +65,7 @@ _SIGS = {
     "drc_tapconv3d_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_deconv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv2d_k1_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv2d_k3_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_cout1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

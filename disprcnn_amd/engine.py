@@ -316,7 +316,7 @@ class ConvPlan:
 
     def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
         p = self.p
-        if self.direct and self.slide:
+        if self.direct and (self.slide or self.down):
             if w16 is None:
                 raise ValueError("this plan runs the LDS-free kernel: pass w16 = engine.pack_weight_t16(weight)")
             w = w16
@@ -341,7 +341,10 @@ class ConvPlan:
             e0.record(torch.cuda.current_stream(self.device))
         if (w.dim() == 3) != self.pointwise:
             raise ValueError("weights are not in the packing this plan expects (engine.pack_conv_weight)")
-        if self.direct and self.slide:
+        if self.direct and self.down:
+            st = _lib.lib().drc_conv3d_k3s2_direct_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv3d_k3s2_direct_fwd")
+        elif self.direct and self.slide:
             st = _lib.lib().drc_tapconv3d_direct_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_tapconv3d_direct_fwd")
         elif self.pointwise:
@@ -369,7 +372,7 @@ class ConvPlan:
 
 
 DIRECT = {"enabled": True}    # stride-1 3x3x3 convs through the LDS-free sliding kernel (tapdirect.hip) instead of tapslide.hip
-DOWN = {"enabled": True, "tile": None}     # stride-2 kernel on parity-split tiles (tapdown.hip); "tile" = development override
+DOWN = {"enabled": True, "tile": None, "min_groups": 700}   # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured, tools/exp_conv.py)     # stride-2 kernel on parity-split tiles (tapdown.hip); "tile" = development override
 
 
 def choose_tile_down(OH, OW):
@@ -408,10 +411,13 @@ def plan_conv3d(x, y, stride, cout, relu):
         ct = pl.p.cout_pad // 16
         tiles = x.N * y.D * (-(-y.H // pl.p.R)) * (-(-y.W // pl.p.WT))
         CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
-        while CT > 1 and (nvt * CT > 28 or tiles * (ct // CT) < 2048):     # keep >= 2 groups per SIMD
+        while CT > 1 and (nvt * CT > 28 or tiles * (ct // CT) < DOWN["min_groups"]):
             CT //= 2
         pl.down_ct = CT
         pl.kname = "tapdown_kernel<%d,%d>" % (nvt, CT)
+        if DIRECT["enabled"] and DIRECT.get("down", True):
+            pl.direct = True
+            pl.kname = "downdirect_kernel<%d,%d>" % (nvt, CT)
     return pl
 
 

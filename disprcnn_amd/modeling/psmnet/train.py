@@ -121,6 +121,8 @@ class RegressorBackward:
         w16 = None
         if deconv:
             wp = E.pack_weight(wt)
+            if ent["plan"].direct and ent["plan"].down:
+                w16 = E.pack_weight_t16(wt)
         elif stride == 2:
             wp = E.pack_weight(wt, transposed=True)
         else:

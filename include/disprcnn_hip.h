@@ -141,6 +141,10 @@ int drc_deconv3d_k3s2_fwd(const drc_tapconv_params* p, void* stream);
  * cout_pad/16; ceil(R*WT/16) * cout_tiles_per_wave <= 28; the tile's four planes must fit 18 LDS-DMA pieces. */
 int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* drc_conv3d_k3s2_fwd with both MFMA operands read straight from global memory (no LDS): the stride only changes the
+ * per-lane address of the float4 B fragment.  Weights packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16). */
+int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* Conv2d(k3, stride 1, dilation d, pad d) (+BN/bias, +residual, +ReLU): the 3x3 convolutions of the PSMNet feature CNN
  * (submodule.py:60-139) and of ResNet-50-FPN, with the wait protocol of drc_conv3d_k3s2_fwd (dense LDS-DMA tile, static piece
  * count, uncounted weight loads, two waves per SIMD).  Parameter block of drc_tapconv_fwd for the single 1x3x3 class

@@ -48,6 +48,10 @@ if __name__ == "__main__":
         E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
     if os.environ.get("DIRECT"):
         E.DIRECT["enabled"] = os.environ["DIRECT"] != "0"
+    if os.environ.get("DN_MIN_GROUPS"):
+        E.DOWN["min_groups"] = int(os.environ["DN_MIN_GROUPS"])
+    if os.environ.get("DIRECT_DOWN"):
+        E.DIRECT["down"] = os.environ["DIRECT_DOWN"] != "0"
     if os.environ.get("SLIDE_MIN_OD"):
         E.SLIDE["min_od"] = int(os.environ["SLIDE_MIN_OD"]); E.SLIDE["min_share"] = 1
     if os.environ.get("SLIDE_CT"):
