@@ -68,6 +68,7 @@ _SIGS = {
     "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv2d_k1_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv2d_k3_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_conv2d_k3_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_cout1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drc_upsample_softargmin_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_avgpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -1,7 +1,8 @@
-// downdirect.hip -- Conv3d(k3, stride 2, pad 1) (+BN, +residual, +ReLU) with both MFMA operands read straight from global
-// memory (no LDS) (gfx950 / CDNA4).
+// downdirect.hip -- Conv3d(k3, stride 2, pad 1) and Conv2d(k3, stride 1|2, dilation d) (+BN/bias, +residual, +ReLU) with both
+// MFMA operands read straight from global memory (no LDS) (gfx950 / CDNA4).
 //
-//   reference: hourglass.conv1 / conv3 (stackhourglass.py:9-16) and the data gradient of the ConvTranspose3d layers.
+//   reference: hourglass.conv1 / conv3 (stackhourglass.py:9-16) and the data gradient of the ConvTranspose3d layers; the 3x3
+//   convolutions of the PSMNet feature CNN (submodule.py:60-139) and of ResNet-50-FPN (backbone/resnet.py, backbone/fpn.py).
 //
 // Operand scheme of tapdirect.hip: in the blocked layout the B fragment of tap (kd, kh, kw) is one float4 per lane -- lane
 // (output voxel j, g) reads channels 4g..4g+3 of input voxel (2od+kd, 2oh+kh, 2ow+kw) -- and covers four MFMA k-steps; the
@@ -9,7 +10,8 @@
 // variants had to de-interleave parity planes (tapdown.hip) or eat 4-way bank conflicts (tapconv.hip).  A wave owns R x WT
 // output voxels of one output slice and CT*16 output channels (all 64 channels of the hourglass layers in one wave) and walks
 // (channel block, kd, tap) with the next step's VT + CT loads in flight: 11 loads per 112 MFMAs at VT = 7, CT = 4.
-// Weights: [27][cb_in][cout_pad][16] (engine.pack_weight_t16).
+// The 2D instantiation (DIM3 = false) drops the depth taps and takes stride and dilation from the parameter block.
+// Weights: [27 | 9][cb_in][cout_pad][16] (engine.pack_weight_t16).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int VT, int CT>
+template <int VT, int CT, bool DIM3>
 __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tapconv_params p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -50,7 +52,9 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
         vr[vt] = s < nslots ? r : -1; vc[vt] = c;
     }
     const int64_t w_cb = (int64_t)p.cout_pad * 16, w_tap = w_cb * p.cb_in;
-    const int steps = p.cb_in * 27;                  // per group: (cb outer, kd, kh, kw)
+    constexpr int NT = DIM3 ? 27 : 9;                // taps per channel block
+    const int steps = p.cb_in * NT;                  // per group: (cb outer, kd, kh, kw)
+    const int str = p.in_mul, dil = p.cls[0].sh;     // stride; tap spacing (dilation), same in h and w
 
     struct Group { int n, od, oh0, ow0, ct0, nr, nc; const float* base; };
     auto decode = [&](long gidx) __attribute__((always_inline)) -> Group {
@@ -63,8 +67,8 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
         q.oh0 = rt * p.R; q.ow0 = wt * p.WT;
         q.nr = OH - q.oh0 < p.R ? OH - q.oh0 : p.R;
         q.nc = OW - q.ow0 < p.WT ? OW - q.ow0 : p.WT;
-        q.base = p.x + (int64_t)q.n * p.x_n_stride + (int64_t)(2 * q.od + p.cls[0].dd0) * p.x_d_stride +
-                 (int64_t)(2 * q.oh0 + p.cls[0].dh0) * p.x_h_stride + (int64_t)(2 * q.ow0 + p.cls[0].dw0) * 16;
+        q.base = p.x + (int64_t)q.n * p.x_n_stride + (int64_t)(str * q.od + p.cls[0].dd0) * p.x_d_stride +
+                 (int64_t)(str * q.oh0 + p.cls[0].dh0) * p.x_h_stride + (int64_t)(str * q.ow0 + p.cls[0].dw0) * 16;
         return q;
     };
     unsigned lane_vo[VT];
@@ -74,14 +78,15 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
             int r = vr[vt] < 0 ? 0 : vr[vt], c = vc[vt];
             r = r < G.nr ? r : G.nr - 1;
             c = c < G.nc ? c : G.nc - 1;
-            lane_vo[vt] = (unsigned)((2 * r * (int)p.x_h_stride + 2 * c * 16 + g * 4) * 4);
+            lane_vo[vt] = (unsigned)((str * r * (int)p.x_h_stride + str * c * 16 + g * 4) * 4);
         }
     };
-    // operands of step s (cb = s / 27, tap = s % 27) of group G
+    // operands of step s (cb = s / NT, tap = s % NT) of group G
     auto load_step = [&](f32x4 (&B)[VT], f32x4 (&Wt)[CT], const Group& G, const unsigned (&vo)[VT], int s) __attribute__((always_inline)) {
-        const int cb = s / 27, t = s - cb * 27;
-        const int kd = t / 9, kh = (t - kd * 9) / 3, kw = t - kd * 9 - kh * 3;
-        const char* sb = (const char*)(G.base + (int64_t)cb * p.x_cb_stride + (int64_t)kd * p.x_d_stride + (int64_t)kh * p.x_h_stride + kw * 16);
+        const int cb = s / NT, t = s - cb * NT;
+        const int kd = DIM3 ? t / 9 : 0, kh = (t - kd * 9) / 3, kw = t - kd * 9 - kh * 3;
+        const char* sb = (const char*)(G.base + (int64_t)cb * p.x_cb_stride + (int64_t)kd * p.x_d_stride + (int64_t)(kh * dil) * p.x_h_stride +
+                                       kw * dil * 16);
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) B[vt] = *(const f32x4*)(sb + vo[vt]);
         const char* wsb = (const char*)(p.w + (int64_t)t * w_tap + (int64_t)cb * w_cb);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
                 int r = vr[vt] < 0 ? 0 : vr[vt], c = vc[vt];
                 r = r < nxg.nr ? r : nxg.nr - 1;
                 c = c < nxg.nc ? c : nxg.nc - 1;
-                nvo[vt] = (unsigned)((2 * r * (int)p.x_h_stride + 2 * c * 16 + g * 4) * 4);
+                nvo[vt] = (unsigned)((str * r * (int)p.x_h_stride + str * c * 16 + g * 4) * 4);
             }
         }
         if (s == steps - 2) {
@@ -189,32 +194,32 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
 #undef DW_CLEAR_ACC
 }
 
-template <int VT, int CT>
+template <int VT, int CT, bool DIM3>
 int launch(const drc_tapconv_params& p, hipStream_t stream) {
     static int occ_blocks = 0;
     if (!occ_blocks) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, downdirect_kernel<VT, CT>, 64 * DW_WAVES, 0) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, downdirect_kernel<VT, CT, DIM3>, 64 * DW_WAVES, 0) != hipSuccess || nb < 1) nb = 1;
         occ_blocks = nb;
     }
     const long groups = (long)(p.cout_pad / 16 / CT) * p.N * p.OD * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
     long workers = 256L * DW_WAVES * occ_blocks;
     if (workers > groups) workers = groups;
     dim3 grid((unsigned)((workers + DW_WAVES - 1) / DW_WAVES), 1, 1);
-    hipLaunchKernelGGL((downdirect_kernel<VT, CT>), grid, dim3(64 * DW_WAVES), 0, stream, p);
+    hipLaunchKernelGGL((downdirect_kernel<VT, CT, DIM3>), grid, dim3(64 * DW_WAVES), 0, stream, p);
     return (int)hipGetLastError();
 }
 
-template <int CT>
+template <int CT, bool DIM3>
 int launch_vt(int nvt, const drc_tapconv_params& p, hipStream_t s) {
     switch (nvt) {
-        case 1: return launch<1, CT>(p, s);
-        case 2: return launch<2, CT>(p, s);
-        case 3: return launch<3, CT>(p, s);
-        case 4: return launch<4, CT>(p, s);
-        case 5: return launch<5, CT>(p, s);
-        case 6: return launch<6, CT>(p, s);
-        case 7: return launch<7, CT>(p, s);
+        case 1: return launch<1, CT, DIM3>(p, s);
+        case 2: return launch<2, CT, DIM3>(p, s);
+        case 3: return launch<3, CT, DIM3>(p, s);
+        case 4: return launch<4, CT, DIM3>(p, s);
+        case 5: return launch<5, CT, DIM3>(p, s);
+        case 6: return launch<6, CT, DIM3>(p, s);
+        case 7: return launch<7, CT, DIM3>(p, s);
     }
     return -3;
 }
@@ -239,5 +244,26 @@ extern "C" int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* pp, int cout
     const int nvt = (p.R * p.WT + 15) / 16;
     if (nvt * CT > 28) return -3;
     hipStream_t s = (hipStream_t)stream;
-    return CT == 4 ? launch_vt<4>(nvt, p, s) : CT == 2 ? launch_vt<2>(nvt, p, s) : launch_vt<1>(nvt, p, s);
+    return CT == 4 ? launch_vt<4, true>(nvt, p, s) : CT == 2 ? launch_vt<2, true>(nvt, p, s) : launch_vt<1, true>(nvt, p, s);
+}
+
+extern "C" int drc_conv2d_k3_direct_fwd(const drc_tapconv_params* pp, int cout_tiles_per_wave, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD != 1 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
+    const drc_tap_class& k = p.cls[0];
+    if (p.n_classes != 1 || (p.in_mul != 1 && p.in_mul != 2) || p.out_mul != 1 || k.nd != 1 || k.nh != 3 || k.nw != 3 || k.sh < 1 ||
+        k.sh != k.sw || k.wbase != 0 || k.wsh != 3 || k.wsw != 1)
+        return -4;
+    if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 112) return -3;
+    if ((int64_t)(p.in_mul * p.R + 2 * k.sh + 1) * p.x_h_stride * 4 >= (1LL << 31)) return -5;   // 32-bit lane offsets
+    const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;
+    if ((CT != 1 && CT != 2 && CT != 4) || ct % CT) return -2;
+    const int nvt = (p.R * p.WT + 15) / 16;
+    if (nvt * CT > 28) return -3;
+    hipStream_t s = (hipStream_t)stream;
+    return CT == 4 ? launch_vt<4, false>(nvt, p, s) : CT == 2 ? launch_vt<2, false>(nvt, p, s) : launch_vt<1, false>(nvt, p, s);
 }

@@ -269,6 +269,7 @@ class ConvPlan:
         self.pointwise = False
         self.tap2d = False
         self.direct = False
+        self.c2d = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -316,7 +317,7 @@ class ConvPlan:
 
     def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
         p = self.p
-        if self.direct and (self.slide or self.down):
+        if self.direct and (self.slide or self.down or self.c2d):
             if w16 is None:
                 raise ValueError("this plan runs the LDS-free kernel: pass w16 = engine.pack_weight_t16(weight)")
             w = w16
@@ -341,7 +342,10 @@ class ConvPlan:
             e0.record(torch.cuda.current_stream(self.device))
         if (w.dim() == 3) != self.pointwise:
             raise ValueError("weights are not in the packing this plan expects (engine.pack_conv_weight)")
-        if self.direct and self.down:
+        if self.direct and self.c2d:
+            st = _lib.lib().drc_conv2d_k3_direct_fwd(C.byref(p), self.c2d_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv2d_k3_direct_fwd")
+        elif self.direct and self.down:
             st = _lib.lib().drc_conv3d_k3s2_direct_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_direct_fwd")
         elif self.direct and self.slide:
@@ -484,7 +488,27 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
     assert x.pd == 0 and x.D == 1
     classes = taps_conv((1, k, k), (1, dilation, dilation), (0, pad, pad), (0, x.ph, x.pw))
     pl = ConvPlan(x, y, classes, stride, 1, (1, y.H, y.W), cout, relu)
-    if k == 3 and stride == 1 and pad == dilation and TAP2D["enabled"]:
+    if k == 3 and DIRECT["enabled"] and DIRECT.get("conv2d", True):
+        # LDS-free kernel: any stride (1|2) and dilation; the tile only has to give full voxel tiles
+        best = None
+        for r in range(1, min(y.H, MAX_SLOTS) + 1):
+            for wt in range(1, min(y.W, MAX_SLOTS // r) + 1):
+                nvt_ = -(-(r * wt) // 16)
+                waste = (-(-y.H // r)) * (-(-y.W // wt)) * nvt_ * 16 / (y.H * y.W)
+                key = (-round(waste, 2), r * wt, wt)
+                if best is None or key > best[0]:
+                    best = (key, r, wt)
+        pl.c2d, pl.direct = True, True
+        pl.p.R, pl.p.WT = best[1], best[2]
+        nvt = -(-(best[1] * best[2]) // 16)
+        ct = pl.p.cout_pad // 16
+        tiles = x.N * (-(-y.H // best[1])) * (-(-y.W // best[2]))
+        CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
+        while CT > 1 and (nvt * CT > 28 or tiles * (ct // CT) < 700):
+            CT //= 2
+        pl.c2d_ct = CT
+        pl.kname = "conv2ddirect_kernel<%d,%d>" % (nvt, CT)
+    elif k == 3 and stride == 1 and pad == dilation and TAP2D["enabled"]:
         tile = choose_tile_2d(y.H, y.W, dilation)
         if tile is not None:
             pl.tap2d = True

@@ -10,6 +10,7 @@ class _Site:
     def __init__(self, conv, bn, device):
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
         self.w = E.pack_conv_weight(w)
+        self.w16 = E.pack_weight_t16(w) if tuple(w.shape[2:]) == (3, 3) else None      # 3x3 layers: LDS-free kernel's packing
         cp = E.cout_pad_of(w.shape[0])
         if bn is not None:
             self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
@@ -131,7 +132,7 @@ class BackboneRuntime:
 
         def conv(plan, x_, y_, res=None):
             c = Wt[plan]
-            p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None)
+            p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None, w16=c.w16)
 
         t["img"].from_dense(x)
         conv("stem", "img", "stem")

@@ -19,8 +19,9 @@ class _Conv:
         self.cout = w.shape[1] if transposed else w.shape[0]
         self.cin = w.shape[0] if transposed else w.shape[1]
         self.w = E.pack_conv_weight(w, transposed)
-        # the 3x3x3 Conv3d layers (stride 1 and 2) run on the LDS-free kernels, which read weights in their own packing
-        self.w16 = E.pack_weight_t16(w) if (w.dim() == 5 and not transposed) else None
+        # the 3x3x3 Conv3d layers (stride 1 and 2) and the 3x3 Conv2d layers run on the LDS-free kernels, which read weights in
+        # their own packing
+        self.w16 = E.pack_weight_t16(w) if ((w.dim() == 5 and not transposed) or (w.dim() == 4 and tuple(w.shape[2:]) == (3, 3))) else None
         cout_pad = E.cout_pad_of(self.cout)
         self.bn = bn
         self.unit_scale = torch.ones(cout_pad, dtype=torch.float32, device=device)

@@ -128,7 +128,7 @@ class RegressorBackward:
         else:
             wtf = wt.transpose(0, 1).flip(*range(2, wt.dim())).contiguous()
             wp = E.pack_weight_pw(wtf) if ent["plan"].pointwise else E.pack_weight(wtf)
-            if ent["plan"].direct and ent["plan"].slide:
+            if ent["plan"].direct and (ent["plan"].slide or ent["plan"].c2d):
                 w16 = E.pack_weight_t16(wtf)
         cp = ent["plan"].p.cout_pad
         return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev), w16

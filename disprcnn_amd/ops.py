@@ -89,6 +89,6 @@ def conv2d_bn(x, weight, scale, shift, stride=1, pad=1, dilation=1, relu=False, 
     cp = E.cout_pad_of(cout)
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale; sh[:cout] = shift
-    w16 = E.pack_weight_t16(weight.to(dev).float(), transposed) if plan.direct else None
+    w16 = E.pack_weight_t16(weight.to(dev).float()) if plan.direct else None
     plan.run(xb, wp, sc, sh, yb, rb, w16=w16)
     return yb.to_dense()[:, :, 0]

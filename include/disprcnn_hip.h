@@ -151,6 +151,11 @@ int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_w
  * (OD = 1, tap spacing = dilation); cout_tiles_per_wave in {1,2,4}; (R+2d)*(WT+2d) voxels must fit 18 LDS-DMA pieces. */
 int drc_conv2d_k3_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* Conv2d(k3, stride 1 or 2, dilation d) (+BN/bias, +residual, +ReLU) with both MFMA operands read straight from global memory
+ * (the 2D instantiation of drc_conv3d_k3s2_direct_fwd; stride = in_mul, dilation = tap spacing of the class).  Weights packed
+ * [9][cb_in][cout_pad][16] (engine.pack_weight_t16). */
+int drc_conv2d_k3_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* Conv2d(k1, stride 1 or 2, pad 0) (+BN/bias, +residual, +ReLU) as a register-blocked MFMA GEMM with both operands read
  * straight from global memory (no LDS): the 1x1 convolutions of ResNet-50-FPN (backbone/resnet.py, backbone/fpn.py) and of the
  * PSMNet feature CNN (submodule.py).  Parameter block of drc_tapconv_fwd for the single 1x1 class (OD = 1); the weights are
