@@ -142,6 +142,32 @@ def test_conv3d_direct_kernel_vs_oracle(dev, cin, cout, dims):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("kind,cin,cout,stride,dims", [("3d", 32, 32, 1, (6, 28, 28)), ("3d", 64, 32, 1, (4, 12, 28)), ("3d", 32, 64, 2, (12, 28, 28)),
+                                                       ("3d", 16, 48, 2, (6, 10, 18)), ("2d", 32, 32, 1, (40, 56)), ("2d", 128, 128, 1, (28, 28))])
+def test_lds_staged_variants_vs_oracle(dev, kind, cin, cout, stride, dims):
+    """The LDS-staged kernels (tapslide / tapdown / tap2d: LDS-DMA tiles, explicit waits) stay selectable with
+    engine.DIRECT['enabled'] = False; same layers, same tolerance as the default LDS-free kernels."""
+    from disprcnn_amd import ops, engine as E
+    n = 2
+    x = synth.hash_uniform(f"V{kind}{cin}{cout}{stride}:x", (n, cin) + dims)
+    w = synth.hash_uniform(f"V{kind}{cin}{cout}:w", (cout, cin) + (3,) * len(dims), -0.1, 0.1)
+    scale = synth.hash_uniform("V:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("V:b", (cout,), -0.5, 0.5)
+    bc = (1, -1) + (1,) * len(dims)
+    saved = (E.DIRECT["enabled"], E.SLIDE["min_units"])
+    E.DIRECT["enabled"], E.SLIDE["min_units"] = False, 1
+    try:
+        if kind == "3d":
+            ref = F.relu(F.conv3d(x, w, None, stride, 1) * scale.view(bc) + shift.view(bc))
+            got = ops.conv3d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, True, None)
+        else:
+            ref = F.relu(F.conv2d(x, w, None, stride, 1) * scale.view(bc) + shift.view(bc))
+            got = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, 1, 1, True, None)
+    finally:
+        E.DIRECT["enabled"], E.SLIDE["min_units"] = saved
+    _close(got, ref)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [(3, 32, 3, 2, 1, 1, (64, 80)), (32, 32, 3, 1, 1, 1, (40, 56)),
                                                          (32, 64, 1, 2, 0, 1, (40, 56)), (128, 128, 3, 1, 2, 2, (28, 28)),
                                                          (320, 128, 3, 1, 1, 1, (12, 20)), (128, 32, 1, 1, 0, 1, (3, 3)),
