@@ -80,7 +80,7 @@ _SIGS = {
     "drc_roi_align_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "drc_roi_align_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "drc_align_roi_pairs": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P, _P]),
+    "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P]),
     "drc_bn_apply_blocked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "drc_tapconv_wgrad": (_I, [C.POINTER(DrcWgradParams), _P]),
     "drc_bilinear_up_blocked_bwd": (_I, [_P, _P, _P, _P, _P]),

@@ -38,4 +38,16 @@ __device__ __forceinline__ void walk_rows(const BlkGeom& g, F f) {
     }
 }
 
+// voxels (per channel) that block `bx` of a `nblocks`-block launch visits in walk_rows
+__device__ __forceinline__ float rows_of_block(const BlkGeom& g, int threads, unsigned bx, unsigned nblocks) {
+    const int tpr = g.W * 4;
+    const int rpb = tpr >= threads ? 1 : threads / tpr;
+    const int rows = g.N * g.D * g.H;
+    int chunk = (rows + (int)nblocks - 1) / (int)nblocks;
+    chunk = (chunk + rpb - 1) / rpb * rpb;
+    const long r0 = (long)bx * chunk;
+    long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    return r1 > r0 ? (float)(r1 - r0) * (float)g.W : 0.f;
+}
+
 }  // namespace drc_blk

@@ -104,8 +104,7 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
 // ------------------------------------------------------------------------------------------------------------------
 // Training-mode BatchNorm on blocked tensors (reference: nn.BatchNorm3d/2d inside convbn_3d / convbn, submodule.py:13-22,
 // per-GPU batch statistics, eps 1e-5, momentum 0.1 handled by the caller).
-//   bn_stats   : per-channel sum of (x - shift) and (x - shift)^2 over the interior voxels (two-pass variance: call once
-//                with shift = 0 to get the mean, again with shift = mean for the centred second moment)
+//   bn_stats   : per-channel mean and sum of squared deviations over the interior voxels in one pass (Chan-combined partials)
 //   bn_apply   : y = act( (x - mean) * invstd * gamma + beta (+ res) ), interior only (halos stay zero)
 //   bn_bwd_reduce / bn_bwd_apply : the standard BN backward with the ReLU mask and residual fan-out fused
 namespace {
@@ -113,36 +112,50 @@ namespace {
 using drc_blk::BlkGeom;
 using drc_blk::blk_off;
 
-// grid: (chunks, CB); each block walks a contiguous run of rows of one channel block; thread = float4 quad of a voxel
-__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, BlkGeom g, const float* __restrict__ shift,
-                                                            float* __restrict__ sums /* [2][CB*16] */, float* scratch) {
+// grid: (chunks, CB); each block walks a contiguous run of rows of one channel block; thread = float4 quad of a voxel.
+// One pass: every thread sums (x - x0) and (x - x0)^2 around its own first value x0, turns that into (count, mean, M2) and the
+// statistics are merged pairwise (Chan) lane -> wave -> block -> launch, all in a fixed order.
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ x, BlkGeom g, float* __restrict__ out /* [2][CB*16]: mean, M2 */,
+                                                            float* scratch) {
     const int cb = blockIdx.y;
-    const int q = threadIdx.x & 3;
-    f32x4_t sh = {0.f, 0.f, 0.f, 0.f};
-    if (shift) sh = *(const f32x4_t*)(shift + cb * 16 + q * 4);
-    f32x4_t s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    drc_blk::walk_rows<kThreads>(g, [&](int n, int dd, int yy, int xx, int qq) {
-        const f32x4_t val = *(const f32x4_t*)(x + blk_off(g, n, cb, dd, yy, xx) + qq * 4) - sh;   // qq == q: W*4 is a multiple of 4
-        s1 += val; s2 += val * val;
+    float n = 0.f;
+    f32x4_t x0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    drc_blk::walk_rows<kThreads>(g, [&](int nn, int dd, int yy, int xx, int qq) {
+        const f32x4_t v = *(const f32x4_t*)(x + blk_off(g, nn, cb, dd, yy, xx) + qq * 4);
+        if (n == 0.f) x0 = v;
+        const f32x4_t d = v - x0;
+        s1 += d; s2 += d * d; n += 1.f;
     });
-    // reduce over the 16 voxel-lanes that share this quad inside the wave, then across waves through LDS
-    float r[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    const float inv = n > 0.f ? 1.f / n : 0.f;
+    float mean[4] = {x0.x + s1.x * inv, x0.y + s1.y * inv, x0.z + s1.z * inv, x0.w + s1.w * inv};
+    float m2[4] = {s2.x - s1.x * s1.x * inv, s2.y - s1.y * s1.y * inv, s2.z - s1.z * s1.z * inv, s2.w - s1.w * s1.w * inv};
+    // merge over the 16 voxel-lanes that share this quad inside the wave
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int m = 4; m < 64; m <<= 1) {
+        const float nb = __shfl_xor(n, m);
 #pragma unroll
-        for (int m = 4; m < 64; m <<= 1) r[k] += __shfl_xor(r[k], m);
-    __shared__ float red[kThreads / 64][4][8];
+        for (int k = 0; k < 4; ++k) {
+            const drc_det::Stat r = drc_det::merge(drc_det::Stat{n, mean[k], m2[k]}, drc_det::Stat{nb, __shfl_xor(mean[k], m), __shfl_xor(m2[k], m)});
+            mean[k] = r.mean; m2[k] = r.m2;
+        }
+        n += nb;
+    }
+    __shared__ float red[kThreads / 64][4][9];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane < 4) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) red[w][lane][k] = r[k];
+        for (int k = 0; k < 4; ++k) { red[w][lane][k] = mean[k]; red[w][lane][4 + k] = m2[k]; }
+        red[w][lane][8] = n;
     }
     __syncthreads();
-    const int qq = (threadIdx.x >> 3) & 3, k = threadIdx.x & 7;
-    float v = 0.f;
-    if (threadIdx.x < 32)
-        for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
-    drc_det::finish(v, cb, g.CB, cb * 16 + qq * 4 + (k & 3), k >> 2, sums, scratch);
+    drc_det::Stat st = {0.f, 0.f, 0.f};
+    if (threadIdx.x < 16) {
+        const int qq = threadIdx.x >> 2, k = threadIdx.x & 3;
+        for (int i = 0; i < kThreads / 64; ++i) st = drc_det::merge(st, drc_det::Stat{red[i][qq][8], red[i][qq][k], red[i][qq][4 + k]});
+    }
+    const BlkGeom gg = g;
+    drc_det::finish_stat(st, cb, g.CB, out, out + g.CB * 16, scratch,
+                         [&](unsigned i) { return drc_blk::rows_of_block(gg, kThreads, i, gridDim.x); });
 }
 
 // grid: (chunks, CB)
@@ -169,17 +182,17 @@ inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[
 
 extern "C" {
 
-int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, float* scratch, void* stream) {
+int drc_bn_stats_blocked(const float* x, const int* geom8, float* stats, float* scratch, void* stream) {
     if (!geom_ok(geom8)) return -2;
     if (geom8[0] == 0) return 0;
-    if (!x || !sums || !scratch) return -1;
+    if (!x || !stats || !scratch) return -1;
     const BlkGeom g = to_geom(geom8);
     const long nvox = (long)g.N * g.D * g.H * g.W;
     long chunks = (nvox + (kThreads / 4) * 8 - 1) / ((kThreads / 4) * 8);
     if (chunks < 1) chunks = 1;
     if (chunks > DRC_BN_MAX_CHUNKS) chunks = DRC_BN_MAX_CHUNKS;
     if (chunks > (long)g.N * g.D * g.H) chunks = (long)g.N * g.D * g.H;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, shift, sums, scratch);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, stats, scratch);
     return (int)hipGetLastError();
 }
 

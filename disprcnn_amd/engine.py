@@ -583,21 +583,14 @@ def bn_scratch(dev, cb):
 
 
 def bn_batch_stats(raw):
-    """Per-channel batch mean and biased variance of a Blocked tensor's interior (two passes: mean, then centred moment)."""
+    """Per-channel batch mean and biased variance of a Blocked tensor's interior (one pass, Chan-combined, fixed order)."""
     dev = raw.device
     C16 = raw.cb * CB
     M = raw.N * raw.D * raw.H * raw.W
-    sums = torch.empty(2, C16, dtype=torch.float32, device=dev)
-    g = _geom8(raw)
-    scratch = _ptr(bn_scratch(dev, raw.cb))
-    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, None, _ptr(sums), scratch, _stream_ptr(dev))
+    stats = torch.empty(2, C16, dtype=torch.float32, device=dev)
+    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), _geom8(raw), _ptr(stats), _ptr(bn_scratch(dev, raw.cb)), _stream_ptr(dev))
     _lib.check(st, "drc_bn_stats_blocked")
-    mean = sums[0] / M
-    sums2 = torch.empty(2, C16, dtype=torch.float32, device=dev)
-    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), g, _ptr(mean), _ptr(sums2), scratch, _stream_ptr(dev))
-    _lib.check(st, "drc_bn_stats_blocked")
-    var = sums2[1] / M
-    return mean.contiguous(), var.contiguous(), M
+    return stats[0], stats[1] / M, M
 
 
 def bn_apply(raw, y, res, mean, invstd, gamma, beta, relu):

@@ -235,15 +235,16 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
  * submodule.py:13-22).  Every `geom` argument of the BatchNorm / SPP-backward entry points is
  * int[10] = {N, CB, D, H, W, pd, ph, pw, cb_total, cb_off}: channel blocks [cb_off, cb_off+CB) of a blocked tensor that
  * has cb_total blocks (a plain tensor has cb_total = CB, cb_off = 0; a concat slice addresses its parent).
- *   drc_bn_stats_blocked : sums[0][c] = sum (x - shift[c]), sums[1][c] = sum (x - shift[c])^2 over interior voxels
- *                          (sums [2][CB*16]; shift may be NULL; two passes give a cancellation-free variance).  The
- *                          cross-block reduction runs in a fixed order, so the statistics (and with them every ReLU mask
- *                          downstream) are bit-reproducible run to run.  `scratch`: DRC_BN_SCRATCH_FLOATS(CB) floats whose
- *                          last CB words (tickets) are zero on entry; they are zero again on exit.  One scratch per stream.
+ *   drc_bn_stats_blocked : stats[0][c] = mean_c, stats[1][c] = sum (x - mean_c)^2 over the interior voxels (stats [2][CB*16]),
+ *                          in ONE pass: per-thread sums around the thread's first value, merged pairwise (Chan) in a fixed
+ *                          order lane -> wave -> block -> launch, so the variance is cancellation-free and the statistics (and
+ *                          with them every ReLU mask downstream) are bit-reproducible run to run.  `scratch`:
+ *                          DRC_BN_SCRATCH_FLOATS(CB) floats whose last CB words (tickets) are zero on entry; they are zero
+ *                          again on exit.  One scratch per stream.
  *   drc_bn_apply_blocked : y = act((x - mean) * invstd * gamma + beta (+ res)), interior only */
 #define DRC_BN_MAX_CHUNKS 512
 #define DRC_BN_SCRATCH_FLOATS(CB) ((size_t)DRC_BN_MAX_CHUNKS * (CB) * 32 + (CB))
-int drc_bn_stats_blocked(const float* x, const int* geom8, const float* shift, float* sums, float* scratch, void* stream);
+int drc_bn_stats_blocked(const float* x, const int* geom8, float* stats, float* scratch, void* stream);
 int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int* geom_y, const float* res, const int* geom_r,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, void* stream);
 
