@@ -72,6 +72,7 @@ _SIGS = {
     "drc_conv3d_cout1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drc_upsample_softargmin_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_avgpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_pack_weights": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "drc_avgpool2d_blocked_slice": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_bilinear_up_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_bilinear_resize_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -81,6 +82,7 @@ _SIGS = {
     "drc_roi_align_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "drc_align_roi_pairs": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P]),
+    "drc_bn_finalize": (_I, [_P, _I, _I, C.c_longlong, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "drc_bn_apply_blocked": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "drc_tapconv_wgrad": (_I, [C.POINTER(DrcWgradParams), _P]),
     "drc_bilinear_up_blocked_bwd": (_I, [_P, _P, _P, _P, _P]),

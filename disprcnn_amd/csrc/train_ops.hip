@@ -175,6 +175,22 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
     });
 }
 
+// one launch instead of ~10 tiny torch kernels per site: invstd = rsqrt(M2/M + eps); running statistics updated like nn.BatchNorm
+// (momentum, UNBIASED batch variance); num_batches_tracked += 1
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C16, int C, float M, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* num_batches_tracked,
+                                   float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C16) return;
+    const float mean = stats[c], var = stats[C16 + c] / M;
+    invstd[c] = rsqrtf(var + eps);
+    if (c < C && running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (M / fmaxf(M - 1.f, 1.f));
+    }
+}
+
 inline bool geom_ok(const int* g) { return g && g[0] >= 0 && g[1] > 0 && g[2] > 0 && g[3] > 0 && g[4] > 0 && g[5] >= 0 && g[6] >= 0 && g[7] >= 0 && g[9] >= 0 && g[9] + g[1] <= g[8]; }
 inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9]}; }
 
@@ -193,6 +209,15 @@ int drc_bn_stats_blocked(const float* x, const int* geom8, float* stats, float* 
     if (chunks > DRC_BN_MAX_CHUNKS) chunks = DRC_BN_MAX_CHUNKS;
     if (chunks > (long)g.N * g.D * g.H) chunks = (long)g.N * g.D * g.H;
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)chunks, (unsigned)g.CB), dim3(kThreads), 0, (hipStream_t)stream, x, g, stats, scratch);
+    return (int)hipGetLastError();
+}
+
+int drc_bn_finalize(const float* stats, int C16, int C, long long count, float eps, float momentum, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float* invstd, void* stream) {
+    if (C16 <= 0 || C < 0 || C > C16 || count <= 0) return -2;
+    if (!stats || !invstd || ((running_mean == nullptr) != (running_var == nullptr))) return -1;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C16 + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, C16, C, (float)count, eps, momentum,
+                       running_mean, running_var, num_batches_tracked, invstd);
     return (int)hipGetLastError();
 }
 

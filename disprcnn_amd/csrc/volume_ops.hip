@@ -449,6 +449,29 @@ inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
 
+// weights [A][B][K] (Conv: A = Cout, B = Cin; ConvTranspose: A = Cin, B = Cout) -> the engine's two packings in one launch,
+// zero-padded to whole channel blocks:  tap [K][cb][2 halves][cout_pad][8]  and  t16 [K][cb][cout_pad][16]
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int K, int transposed, int flip,
+                                                           float* __restrict__ out_tap, float* __restrict__ out_t16) {
+    const int cb_n = (cin + 15) / 16, cout_pad = (cout + 15) / 16 * 16;
+    const long total = (long)K * cb_n * cout_pad * 16;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long t = idx;
+        const int c = (int)(t & 15); t >>= 4;
+        const int co = (int)(t % cout_pad); t /= cout_pad;
+        const int cb = (int)(t % cb_n);
+        const int k = (int)(t / cb_n);
+        const int ci = cb * 16 + c;
+        float v = 0.f;
+        if (co < cout && ci < cin) {
+            const int ks = flip ? K - 1 - k : k;
+            v = transposed ? w[((long)ci * cout + co) * K + ks] : w[((long)co * cin + ci) * K + ks];
+        }
+        if (out_t16) out_t16[idx] = v;
+        if (out_tap) out_tap[((((long)k * cb_n + cb) * 2 + (c >> 3)) * cout_pad + co) * 8 + (c & 7)] = v;
+    }
+}
+
 extern "C" int drc_conv3d_cout1_mfma_try(const float* x, const float* w, const float* res, float* out, int N, int cb_in, int D, int H, int W,
                                          void* stream);   // cout1_mfma.hip
 
@@ -561,6 +584,15 @@ int drc_avgpool2d_blocked(const float* x, float* y, int N, int CB, int H, int W,
     if (blocks == 0) return 0;
     if (!x || !y) return -1;
     hipLaunchKernelGGL(avgpool2d_blocked_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, x, y, N, CB, H, W, px, k, OH, OW, py, CB, 0);
+    return done();
+}
+
+int drc_pack_weights(const float* w, int cout, int cin, int K, int transposed, int flip, float* out_tap, float* out_t16, void* stream) {
+    if (cout <= 0 || cin <= 0 || K <= 0) return -2;
+    if (!w || (!out_tap && !out_t16)) return -1;
+    const long total = (long)K * ((cin + 15) / 16) * ((cout + 15) / 16 * 16) * 16;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, K, transposed, flip,
+                       out_tap, out_t16);
     return done();
 }
 

@@ -99,9 +99,27 @@ def _base_ptr(t):
 
 
 # ------------------------------------------------------------------------------------------- weights
+def pack_layouts(w, transposed=False, flip=False, want_tap=True, want_t16=True):
+    """Both packings of a conv weight in ONE launch (drc_pack_weights): (tap [K][cb][2][cout_pad][8], t16 [K][cb][cout_pad][16]).
+    w: [Cout,Cin,*k] or ConvTranspose [Cin,Cout,*k] on the GPU; flip reverses the taps (data gradients)."""
+    w = w.detach().contiguous().float()
+    a, b = w.shape[:2]
+    cout, cin = (b, a) if transposed else (a, b)
+    K = int(math.prod(w.shape[2:]))
+    cb = (cin + CB - 1) // CB
+    cout_pad = (cout + CB - 1) // CB * CB
+    tap = torch.empty(K, cb, 2, cout_pad, 8, dtype=torch.float32, device=w.device) if want_tap else None
+    t16 = torch.empty(K, cb, cout_pad, 16, dtype=torch.float32, device=w.device) if want_t16 else None
+    st = _lib.lib().drc_pack_weights(_ptr(w), cout, cin, K, int(transposed), int(flip), _ptr(tap), _ptr(t16), _stream_ptr(w.device))
+    _lib.check(st, "drc_pack_weights")
+    return tap, t16
+
+
 def pack_weight(w, transposed=False):
     """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) -> [K][cb_in][2 halves][cout_pad][8] fp32 contiguous
     (shape[3] is cout_pad; channel c of block cb sits in half c//8, slot c%8)."""
+    if w.is_cuda:
+        return pack_layouts(w, transposed, want_t16=False)[0]
     if transposed:
         w = w.transpose(0, 1)
     cout, cin = w.shape[:2]
@@ -125,6 +143,8 @@ def is_pointwise(weight_shape, transposed=False):
 def pack_weight_pw(w):
     """[Cout,Cin,1,1] -> [cb_in][cout_pad][16] fp32 contiguous: lane (cout, g) of the MFMA A operand reads channels 4g..4g+3
     of a 16-channel block as one float4 (1 KiB per 16 couts)."""
+    if w.is_cuda:
+        return pack_layouts(w, want_tap=False)[1][0]
     cout, cin = w.shape[:2]
     cb = (cin + CB - 1) // CB
     cout_pad = (cout + CB - 1) // CB * CB
@@ -136,6 +156,8 @@ def pack_weight_pw(w):
 def pack_weight_t16(w, transposed=False):
     """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) -> [K taps][cb_in][cout_pad][16] fp32 contiguous: the packing of the
     LDS-free kernels, whose lane (cout, g) reads channels 4g..4g+3 of a 16-channel block as one float4."""
+    if w.is_cuda:
+        return pack_layouts(w, transposed, want_tap=False)[1]
     if transposed:
         w = w.transpose(0, 1)
     cout, cin = w.shape[:2]
@@ -591,6 +613,30 @@ def bn_batch_stats(raw):
     st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), _geom8(raw), _ptr(stats), _ptr(bn_scratch(dev, raw.cb)), _stream_ptr(dev))
     _lib.check(st, "drc_bn_stats_blocked")
     return stats[0], stats[1] / M, M
+
+
+def bn_batch_stats_raw(raw):
+    """stats [2][C16] = (mean, sum of squared deviations) of a Blocked tensor's interior, and the voxel count."""
+    dev = raw.device
+    stats = torch.empty(2, raw.cb * CB, dtype=torch.float32, device=dev)
+    st = _lib.lib().drc_bn_stats_blocked(_ptr(raw.storage), _geom8(raw), _ptr(stats), _ptr(bn_scratch(dev, raw.cb)), _stream_ptr(dev))
+    _lib.check(st, "drc_bn_stats_blocked")
+    return stats, raw.N * raw.D * raw.H * raw.W
+
+
+def bn_finalize(stats, count, bn, cout):
+    """invstd from the batch statistics + the module's running-statistics update, one launch (nn.BatchNorm semantics)."""
+    dev = stats.device
+    invstd = torch.empty(stats.shape[1], dtype=torch.float32, device=dev)
+    track = bn.track_running_stats and bn.running_mean is not None
+    st = _lib.lib().drc_bn_finalize(_ptr(stats), stats.shape[1], cout, count, float(bn.eps), float(bn.momentum),
+                                    _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+                                    _ptr(bn.num_batches_tracked) if track else None, _ptr(invstd), _stream_ptr(dev))
+    _lib.check(st, "drc_bn_finalize")
+    if track:   # the kernel wrote the buffers behind torch's back: bump their version counters (BN-fold caches key on them)
+        for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+            torch.autograd.graph.increment_version(t)
+    return invstd
 
 
 def bn_apply(raw, y, res, mean, invstd, gamma, beta, relu):

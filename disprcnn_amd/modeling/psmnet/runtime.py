@@ -18,11 +18,17 @@ class _Conv:
         self.conv, self.transposed = conv, transposed
         self.cout = w.shape[1] if transposed else w.shape[0]
         self.cin = w.shape[0] if transposed else w.shape[1]
-        self.w = E.pack_conv_weight(w, transposed)
         # the 3x3x3 Conv3d layers (stride 1 and 2) and the 3x3 Conv2d layers run on the LDS-free kernels, which read weights in
-        # their own packing
-        self.w16 = E.pack_weight_t16(w) if ((w.dim() == 5 and not transposed) or (w.dim() == 4 and tuple(w.shape[2:]) == (3, 3))) else None
+        # their own packing: both packings come out of one launch
+        need16 = (w.dim() == 5 and not transposed) or (w.dim() == 4 and tuple(w.shape[2:]) == (3, 3))
+        if E.is_pointwise(w.shape, transposed):
+            self.w, self.w16 = E.pack_weight_pw(w), None
+        elif w.is_cuda:
+            self.w, self.w16 = E.pack_layouts(w, transposed, want_t16=need16)
+        else:
+            self.w, self.w16 = E.pack_weight(w, transposed), (E.pack_weight_t16(w) if need16 else None)
         cout_pad = E.cout_pad_of(self.cout)
+        self.cout_pad, self.device = cout_pad, device
         self.bn = bn
         self.unit_scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
         self.zero_shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
@@ -31,13 +37,18 @@ class _Conv:
             self.beta = torch.zeros(cout_pad, dtype=torch.float32, device=device)
             self.gamma[: self.cout] = bn.weight.detach().to(device).float()
             self.beta[: self.cout] = bn.bias.detach().to(device).float()
-        if bn is not None:
-            self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
-                                               bn.running_mean.detach().to(device).float(),
-                                               bn.running_var.detach().to(device).float(), bn.eps, cout_pad)
+            self.scale = self.shift = None          # eval-mode fold: computed on demand (refold), it depends on the running statistics
         else:
             self.scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
             self.shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+
+    def refold(self):
+        """Eval-mode BatchNorm folded into per-cout scale/shift from the module's current running statistics."""
+        bn, device = self.bn, self.device
+        if bn is not None:
+            self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
+                                               bn.running_mean.detach().to(device).float(),
+                                               bn.running_var.detach().to(device).float(), bn.eps, self.cout_pad)
 
 
 class PSMNetRuntime:
@@ -45,6 +56,7 @@ class PSMNetRuntime:
         self.model = model
         self.device = device
         self._weights_version = None
+        self._folds_version = None
         self._w = None
         self._ws = {}      # workspaces: key -> dict of tensors/plans
         self._training = False
@@ -55,12 +67,24 @@ class PSMNetRuntime:
 
     # ------------------------------------------------------------------ weights
     def _version(self):
-        return tuple(t._version for t in list(self.model.parameters()) + list(self.model.buffers())) + \
-            tuple(t.data_ptr() for t in self.model.parameters())
+        return tuple(t._version for t in self.model.parameters()) + tuple(t.data_ptr() for t in self.model.parameters())
+
+    def _buffers_version(self):
+        return tuple(t._version for t in self.model.buffers()) + tuple(t.data_ptr() for t in self.model.buffers())
 
     def _compile(self):
+        """Packed weights are rebuilt when a PARAMETER changed; the eval-mode BatchNorm folds additionally when a buffer (running
+        statistics) changed -- but only when an eval forward needs them: a train step updates the running statistics every
+        time and must not trigger a re-pack."""
         v = self._version()
         if self._w is not None and v == self._weights_version:
+            if not self._training:
+                vb = self._buffers_version()
+                if vb != self._folds_version:
+                    for c in self._w.values():
+                        if isinstance(c, _Conv):
+                            c.refold()
+                    self._folds_version = vb
             return self._w
         m, dev = self.model, self.device
         W = {}
@@ -90,7 +114,12 @@ class PSMNetRuntime:
             cb3(f"fe.{name}", getattr(fe, name)[1])
         cb3("fe.lastconv.0", fe.lastconv[0])
         W["fe.lastconv.2"] = _Conv(fe.lastconv[2], None, dev)
-        self._w, self._weights_version = W, v
+        self._w, self._weights_version, self._folds_version = W, v, None
+        if not self._training:
+            for c in W.values():
+                if isinstance(c, _Conv):
+                    c.refold()
+            self._folds_version = self._buffers_version()
         return W
 
     # ------------------------------------------------------------------ one conv(+BN)(+res)(+ReLU) site
@@ -113,15 +142,22 @@ class PSMNetRuntime:
             raw = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
             ws["raw"][plan] = raw
         pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False, w16=c.w16)
-        mean, var, M = E.bn_batch_stats(raw)
-        invstd = torch.rsqrt(var + c.bn.eps)
         bn = c.bn
-        with torch.no_grad():                                   # running statistics (buffers live on the module)
-            bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            unb = var[: c.cout] * (M / max(M - 1, 1))
-            bn.running_mean.mul_(1 - mom).add_(mean[: c.cout].to(bn.running_mean.device), alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(unb.to(bn.running_var.device), alpha=mom)
+        fused = (bn.momentum is not None and bn.running_mean is not None and bn.running_mean.device == raw.device and
+                 bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous())
+        if fused:
+            stats, M = E.bn_batch_stats_raw(raw)
+            mean = stats[0]
+            invstd = E.bn_finalize(stats, M, bn, c.cout)          # + running statistics (buffers live on the module), one launch
+        else:
+            mean, var, M = E.bn_batch_stats(raw)
+            invstd = torch.rsqrt(var + bn.eps)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                unb = var[: c.cout] * (M / max(M - 1, 1))
+                bn.running_mean.mul_(1 - mom).add_(mean[: c.cout].to(bn.running_mean.device), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(unb.to(bn.running_var.device), alpha=mom)
         relu = bool(pl.p.relu)
         E.bn_apply(raw, yt, rs, mean, invstd, c.gamma, c.beta, relu)     # yt may be a concat slice (geometry carries cb_off)
         ws.setdefault("saved", {})[plan] = (mean, invstd, M)

@@ -118,18 +118,17 @@ class RegressorBackward:
                     pl = E.plan_conv2d(g_out, g_in, k, 1, dil * (k - 1) - pad_fwd, dil, c.cin, False)
             ent = dict(plan=pl)
             cache[plan_name] = ent
-        w16 = None
-        if deconv:
-            wp = E.pack_weight(wt)
-            if ent["plan"].direct and ent["plan"].down:
-                w16 = E.pack_weight_t16(wt)
-        elif stride == 2:
-            wp = E.pack_weight(wt, transposed=True)
-        else:
-            wtf = wt.transpose(0, 1).flip(*range(2, wt.dim())).contiguous()
-            wp = E.pack_weight_pw(wtf) if ent["plan"].pointwise else E.pack_weight(wtf)
-            if ent["plan"].direct and (ent["plan"].slide or ent["plan"].c2d):
-                w16 = E.pack_weight_t16(wtf)
+        # transformed weights, both packings from one launch (drc_pack_weights: in/out swap and tap flip are index arithmetic)
+        pl = ent["plan"]
+        need16 = pl.direct and (pl.slide or pl.down or pl.c2d)
+        if deconv:                      # ConvTranspose weight [Cin,Cout,k] read as Conv[out=Cin, in=Cout]
+            wp, w16 = E.pack_layouts(wt, False, False, want_t16=need16)
+        elif stride == 2:               # Conv weight [Cout,Cin,k] as the transposed conv's [in=Cout, out=Cin]
+            wp, w16 = E.pack_layouts(wt, True, False, want_t16=need16)
+        elif pl.pointwise:              # 1x1: in/out swap only
+            wp, w16 = E.pack_layouts(wt, True, False, want_tap=False)[1][0], None
+        else:                           # stride 1: in/out swap + flipped taps
+            wp, w16 = E.pack_layouts(wt, True, True, want_t16=need16)
         cp = ent["plan"].p.cout_pad
         return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev), w16
 

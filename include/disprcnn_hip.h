@@ -176,6 +176,12 @@ int drc_conv3d_cout1_fwd(const float* x, const float* w, const float* res, float
 int drc_upsample_softargmin_fwd(const float* cost, float* disp, int N, int Dp, int Hp, int Wp,
                                 int D, int H, int W, int mindisp, void* stream);
 
+/* Weight packing in one launch.  w: dense [Cout][Cin][K] (transposed = 0) or ConvTranspose [Cin][Cout][K] (transposed = 1); flip
+ * reverses the tap order (data gradients).  out_tap: [K][cb_in][2][cout_pad][8] (drc_tapconv_fwd and the LDS-staged kernels);
+ * out_t16: [K][cb_in][cout_pad][16] (the LDS-free kernels; K = 1: the 1x1 packing).  Either output may be NULL; channel padding is
+ * written as zeros. */
+int drc_pack_weights(const float* w, int cout, int cin, int K, int transposed, int flip, float* out_tap, float* out_t16, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Small helpers for the 2D feature CNN (submodule.py:76-139): average pool and bilinear
  * (align_corners=True) upsample on blocked 2D tensors, channel-offset aware (writes into a
@@ -245,6 +251,10 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
 #define DRC_BN_MAX_CHUNKS 512
 #define DRC_BN_SCRATCH_FLOATS(CB) ((size_t)DRC_BN_MAX_CHUNKS * (CB) * 32 + (CB))
 int drc_bn_stats_blocked(const float* x, const int* geom8, float* stats, float* scratch, void* stream);
+/* invstd[c] = rsqrt(stats[1][c]/count + eps) for all C16 (padded) channels, and, if running_mean != NULL, the nn.BatchNorm
+ * running-statistics update of the first C channels (momentum, unbiased batch variance); *num_batches_tracked += 1 if non-NULL */
+int drc_bn_finalize(const float* stats, int C16, int C, long long count, float eps, float momentum, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float* invstd, void* stream);
 int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int* geom_y, const float* res, const int* geom_r,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, int relu, void* stream);
 
