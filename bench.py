@@ -221,7 +221,7 @@ def main():
                 del bb, det
                 # ---- extra: one TRAIN step of the disparity stage (reference: PSMNet.train() + PSMLoss, trainer.do_train): forward with
                 # per-GPU batch-stat BatchNorm, 3-head smooth-L1 loss, full backward (dgrad + MFMA wgrad) on the HIP engine, gradient
-                # sync (GradientSync: a no-op at world size 1); 64 ROI pairs of Config A from the feature boundary, and 8 ROI crops of
+                # sync (GradientSync: a no-op at world size 1), optimizer step; 64 ROI pairs of Config A from the feature boundary, and 8 ROI crops of
                 # Config B through the 2D CNN as well
                 from disprcnn_amd.utils.loss_utils import PSMLoss
                 from disprcnn_amd.utils.comm import GradientSync
@@ -243,13 +243,14 @@ def main():
                         fl3 = FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * nroi
                     msk = torch.ones_like(tgt, dtype=torch.uint8)
                     crit = PSMLoss()
+                    opt = torch.optim.SGD(mdl.parameters(), lr=1e-7, momentum=0.9)   # the parameters change every step: weights are re-packed
 
                     def train_step():
-                        for p_ in mdl.parameters():
-                            p_.grad = None
+                        opt.zero_grad(set_to_none=True)
                         loss = crit(fwd(), {"disparity": tgt, "mask": msk})
                         loss.backward()
                         sync()
+                        opt.step()
                         return loss
                     for _ in range(2):
                         train_step()
@@ -260,7 +261,7 @@ def main():
                     tr[tag] = {"ms_per_step": round(tt * 1e3, 2), "roi_pairs_per_s": round(nroi / tt, 1),
                                "regressor_tflops_fwd_bwd": round(3 * fl3 / tt / 1e12, 2)}
                     mdl.eval()
-                tr["workload"] = "forward (batch-stat BN) + PSMLoss + backward + gradient sync; regressor FLOPs counted as 3x forward"
+                tr["workload"] = "forward (batch-stat BN) + PSMLoss + backward + gradient sync + SGD step; regressor FLOPs counted as 3x forward"
                 extra["train_step"] = tr
                 del mB
             except Exception as ex:  # report, never hide
