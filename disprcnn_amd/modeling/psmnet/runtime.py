@@ -1,4 +1,5 @@
-"""Execution of PSMNet on the HIP engine (eval mode: BatchNorm folded into the conv epilogues).
+"""Execution of PSMNet on the HIP engine (eval mode: BatchNorm folded into the conv epilogues; train mode: per-GPU batch
+statistics, a tape of conv+BN sites for the backward in train.py).
 
 Graph restated from the reference (stackhourglass.py:106-174, submodule.py:106-139) as a flat
 schedule of launches over blocked, zero-haloed tensors.  Workspaces and launch plans are cached
