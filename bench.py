@@ -172,6 +172,21 @@ def main():
                 extra["config_b_full_psmnet"] = {"roi_pairs_per_s": round(16 / tb, 1), "ms_per_16_roi_image": round(tb * 1e3, 2),
                                                  "stereo_pairs_per_s_16roi": round(1 / tb, 2),
                                                  "workload": "16 ROI crops 224x224, D=96 (-48..48): 2D CNN + cost volume + 3D + soft-argmin"}
+                # ---- extra: BASELINE configs[3] shape (64 ROIs/image at 224x224x96) -- in fp32: no fp16 path is built (the
+                # reference has no fp16 oracle), so this is the stress shape at the reference's own precision
+                l64, r64 = synth.synth_images(64, 224, 224, tag="benchB64")
+                l64, r64 = l64.to(dev), r64.to(dev)
+                with torch.no_grad():
+                    mB((l64, r64))
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for _ in range(3):
+                        mB((l64, r64))
+                    torch.cuda.synchronize()
+                    ts = (time.perf_counter() - ts) / 3
+                extra["stress_64roi_224x224x96_f32"] = {"roi_pairs_per_s": round(64 / ts, 1), "ms_per_64_roi_image": round(ts * 1e3, 2),
+                                                        "regressor_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / ts / 1e12, 1)}
+                del l64, r64
                 # ---- extra: BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
                 # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
                 from types import SimpleNamespace as NS
