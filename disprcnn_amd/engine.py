@@ -397,8 +397,10 @@ class ConvPlan:
             TIMING.append((self.kname, self.flops, e0, e1))
 
 
-DIRECT = {"enabled": True}    # stride-1 3x3x3 convs through the LDS-free sliding kernel (tapdirect.hip) instead of tapslide.hip
-DOWN = {"enabled": True, "tile": None, "min_groups": 700}   # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured, tools/exp_conv.py)     # stride-2 kernel on parity-split tiles (tapdown.hip); "tile" = development override
+# Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
+DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
+DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/exp_conv.py)
+        "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)
 
 
 def choose_tile_down(OH, OW):
@@ -483,7 +485,7 @@ def plan_deconv3d(x, y, cout, relu):
     return pl
 
 
-TAP2D = {"enabled": True, "tile": None}     # 3x3 stride-1 Conv2d kernel with explicit waits (tap2d.hip)
+TAP2D = {"enabled": True, "tile": None}     # LDS-staged 3x3 stride-1 Conv2d kernel (tap2d.hip), used when DIRECT is off
 
 
 def choose_tile_2d(OH, OW, dil):
