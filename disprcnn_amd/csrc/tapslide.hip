@@ -162,9 +162,11 @@ __global__ __launch_bounds__(64 * SLIDE_WAVES) void tapslide_kernel(const drc_ta
         }
 #define SLIDE_CH_DMA(T)                                                                                \
         {   /* steps beyond the last piece re-stage an earlier one (same bytes): the count stays static */ \
-            const int q_ = two_pieces ? 2 * (T) : (T);                                                 \
-            stage_piece(st_d, st_pc, bufsel ^ 1, q_ < pieces ? q_ : q_ - pieces);                      \
-            if (two_pieces) stage_piece(st_d, st_pc, bufsel ^ 1, q_ + 1 < pieces ? q_ + 1 : q_ + 1 - pieces); \
+            int q_ = two_pieces ? 2 * (T) : (T), q1_ = q_ + 1;                                         \
+            while (q_ >= pieces) q_ -= pieces;       /* tiny tiles: wrap as often as needed */          \
+            while (q1_ >= pieces) q1_ -= pieces;                                                       \
+            stage_piece(st_d, st_pc, bufsel ^ 1, q_);                                                  \
+            if (two_pieces) stage_piece(st_d, st_pc, bufsel ^ 1, q1_);                                 \
         }
 #define SLIDE_CH_B(T, B_LD)                                                                            \
         {                                                                                              \

@@ -432,6 +432,9 @@ def plan_conv3d(x, y, stride, cout, relu):
     if pl.slide and DIRECT["enabled"]:
         pl.direct = True
         pl.kname = pl.kname.replace("tapslide", "tapdirect")
+    elif pl.slide and (pl.p.R + 2) * (-(-(2 * (pl.p.WT + 2)) // 64)) > 18:
+        pl.slide = False                     # the LDS-staged kernel stages at most two pieces per tap step: tall narrow tiles go generic
+        pl.kname = pl.kname.replace("tapslide", "tapconv")
     if stride == 2 and DOWN["enabled"]:
         pl.down = True
         pl.p.R, pl.p.WT = choose_tile_down(y.H, y.W)
