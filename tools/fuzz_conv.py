@@ -15,13 +15,13 @@ n_cases = int(os.environ.get("CASES", "80"))
 for case in range(n_cases):
     kind = rng.choice(["3d_s1", "3d_s1", "3d_s2", "deconv", "2d_k3", "2d_k3s2", "2d_k1", "2d_k1s2", "2d_dil2"])
     cin, cout = rng.choice([3, 8, 16, 24, 32, 40, 64, 96]), rng.choice([8, 16, 24, 32, 48, 64, 80, 128])
-    n = rng.choice([1, 2, 3, 5])
+    n = rng.choice([33, 64, 100, 130]) if os.environ.get("BIGN") else rng.choice([1, 2, 3, 5])   # BIGN: many groups per wave, larger cout tiles per wave
     force_slide = rng.random() < 0.7
     if kind.startswith("3d") or kind == "deconv":
         if kind == "3d_s2":
-            dims = (2 * rng.randint(1, 5), 2 * rng.randint(1, 12), 2 * rng.randint(1, 20))
+            dims = (2 * rng.randint(1, 5), 2 * rng.randint(1, 12), 2 * rng.randint(1, 20)) if not os.environ.get("BIGN") else (2 * rng.randint(1, 3), 2 * rng.randint(1, 5), 2 * rng.randint(1, 8))
         else:
-            dims = (rng.randint(1, 9), rng.randint(1, 20), rng.randint(1, 33))
+            dims = (rng.randint(1, 9), rng.randint(1, 20), rng.randint(1, 33)) if not os.environ.get("BIGN") else (rng.randint(1, 5), rng.randint(1, 9), rng.randint(1, 15))
         x = torch.randn((n, cin) + dims, generator=g)
         w = torch.randn((cin, cout, 3, 3, 3) if kind == "deconv" else (cout, cin, 3, 3, 3), generator=g) * 0.1
         sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
@@ -43,7 +43,7 @@ for case in range(n_cases):
         stride = 2 if kind.endswith("s2") else 1
         dil = 2 if kind == "2d_dil2" else 1
         pad = 0 if k == 1 else dil
-        hw = (rng.randint(4, 40), rng.randint(4, 70))
+        hw = (rng.randint(4, 40), rng.randint(4, 70)) if not os.environ.get("BIGN") else (rng.randint(4, 14), rng.randint(4, 20))
         x = torch.randn((n, cin) + hw, generator=g)
         w = torch.randn(cout, cin, k, k, generator=g) * 0.1
         sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
