@@ -66,6 +66,8 @@ _SIGS = {
     "drc_deconv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_conv3d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_pack_weights_wino": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_conv2d_k1_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv2d_k3_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv2d_k3_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),

@@ -169,6 +169,21 @@ def pack_weight_t16(w, transposed=False):
     return wp.view(K, cb, CB, cout_pad).permute(0, 1, 3, 2).contiguous()
 
 
+def pack_weight_wino(w, transposed=False, flip=False):
+    """3x3x3 weights [Cout,Cin,3,3,3] (or [Cin,Cout,...] with transposed; flip reverses the taps) -> Winograd F(2,3)^3
+    transformed [64 frequency points][cb_in][cout_pad][16] (drc_pack_weights_wino): the packing of wino3d.hip."""
+    w = w.detach().contiguous().float()
+    require_gpu(w, "pack_weight_wino")
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError("pack_weight_wino expects a 3x3x3 kernel")
+    a, b = w.shape[:2]
+    cout, cin = (b, a) if transposed else (a, b)
+    out = torch.empty(64, (cin + CB - 1) // CB, cout_pad_of(cout), 16, dtype=torch.float32, device=w.device)
+    st = _lib.lib().drc_pack_weights_wino(_ptr(w), cout, cin, int(transposed), int(flip), _ptr(out), _stream_ptr(w.device))
+    _lib.check(st, "drc_pack_weights_wino")
+    return out
+
+
 def pack_conv_weight(w, transposed=False):
     """The packing the engine's plan for this convolution expects (pointwise for 1x1 Conv2d, tap layout otherwise)."""
     return pack_weight_pw(w) if is_pointwise(w.shape, transposed) else pack_weight(w, transposed)
@@ -291,6 +306,7 @@ class ConvPlan:
         self.pointwise = False
         self.tap2d = False
         self.direct = False
+        self.wino = False
         self.c2d = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
@@ -337,11 +353,19 @@ class ConvPlan:
             else:
                 self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)
 
+    def pack16(self, w, transposed=False, flip=False):
+        """The weight packing this plan's LDS-free kernel reads (None when the plan runs an LDS-staged kernel)."""
+        if self.wino:
+            return pack_weight_wino(w, transposed, flip)
+        if self.direct and (self.slide or self.down or self.c2d):
+            return pack_layouts(w, transposed, flip, want_tap=False)[1]
+        return None
+
     def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
         p = self.p
         if self.direct and (self.slide or self.down or self.c2d):
-            if w16 is None:
-                raise ValueError("this plan runs the LDS-free kernel: pass w16 = engine.pack_weight_t16(weight)")
+            if w16 is None or (w16.shape[0] == 64) != self.wino:
+                raise ValueError("this plan runs an LDS-free kernel: pass w16 = plan.pack16(weight)")
             w = w16
         relu_saved = p.relu
         if relu is not None:
@@ -370,6 +394,9 @@ class ConvPlan:
         elif self.direct and self.down:
             st = _lib.lib().drc_conv3d_k3s2_direct_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_direct_fwd")
+        elif self.wino:
+            st = _lib.lib().drc_conv3d_k3_wino_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv3d_k3_wino_fwd")
         elif self.direct and self.slide:
             st = _lib.lib().drc_tapconv3d_direct_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_tapconv3d_direct_fwd")
@@ -398,6 +425,7 @@ class ConvPlan:
 
 
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
+WINO = {"enabled": True}      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
 DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
 DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/exp_conv.py)
         "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)
@@ -432,6 +460,9 @@ def plan_conv3d(x, y, stride, cout, relu):
     if pl.slide and DIRECT["enabled"]:
         pl.direct = True
         pl.kname = pl.kname.replace("tapslide", "tapdirect")
+        if WINO["enabled"] and not (y.D | y.H | y.W) & 1 and x.N * x.n_stride * 4 < 2 ** 32:
+            pl.wino = True
+            pl.kname = "wino3d_kernel<%d>" % pl.slide_ct
     elif pl.slide and (pl.p.R + 2) * (-(-(2 * (pl.p.WT + 2)) // 64)) > 18:
         pl.slide = False                     # the LDS-staged kernel stages at most two pieces per tap step: tall narrow tiles go generic
         pl.kname = pl.kname.replace("tapslide", "tapconv")

@@ -28,6 +28,7 @@ class _Conv:
             self.w, self.w16 = E.pack_layouts(w, transposed, want_t16=need16)
         else:
             self.w, self.w16 = E.pack_weight(w, transposed), (E.pack_weight_t16(w) if need16 else None)
+        self._ww = None
         cout_pad = E.cout_pad_of(self.cout)
         self.cout_pad, self.device = cout_pad, device
         self.bn = bn
@@ -42,6 +43,14 @@ class _Conv:
         else:
             self.scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
             self.shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+
+    def w16_for(self, plan):
+        """The LDS-free packing `plan` reads: t16, or the Winograd-transformed weights (built on first use)."""
+        if not plan.wino:
+            return self.w16
+        if self._ww is None:
+            self._ww = plan.pack16(self.conv.weight.detach().to(device=self.device, dtype=torch.float32), self.transposed)
+        return self._ww
 
     def refold(self):
         """Eval-mode BatchNorm folded into per-cout scale/shift from the module's current running statistics."""
@@ -133,7 +142,7 @@ class PSMNetRuntime:
         pl = p[plan]
         rs = t[res] if res else None
         if not self._training or c.bn is None:
-            pl.run(t[x], c.w, c.scale, c.shift, t[y], rs, w16=c.w16)
+            pl.run(t[x], c.w, c.scale, c.shift, t[y], rs, w16=c.w16_for(pl))
             if self._training and self._tape is not None:        # BN-less conv (lastconv.2): still a site of the reverse pass
                 self._tape.append(("site", ws, plan, wname, x, y, res))
             return
@@ -142,7 +151,7 @@ class PSMNetRuntime:
         if raw is None:
             raw = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
             ws["raw"][plan] = raw
-        pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False, w16=c.w16)
+        pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False, w16=c.w16_for(pl))
         bn = c.bn
         fused = (bn.momentum is not None and bn.running_mean is not None and bn.running_mean.device == raw.device and
                  bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous())

@@ -127,6 +127,8 @@ class RegressorBackward:
             wp, w16 = E.pack_layouts(wt, True, False, want_t16=need16)
         elif pl.pointwise:              # 1x1: in/out swap only
             wp, w16 = E.pack_layouts(wt, True, False, want_tap=False)[1][0], None
+        elif pl.wino:                   # stride 1 as Winograd: in/out swap + flipped taps inside the weight transform
+            wp, w16 = E.pack_layouts(wt, True, True, want_t16=False)[0], pl.pack16(wt, True, True)
         else:                           # stride 1: in/out swap + flipped taps
             wp, w16 = E.pack_layouts(wt, True, True, want_t16=need16)
         cp = ent["plan"].p.cout_pad

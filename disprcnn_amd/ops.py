@@ -67,8 +67,7 @@ def conv3d_bn(x, weight, scale, shift, stride=1, relu=False, residual=None, tran
     cp = wp.shape[3]
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale; sh[:cout] = shift
-    w16 = E.pack_weight_t16(weight.to(dev).float(), transposed) if plan.direct else None
-    plan.run(xb, wp, sc, sh, yb, rb, w16=w16)
+    plan.run(xb, wp, sc, sh, yb, rb, w16=plan.pack16(weight.to(dev).float(), transposed))
     return yb.to_dense()
 
 
@@ -89,6 +88,5 @@ def conv2d_bn(x, weight, scale, shift, stride=1, pad=1, dilation=1, relu=False, 
     cp = E.cout_pad_of(cout)
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale; sh[:cout] = shift
-    w16 = E.pack_weight_t16(weight.to(dev).float()) if plan.direct else None
-    plan.run(xb, wp, sc, sh, yb, rb, w16=w16)
+    plan.run(xb, wp, sc, sh, yb, rb, w16=plan.pack16(weight.to(dev).float()))
     return yb.to_dense()[:, :, 0]

@@ -145,6 +145,17 @@ int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, vo
  * per-lane address of the float4 B fragment.  Weights packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16). */
 int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* The stride-1 3x3x3 convolution of drc_tapconv3d_direct_fwd (same parameter block; R, WT and lds_bytes_per_wave ignored) as
+ * Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: 64 instead of 216 multiplies per (cin, cout) pair and 2x2x2 output tile.
+ * Needs even OD, OH, OW and N * x_n_stride * 4 < 2^32; weights from drc_pack_weights_wino.  Results differ from the direct
+ * kernels' by fp32 rounding only (about twice the direct kernel's own error against fp64). */
+int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
+/* Winograd weight transform U = (G x G x G) g of a 3x3x3 kernel, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]:
+ * w [Cout][Cin][27] (transposed: [Cin][Cout][27]; flip reverses the taps -- data gradients) ->
+ * out [64 = (xd*4+xh)*4+xw][ceil(Cin/16)][cout_pad][16], zero-padded. */
+int drc_pack_weights_wino(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream);
+
 /* Conv2d(k3, stride 1, dilation d, pad d) (+BN/bias, +residual, +ReLU): the 3x3 convolutions of the PSMNet feature CNN
  * (submodule.py:60-139) and of ResNet-50-FPN, with the wait protocol of drc_conv3d_k3s2_fwd (dense LDS-DMA tile, static piece
  * count, uncounted weight loads, two waves per SIMD).  Parameter block of drc_tapconv_fwd for the single 1x3x3 class

@@ -130,16 +130,62 @@ def test_conv3d_direct_kernel_vs_oracle(dev, cin, cout, dims):
     shift = synth.hash_uniform("D:b", (cout,), -0.5, 0.5)
     res = synth.hash_uniform(f"D{cout}{dims}:r", (n, cout) + dims)
     ref = F.relu(F.conv3d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) + res)
-    saved = (E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"])
+    saved = (E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"])
     E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"] = True, 2, 1      # force the sliding path at test sizes
+    E.WINO["enabled"] = False
     try:
         xb = E.Blocked(n, cin, *dims, 1, 1, 1, dev)
         plan = E.plan_conv3d(xb, E.Blocked(n, cout, *dims, 1, 1, 1, dev), 1, cout, True)
         got = ops.conv3d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, True, res.to(dev))
     finally:
-        E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"] = saved
-    assert plan.direct and plan.slide, "shape was expected to take the direct kernel"
+        E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = saved
+    assert plan.direct and plan.slide and not plan.wino, "shape was expected to take the direct kernel"
     _close(got, ref)
+
+
+@pytest.mark.parametrize("n,cin,cout,dims,with_res", [(2, 64, 32, (4, 12, 28), True), (3, 32, 32, (12, 28, 28), False), (1, 32, 32, (2, 56, 56), True),
+                                                      (2, 16, 48, (6, 4, 10), True), (2, 64, 64, (6, 14, 14), False), (5, 40, 24, (8, 10, 30), True),
+                                                      (1, 7, 33, (2, 2, 2), True), (9, 32, 32, (2, 2, 6), False)])
+def test_conv3d_winograd_kernel_vs_oracle(dev, n, cin, cout, dims, with_res):
+    """wino3d.hip (Winograd F(2x2x2,3x3x3), the default for stride-1 3x3x3 layers with even output dims) against the direct
+    convolution: partial tile groups, blocks with fewer than four groups, one and two cout groups, channel counts that are
+    not multiples of 16, with and without the residual.  Same tolerance as the direct kernels."""
+    from disprcnn_amd import ops, engine as E
+    x = synth.hash_uniform(f"W{cin}{cout}{dims}:x", (n, cin) + dims)
+    w = synth.hash_uniform(f"W{cin}{cout}:w", (cout, cin, 3, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("W:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("W:b", (cout,), -0.5, 0.5)
+    res = synth.hash_uniform(f"W{cout}{dims}:r", (n, cout) + dims) if with_res else None
+    ref = F.conv3d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    ref = F.relu(ref + res) if with_res else ref
+    saved = (E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"])
+    E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = True, 2, 1, True
+    try:
+        xb = E.Blocked(n, cin, *dims, 1, 1, 1, dev)
+        plan = E.plan_conv3d(xb, E.Blocked(n, cout, *dims, 1, 1, 1, dev), 1, cout, True)
+        got = ops.conv3d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, with_res, res.to(dev) if with_res else None)
+    finally:
+        E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = saved
+    assert plan.wino, "shape was expected to take the Winograd kernel"
+    _close(got, ref)
+
+
+def test_winograd_weight_transform_vs_oracle(dev):
+    """drc_pack_weights_wino against U = (G x G x G) g in float64, incl. the in/out swap and tap flip of the data gradient."""
+    from disprcnn_amd import engine as E
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    for cout, cin, transposed, flip in [(32, 32, False, False), (20, 40, False, False), (24, 16, True, True)]:
+        w = synth.hash_uniform(f"WT{cout}{cin}", (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), -1, 1)
+        got = E.pack_weight_wino(w.to(dev), transposed, flip).cpu()
+        wc = w.transpose(0, 1) if transposed else w
+        wc = wc.flip(2, 3, 4) if flip else wc
+        U = torch.einsum("ai,bj,ek,ocijk->abeoc", G, G, G, wc.double())          # [xd][xh][xw][cout][cin]
+        cb, cp = (cin + 15) // 16, (cout + 15) // 16 * 16
+        ref = torch.zeros(64, cb * 16, cp, dtype=torch.float64)
+        ref[:, :cin, :cout] = U.reshape(64, cout, cin).transpose(1, 2)
+        ref = ref.view(64, cb, 16, cp).permute(0, 1, 3, 2)
+        assert got.shape == ref.shape
+        assert (got.double() - ref).abs().max().item() < 1e-6
 
 
 @pytest.mark.parametrize("kind,cin,cout,stride,dims", [("3d", 32, 32, 1, (6, 28, 28)), ("3d", 64, 32, 1, (4, 12, 28)), ("3d", 32, 64, 2, (12, 28, 28)),

@@ -16,7 +16,7 @@ def run(N, cin, cout, dims, stride=1, deconv=False, reps=20):
     plan = E.plan_deconv3d(x, y, cout, True) if deconv else E.plan_conv3d(x, y, stride, cout, True)
     w = torch.randn((cin, cout, 3, 3, 3) if deconv else (cout, cin, 3, 3, 3), device=dev) * 0.05
     wp = E.pack_weight(w, deconv)
-    w16 = E.pack_weight_t16(w, deconv) if plan.direct else None
+    w16 = plan.pack16(w, deconv)
     sc = torch.ones(wp.shape[3], device=dev); sh = torch.zeros(wp.shape[3], device=dev)
     for _ in range(3):
         plan.run(x, wp, sc, sh, y, w16=w16)
@@ -46,6 +46,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if os.environ.get("MAX_SLOTS"):
         E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
+    if os.environ.get("WINO"):
+        E.WINO["enabled"] = os.environ["WINO"] != "0"
     if os.environ.get("DIRECT"):
         E.DIRECT["enabled"] = os.environ["DIRECT"] != "0"
     if os.environ.get("DN_MIN_GROUPS"):
