@@ -149,6 +149,13 @@ def main():
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate pass; profiles/r1_pmc.md)",
                     "calls_per_step": calls // args.steps, "avg_launch_us": round(secs / calls * 1e6, 2),
                     "algorithmic_flops_per_launch": flops / calls}
+        if dom.startswith("wino3d"):
+            # `achieved` prices the layer at the direct convolution's 2*27*Cin*Cout flops per voxel (the algorithmic figure of
+            # DESIGN.md section 3); Winograd F(2,3)^3 executes 64/216 of those multiplies on the matrix cores, so `frac` may
+            # exceed 1 -- `executed_frac` is what the MFMA pipe actually sustains against its peak
+            roofline["executed"] = round(achieved * 64 / 216, 2)
+            roofline["executed_frac"] = round(achieved * 64 / 216 / PEAK_F32_TFLOPS, 4)
+            roofline["note"] = "achieved = direct-convolution flops / time; the kernel is Winograd F(2x2x2,3x3x3): 64/216 of them are executed"
         extra["kernels"] = {k: {"calls_per_step": v[0] // args.steps, "avg_us": round(v[1] / v[0] * 1e6, 2),
                                 "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in agg.items()}
         step_flops = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * N

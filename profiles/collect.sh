@@ -15,6 +15,7 @@ timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$O
 timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT" -o write -- $BENCH > "$OUT/write.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT" -o sq -- $BENCH > "$OUT/sq.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SALU SQ_INSTS_LDS -d "$OUT" -o lds -- $BENCH > "$OUT/lds.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum -d "$OUT" -o cache -- $BENCH > "$OUT/cache.log" 2>&1
 grep -h '"metric"' "$OUT"/trace.log | tail -1 > "$OUT/bench_line.json"
 python profiles/summarize.py "$OUT" "$TAG"
 ls -la "$OUT" | head -30

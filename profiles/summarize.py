@@ -80,6 +80,14 @@ def main(out, tag):
         lines.append(f"| `{k}` | {n} | {f:.1f} | {2 * f:.1f} | {w:.1f} | {dur / 1e3:.1f} | {busy:.1f} | {clock:.2f} | {occ:.2f} | "
                      f"{pct('SQ_WAIT_ANY'):.1f} | {pct('SQ_WAIT_INST_ANY'):.1f} | {pct('SQ_ACTIVE_INST_ANY'):.1f} | {lconf:.1f} |")
         traffic[k] = {"fetch_bytes_raw": f * 1e6, "fetch_bytes_corrected": 2 * f * 1e6, "write_bytes": w * 1e6, "launches": n}
+    cache = load_counters(os.path.join(out, "cache_counter_collection.csv"))
+    if cache:
+        lines += ["", "Vector L1 (TCP) and L2 (TCC) per launch: wave-level L1 accesses, L1->L2 read requests, L2 hit rate.", "",
+                  "| kernel | L1 accesses (M) | L1->L2 read requests (M) | L2 hits (M) | L2 misses (M) | L2 hit % |", "|---|---|---|---|---|---|"]
+        for k in sorted(cache, key=lambda k: -sum(cache[k].get("__dur_ns", [0])))[:8]:
+            c = cache[k]
+            a, rq, h, m = (mean(c.get(n, [])) / 1e6 for n in ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"))
+            lines.append(f"| `{k}` | {a:.2f} | {rq:.2f} | {h:.2f} | {m:.2f} | {100 * h / (h + m) if h + m else float('nan'):.1f} |")
     open(os.path.join(here, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1)
     print("wrote", f"profiles/{tag}_kernel_stats.md", f"profiles/{tag}_pmc.md", f"profiles/{tag}_traffic.json")

@@ -12,4 +12,8 @@ s = re.sub(r'(\n\s*)bfly_row\(tn\[', r'\1if (WN_G_BFLY) bfly_row(tn[', s)
 s = s.replace('v[0][w] = tn[0][w] - tn[2][w];', 'if (WN_G_BFLY) { v[0][w] = tn[0][w] - tn[2][w];').replace('v[3][w] = tn[1][w] - tn[3][w];', 'v[3][w] = tn[1][w] - tn[3][w]; }')
 s = s.replace('wf[xw][ct] = *(const f32x4*)&w_ring', 'if (WN_G_W) wf[xw][ct] = *(const f32x4*)&w_ring')
 s = s.replace('fill[q] = *(const f32x4*)(src + fill_off[q]);', 'if (WN_G_FILL) fill[q] = *(const f32x4*)(src + fill_off[q]);')
+# WN_HOT: every raw load re-reads the first step's patch of the wave's first tile group (L1-hot; same instruction stream)
+s = s.replace('auto load_row = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], const char* sa, const char* sb, int h, unsigned xo) __attribute__((always_inline)) {',
+              'auto load_row = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], const char* sa, const char* sb, int h, unsigned xo) __attribute__((always_inline)) {\n#ifdef WN_HOT\n        sa = (const char*)p.x; sb = (const char*)p.x + 64; xo = hot_xo;\n#endif')
+s = s.replace('    // depth butterfly of frequency xd: slice a + sgn', '    const unsigned hot_xo = geo_of(0).xo; (void)hot_xo;\n    // depth butterfly of frequency xd: slice a + sgn')
 open('/tmp/wino3d_abl.hip', 'w').write(s)
