@@ -8,20 +8,29 @@ from disprcnn_amd import ops, engine as E
 dev = torch.device("cuda:0")
 if os.environ.get("DIRECT") == "0":
     E.DIRECT["enabled"] = False          # sweep the LDS-staged variants instead
+WINO_ONLY = os.environ.get("WINO") == "1"
+if WINO_ONLY:
+    E.SLIDE["min_od"] = 2
 rng = random.Random(int(os.environ.get("SEED", "1")))
 g = torch.Generator().manual_seed(int(os.environ.get("SEED", "1")))
 bad = 0
 n_cases = int(os.environ.get("CASES", "80"))
 for case in range(n_cases):
     kind = rng.choice(["3d_s1", "3d_s1", "3d_s2", "deconv", "2d_k3", "2d_k3s2", "2d_k1", "2d_k1s2", "2d_dil2"])
+    if WINO_ONLY:
+        kind = "3d_s1"
     cin, cout = rng.choice([3, 8, 16, 24, 32, 40, 64, 96]), rng.choice([8, 16, 24, 32, 48, 64, 80, 128])
     n = rng.choice([33, 64, 100, 130]) if os.environ.get("BIGN") else rng.choice([1, 2, 3, 5])   # BIGN: many groups per wave, larger cout tiles per wave
-    force_slide = rng.random() < 0.7
+    force_slide = rng.random() < 0.7 or WINO_ONLY
+    if WINO_ONLY:
+        n = rng.choice([1, 2, 3, 5, 7, 19, 33, 64])
     if kind.startswith("3d") or kind == "deconv":
         if kind == "3d_s2":
             dims = (2 * rng.randint(1, 5), 2 * rng.randint(1, 12), 2 * rng.randint(1, 20)) if not os.environ.get("BIGN") else (2 * rng.randint(1, 3), 2 * rng.randint(1, 5), 2 * rng.randint(1, 8))
         else:
             dims = (rng.randint(1, 9), rng.randint(1, 20), rng.randint(1, 33)) if not os.environ.get("BIGN") else (rng.randint(1, 5), rng.randint(1, 9), rng.randint(1, 15))
+        if WINO_ONLY:      # even output dims: the Winograd kernel (tile groups of every fill level, 1..N cout groups)
+            dims = (2 * rng.randint(1, 6), 2 * rng.randint(1, 10), 2 * rng.randint(1, 16)) if n < 19 else (2 * rng.randint(1, 3), 2 * rng.randint(1, 5), 2 * rng.randint(1, 7))
         x = torch.randn((n, cin) + dims, generator=g)
         w = torch.randn((cin, cout, 3, 3, 3) if kind == "deconv" else (cout, cin, 3, 3, 3), generator=g) * 0.1
         sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
