@@ -101,3 +101,33 @@ def test_tile_choice_fits_lds(shape):
     R, WT, lds = E.choose_tile(OH, OW, im, sh, sw)
     assert R * WT <= 112 and lds <= E.LDS_PER_WAVE_MAX
     assert lds == 2 * (im * (R - 1) + sh + 1) * (im * (WT - 1) + sw + 1) * 32
+
+
+def test_stride1_conv3d_kernel_selection():
+    """Which kernel the engine plans for a stride-1 3x3x3 layer: Winograd for even output dims with enough work, the direct
+    kernel for odd dims or with the switch off, the generic kernel for tiny batches; and a plan refuses the wrong packing."""
+    from disprcnn_amd import engine as E
+    dev = torch.device("cpu")
+
+    def plan(n, c, dims):
+        x, y = E.Blocked(n, c, *dims, 1, 1, 1, dev), E.Blocked(n, c, *dims, 1, 1, 1, dev)
+        return E.plan_conv3d(x, y, 1, c, True)
+
+    pl = plan(256, 32, (12, 28, 28))
+    assert pl.wino and pl.direct and pl.kname == "wino3d_kernel<2>"
+    pl = plan(256, 64, (3, 7, 7))                       # conv4 of Config A: odd dims
+    assert not pl.wino and pl.direct and pl.kname.startswith("tapdirect")
+    saved = E.WINO["enabled"]
+    E.WINO["enabled"] = False
+    try:
+        assert not plan(256, 32, (12, 28, 28)).wino
+    finally:
+        E.WINO["enabled"] = saved
+    pl = plan(2, 32, (12, 28, 28))                      # too few work units for the sliding kernels
+    assert not pl.wino and not pl.direct
+    # a Winograd plan wants the 64-point packing, not the 27-tap one
+    pl = plan(256, 32, (12, 28, 28))
+    x, y = E.Blocked(1, 32, 2, 2, 2, 1, 1, 1, dev), E.Blocked(1, 32, 2, 2, 2, 1, 1, 1, dev)
+    w = torch.zeros(32, 32, 3, 3, 3)
+    with pytest.raises(ValueError):
+        pl.run(x, E.pack_weight(w), torch.ones(32), torch.zeros(32), y, w16=E.pack_weight_t16(w))
