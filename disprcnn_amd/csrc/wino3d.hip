@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
     }
 
     int slab = 0;
-    // one (depth frequency, channel block) step: its MFMAs in four row phases of 8*CT... 16*CT MFMAs, with -- in their shadow --
+    // one (depth frequency, channel block) step: its MFMAs in four row phases of 16*CT MFMAs, with -- in their shadow --
     // the depth/w butterflies of the next step's rows (loaded two phases earlier) and the loads of the rows two phases ahead
     // (rows 2, 3 of the next step, then rows 0, 1 of the one after).  Past the last step the loads are harmless repeats.
     auto do_step = [&](auto first_tag) __attribute__((always_inline)) {
