@@ -286,6 +286,25 @@ def main():
                 tr["workload"] = "forward (batch-stat BN) + PSMLoss + backward + gradient sync + SGD step; regressor FLOPs counted as 3x forward"
                 extra["train_step"] = tr
                 del mB
+                # ---- extra: post-processing: 16 images 375x1242, 16 ROI maps 224x224 each -> full-image disparity maps
+                from disprcnn_amd import ops as _ops
+                gpp = torch.Generator().manual_seed(0)
+                nimg, nr, ih, iw = 16, 16, 375, 1242
+                x1 = torch.rand(nimg * nr, generator=gpp) * (iw - 260); y1 = torch.rand(nimg * nr, generator=gpp) * (ih - 180)
+                lbp = torch.stack([x1, y1, x1 + 60 + torch.rand(nimg * nr, generator=gpp) * 190, y1 + 40 + torch.rand(nimg * nr, generator=gpp) * 130], 1)
+                rbp = lbp.clone(); rbp[:, 0] = (lbp[:, 0] - 30).clamp(min=0); rbp[:, 2] = lbp[:, 2] - 25
+                dpp = (torch.rand(nimg * nr, 224, 224, generator=gpp) * 96 - 48).to(dev)
+                b6 = _ops.integer_roi_boxes(lbp.to(dev), rbp.to(dev))
+                for _ in range(3):
+                    _ops.disparity_paste(dpp, b6, [nr] * nimg, ih, iw)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(20):
+                    _ops.disparity_paste(dpp, b6, [nr] * nimg, ih, iw)
+                torch.cuda.synchronize(); tp = (time.perf_counter() - t1) / 20
+                pbytes = nimg * ih * iw * 4 + dpp.numel() * 4
+                extra["post_process_16img_x16roi"] = {"us_per_call": round(tp * 1e6, 1), "images_per_s": round(nimg / tp, 1),
+                                                      "algorithmic_GB_per_s": round(pbytes / tp / 1e9, 1),
+                                                      "workload": "drc_disparity_paste_fwd: 256 ROI maps 224^2 -> 16 maps 375x1242 (one launch; bytes = maps read once + outputs written once)"}
             except Exception as ex:  # report, never hide
                 extra["config_b_full_psmnet"] = extra.get("config_b_full_psmnet") or {"error": repr(ex)}
                 extra["extra_error"] = repr(ex)

@@ -90,3 +90,52 @@ def conv2d_bn(x, weight, scale, shift, stride=1, pad=1, dilation=1, relu=False, 
     sc[:cout] = scale; sh[:cout] = shift
     plan.run(xb, wp, sc, sh, yb, rb, w16=plan.pack16(weight.to(dev).float()))
     return yb.to_dense()[:, :, 0]
+
+
+def integer_roi_boxes(left_bbox, right_bbox):
+    """[R,4] xyxy float boxes (left, right) -> [R,6] int32 (x1, y1, x2, y2, x1p, x2p) after expand_box_to_integer
+    (utils/stereo_utils.py:219-229), computed on the device (the reference goes through .tolist())."""
+    lb, rb = left_bbox.float(), right_bbox.float()
+    return torch.stack([lb[:, 0].floor(), lb[:, 1].floor(), lb[:, 2].ceil(), lb[:, 3].ceil(), rb[:, 0].floor(), rb[:, 2].ceil()],
+                       dim=1).to(torch.int32).contiguous()
+
+
+def disparity_paste(disp, boxes6, rois_per_image, height, width, clamp0=False, masks=None):
+    """Per-ROI disparities [R,S,S] + integer boxes [R,6] -> full-image disparity maps [B,height,width]
+    (DisparityMapProcessor, modeling/psmnet/inference.py:18-47; clamp0 / masks: roi_disp_postprocess, disprcnn3d.py:161-190)."""
+    E.require_gpu(disp, "disparity_paste")
+    dev = disp.device
+    B = len(rois_per_image)
+    R = int(sum(rois_per_image))
+    if disp.dim() != 3 or disp.shape[0] != R or disp.shape[1] != disp.shape[2] or tuple(boxes6.shape) != (R, 6):
+        raise ValueError("disparity_paste expects disp [R,S,S] and boxes [R,6] with R = sum(rois_per_image)")
+    offs = torch.tensor([0] + list(rois_per_image), dtype=torch.int64).cumsum(0).to(torch.int32).to(dev)
+    disp = disp.contiguous().float()
+    boxes6 = boxes6.to(device=dev, dtype=torch.int32).contiguous()
+    if masks is not None:
+        masks = masks.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(masks.shape) != (R, height, width):
+            raise ValueError("masks must be [R,height,width]")
+    out = torch.empty(B, height, width, dtype=torch.float32, device=dev)
+    st = _lib.lib().drc_disparity_paste_fwd(E._ptr(disp), disp.shape[1], E._ptr(boxes6), E._ptr(offs), B, height, width, int(bool(clamp0)),
+                                            E._ptr(masks), E._ptr(out), E._stream_ptr(dev))
+    _lib.check(st, "drc_disparity_paste_fwd")
+    return out
+
+
+def roi_depth_maps(disp, boxes6, fuxb, height, width):
+    """Per-ROI depth maps [R,height,width] = fuxb / (disparity + 1e-6) inside each ROI's box, zero elsewhere
+    (PointRCNN.process_input, pointnet_module/point_rcnn/lib/net/point_rcnn.py:121-133)."""
+    E.require_gpu(disp, "roi_depth_maps")
+    dev = disp.device
+    R = disp.shape[0]
+    if disp.dim() != 3 or disp.shape[1] != disp.shape[2] or tuple(boxes6.shape) != (R, 6):
+        raise ValueError("roi_depth_maps expects disp [R,S,S] and boxes [R,6]")
+    fuxb = torch.as_tensor(fuxb, dtype=torch.float32, device=dev).expand(R).contiguous()
+    disp = disp.contiguous().float()
+    boxes6 = boxes6.to(device=dev, dtype=torch.int32).contiguous()
+    out = torch.empty(R, height, width, dtype=torch.float32, device=dev)
+    st = _lib.lib().drc_roi_depth_maps_fwd(E._ptr(disp), disp.shape[1], E._ptr(boxes6), E._ptr(fuxb), R, height, width, E._ptr(out),
+                                           E._stream_ptr(dev))
+    _lib.check(st, "drc_roi_depth_maps_fwd")
+    return out

@@ -237,6 +237,23 @@ int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const
                         float* rois_left, float* rois_right, int32_t* geom, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f2. Post-processing: per-ROI disparities [R][S][S] -> full-image maps, replacing DisparityMapProcessor
+ * (modeling/psmnet/inference.py:18-47), DispRCNN3D.roi_disp_postprocess (modeling/detector/disprcnn3d.py:161-190) and the
+ * per-ROI depth maps of PointRCNN.process_input (pointnet_module/point_rcnn/lib/net/point_rcnn.py:121-133).
+ *   boxes [R][6] int32 = x1, y1, x2, y2 of the left box and x1p, x2p of the right box, all after expand_box_to_integer;
+ *   value(r, y, x) inside the left box = bilinear(align_corners) resize of map r to (y2-y1) x max(x2-x1, x2p-x1p),
+ *   times that width / S, plus x1 - x1p (structures/disparity.py:38-77); boxes reaching outside the image are clipped
+ *   (the reference raises a shape error there).
+ * drc_disparity_paste_fwd: roi_offsets [B+1] (CSR: the ROIs of image b), out [B][H][W] = max over the image's ROIs of
+ *   (inside ? value : 0), 0 without ROIs -- so one ROI keeps its negative values, several clamp at 0 outside their overlap,
+ *   exactly like the reference's max over stacked zero images.  flags bit 0: clamp each value at 0 first; mask (optional,
+ *   [R][H][W] float) multiplies after the clamp (roi_disp_postprocess).
+ * drc_roi_depth_maps_fwd: out [R][H][W] = inside ? fuxb[r] / (value + 1e-6) : 0. */
+int drc_disparity_paste_fwd(const float* disp, int S, const int32_t* boxes, const int32_t* roi_offsets, int B, int H, int W, int flags,
+                            const float* mask, float* out, void* stream);
+int drc_roi_depth_maps_fwd(const float* disp, int S, const int32_t* boxes, const float* fuxb, int R, int H, int W, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * a10. PSMLoss / EndPointErrorLoss (utils/loss_utils.py:9-32, utils/stereo_utils.py:185-208).
  *   sums5 (caller-zeroed) += { sum m*smoothl1(p1-t), sum m*smoothl1(p2-t), sum m*smoothl1(p3-t), sum m, sum m*|p1-t| }
  *   (pred2/pred3 may be NULL for the eval form).  The scalar loss is assembled by the caller:
