@@ -52,6 +52,54 @@ def all_gather_rows(t):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
 
 
+def gather_predictions(predictions, fields=("scores", "labels", "disparity")):
+    """{image_id: BoxList} of this rank -> list of BoxLists ordered by image id on the main process (None elsewhere).
+
+    Reference: engine/inference.py:53-72 -- `all_gather` pickles every rank's dict (utils/comm.py:47-87: three collectives on a
+    ByteTensor of the pickle).  Here the payload travels as tensors: one row-gather each for the per-image header
+    (image id, width, height, ROI count), the boxes and every tensor field present on all images (first dim = ROIs).
+    Fields that are not tensors are not transported; duplicated image ids keep the copy of the highest rank, like
+    dict.update in the reference."""
+    from ..structures.bounding_box import BoxList
+    ids = sorted(predictions)
+    dev = next((predictions[i].bbox.device for i in ids), torch.device("cpu"))
+    head = torch.tensor([[i, predictions[i].size[0], predictions[i].size[1], len(predictions[i])] for i in ids],
+                        dtype=torch.int64, device=dev).reshape(-1, 4)
+    boxes = torch.cat([predictions[i].bbox for i in ids]) if ids else torch.zeros(0, 4, device=dev)
+    # a field travels if every rank has it on every one of its images: agree on that with one small gather
+    have = torch.tensor([[int(all(predictions[i].has_field(f) and torch.is_tensor(predictions[i].get_field(f)) for i in ids))
+                          for f in fields]], dtype=torch.int64, device=dev)
+    have = all_gather_rows(have).min(dim=0)[0].tolist() if len(fields) else []
+    head_all, boxes_all = all_gather_rows(head), all_gather_rows(boxes.float())
+    payload = {}
+    for f, ok in zip(fields, have):
+        if not ok:
+            continue
+        parts = [predictions[i].get_field(f) for i in ids]
+        shape = next((tuple(p_.shape[1:]) for p_ in parts), None)
+        dtype = next((p_.dtype for p_ in parts), torch.float32)
+        # ranks without images learn the trailing shape from the others: gather it first (rank-independent result)
+        meta = torch.tensor([[len(shape) if shape is not None else -1] + list(shape or ()) + [0] * (8 - len(shape or ()))],
+                            dtype=torch.int64, device=dev)
+        meta = all_gather_rows(meta)
+        known = meta[meta[:, 0] >= 0]
+        if len(known) == 0:
+            continue
+        shape = tuple(int(v) for v in known[0, 1:1 + int(known[0, 0])])
+        local = torch.cat(parts) if parts else torch.zeros((0,) + shape, dtype=dtype, device=dev)
+        payload[f] = all_gather_rows(local)
+    if not is_main_process():
+        return None
+    out, start = {}, 0
+    for img_id, w, h, r in head_all.tolist():
+        bl = BoxList(boxes_all[start:start + r], (w, h))
+        for f, t in payload.items():
+            bl.add_field(f, t[start:start + r])
+        out[img_id] = bl
+        start += r
+    return [out[i] for i in sorted(out)]
+
+
 def reduce_dict(d, average=True):
     """Reduce a dict of scalar tensors to rank 0 (reference comm.py:90-116, trainer.py:19-41)."""
     world = get_world_size()

@@ -73,3 +73,46 @@ def test_single_process_fallbacks():
     t = torch.arange(6.).view(2, 3)
     assert torch.equal(comm.all_gather_rows(t), t)
     assert comm.shard_range(10, 2, 4) == (6, 8) and comm.shard_range(2, 3, 4) == (2, 2)
+
+
+def _pred_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disprcnn_amd.structures import BoxList
+        preds = {}
+        for img in ([0, 3] if rank == 0 else [1]):                 # rank 1 holds one image, image 2 is missing everywhere
+            r = img + 1
+            bl = BoxList(torch.arange(r * 4, dtype=torch.float32).reshape(r, 4) + 100 * img, (320 + img, 96))
+            bl.add_field("scores", torch.full((r,), 0.1 * img))
+            bl.add_field("disparity", torch.full((r, 2, 3), float(img)))
+            if rank == 0:
+                bl.add_field("labels", torch.ones(r, dtype=torch.int64))      # not on rank 1: must not travel
+            preds[img] = bl
+        got = comm.gather_predictions(preds)
+        if rank == 0:
+            q.put([(b.size, len(b), b.bbox[0, 0].item(), sorted(b.fields()), b.get_field("disparity")[0, 0, 0].item(),
+                    round(b.get_field("scores")[0].item(), 3)) for b in got])
+        else:
+            assert got is None
+            q.put("none")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_predictions_two_ranks():
+    """Tensor gather of per-image predictions (the reference pickles them): ordered by image id on rank 0, variable ROI
+    counts, a field missing on one rank is dropped, image sizes travel."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pred_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    main = next(r for r in res if r != "none")
+    assert [m[0] for m in main] == [(320, 96), (321, 96), (323, 96)]
+    assert [m[1] for m in main] == [1, 2, 4]
+    assert [m[2] for m in main] == [0.0, 100.0, 300.0]
+    assert all(m[3] == ["disparity", "scores"] for m in main)
+    assert [m[4] for m in main] == [0.0, 1.0, 3.0] and [m[5] for m in main] == [0.0, 0.1, 0.3]
