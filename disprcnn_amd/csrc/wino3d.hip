@@ -137,8 +137,10 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
 #pragma unroll
         for (int q = 0; q < kFill; ++q) *(f32x4*)(dst + (q * 256 + (int)threadIdx.x) * 4) = fill[q];
     };
-    // half-step boundary hs: publish the weights of hs+1, wait for everyone (readers of hs-1 done, weights of hs visible),
-    // fetch the weights of hs+2.  Only the LDS counter is drained: global loads stay in flight across the barrier.
+    // half-step boundary hs: publish the weights of hs+1, wait for everyone, fetch the weights of hs+2.  The barrier makes
+    // slab hs+1 visible for the next half step and guarantees that nobody still reads slab hs+2 = hs-1 when it is overwritten at
+    // the next boundary (slab hs itself became visible at the previous barrier; reading it ahead of this one measured slower).
+    // Only the LDS counter is drained: global loads stay in flight across the barrier.
     auto boundary = [&](int hs) __attribute__((always_inline)) {
         fill_store((hs + 1) % 3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -220,6 +222,13 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
         load_w(wfA, slab_a, 0);
         load_row(r2a, r2b, sa1, sb1, 2, geo1.xo);
         load_w(wfB, slab_a, 1);
+        // h butterfly, rows 1..3 of this step's B fragments (row 0 was finished at the end of the previous step): in the shadow
+        // of row 0's MFMAs, before tn[1..3] are overwritten by the next step's rows
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            v[1][w] = tn[1][w] + tn[2][w]; v[2][w] = tn[2][w] - tn[1][w]; v[3][w] = tn[1][w] - tn[3][w];
+            asm volatile("" : "+v"(v[1][w]), "+v"(v[2][w]), "+v"(v[3][w]));
+        }
         bfly_row(tn[0], r0a, r0b, sgn);
         WN_MFMA_ROW(0, wfA)
         __builtin_amdgcn_sched_barrier(0);
@@ -238,11 +247,9 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
         bfly_row(tn[3], r3a, r3b, sgn);
         WN_MFMA_ROW(3, wfB)
         __builtin_amdgcn_sched_barrier(0);
-        // h butterfly: the next step's B fragments
+        // h butterfly, row 0 of the next step's B fragments (its MFMAs come first); rows 1..3 follow inside that step
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            v[0][w] = tn[0][w] - tn[2][w]; v[1][w] = tn[1][w] + tn[2][w]; v[2][w] = tn[2][w] - tn[1][w]; v[3][w] = tn[1][w] - tn[3][w];
-        }
+        for (int w = 0; w < 4; ++w) v[0][w] = tn[0][w] - tn[2][w];
         c0 = c1; c1 = c2; geo0 = geo1; geo1 = geo2;
     };
     // end of a depth frequency: its in-plane inverse is parked in LDS; the last one combines the four along depth
