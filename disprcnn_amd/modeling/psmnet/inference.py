@@ -12,11 +12,15 @@ from ...structures.disparity import DisparityMap
 
 
 def sanity_check(left_predictions, right_predictions):
-    assert len(left_predictions) == len(right_predictions)
-    assert all(isinstance(l, BoxList) for l in left_predictions)
-    assert all(isinstance(r, BoxList) for r in right_predictions)
-    assert all(len(l) == len(r) for l, r in zip(left_predictions, right_predictions))
-    assert all(l.size == r.size for l, r in zip(left_predictions, right_predictions))
+    """The preconditions the reference asserts (inference.py:10-15): paired lists of BoxLists, image by image the same number
+    of ROIs and the same image size."""
+    if len(left_predictions) != len(right_predictions):
+        raise AssertionError(f"{len(left_predictions)} left vs {len(right_predictions)} right predictions")
+    for k, (lp, rp) in enumerate(zip(left_predictions, right_predictions)):
+        if not (isinstance(lp, BoxList) and isinstance(rp, BoxList)):
+            raise AssertionError(f"image {k}: predictions must be BoxLists")
+        if len(lp) != len(rp) or lp.size != rp.size:
+            raise AssertionError(f"image {k}: left {len(lp)} ROIs on {lp.size}, right {len(rp)} ROIs on {rp.size}")
 
 
 class DisparityMapProcessor:
