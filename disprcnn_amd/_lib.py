@@ -69,6 +69,8 @@ _SIGS = {
     "drc_conv3d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_disparity_paste_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "drc_roi_depth_maps_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "drc_conv2d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_pack_weights_wino2d": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_pack_weights_wino": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_conv2d_k1_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv2d_k3_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),

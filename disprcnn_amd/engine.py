@@ -184,6 +184,21 @@ def pack_weight_wino(w, transposed=False, flip=False):
     return out
 
 
+def pack_weight_wino2d(w, transposed=False, flip=False):
+    """3x3 weights [Cout,Cin,3,3] (or [Cin,Cout,3,3] with transposed; flip reverses the taps) -> Winograd F(2,3)^2 transformed
+    [16 frequency points][cb_in][cout_pad][16] (drc_pack_weights_wino2d): the packing of wino2d.hip."""
+    w = w.detach().contiguous().float()
+    require_gpu(w, "pack_weight_wino2d")
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("pack_weight_wino2d expects a 3x3 kernel")
+    a, b = w.shape[:2]
+    cout, cin = (b, a) if transposed else (a, b)
+    out = torch.empty(16, (cin + CB - 1) // CB, cout_pad_of(cout), 16, dtype=torch.float32, device=w.device)
+    st = _lib.lib().drc_pack_weights_wino2d(_ptr(w), cout, cin, int(transposed), int(flip), _ptr(out), _stream_ptr(w.device))
+    _lib.check(st, "drc_pack_weights_wino2d")
+    return out
+
+
 def pack_conv_weight(w, transposed=False):
     """The packing the engine's plan for this convolution expects (pointwise for 1x1 Conv2d, tap layout otherwise)."""
     return pack_weight_pw(w) if is_pointwise(w.shape, transposed) else pack_weight(w, transposed)
@@ -356,7 +371,7 @@ class ConvPlan:
     def pack16(self, w, transposed=False, flip=False):
         """The weight packing this plan's LDS-free kernel reads (None when the plan runs an LDS-staged kernel)."""
         if self.wino:
-            return pack_weight_wino(w, transposed, flip)
+            return pack_weight_wino2d(w, transposed, flip) if self.c2d else pack_weight_wino(w, transposed, flip)
         if self.direct and (self.slide or self.down or self.c2d):
             return pack_layouts(w, transposed, flip, want_tap=False)[1]
         return None
@@ -364,7 +379,8 @@ class ConvPlan:
     def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
         p = self.p
         if self.direct and (self.slide or self.down or self.c2d):
-            if w16 is None or (w16.shape[0] == 64) != self.wino:
+            points = (16 if self.c2d else 64) if self.wino else (9 if self.c2d else 27)
+            if w16 is None or w16.shape[0] != points:
                 raise ValueError("this plan runs an LDS-free kernel: pass w16 = plan.pack16(weight)")
             w = w16
         relu_saved = p.relu
@@ -388,7 +404,10 @@ class ConvPlan:
             e0.record(torch.cuda.current_stream(self.device))
         if (w.dim() == 3) != self.pointwise:
             raise ValueError("weights are not in the packing this plan expects (engine.pack_conv_weight)")
-        if self.direct and self.c2d:
+        if self.wino and self.c2d:
+            st = _lib.lib().drc_conv2d_k3_wino_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv2d_k3_wino_fwd")
+        elif self.direct and self.c2d:
             st = _lib.lib().drc_conv2d_k3_direct_fwd(C.byref(p), self.c2d_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv2d_k3_direct_fwd")
         elif self.direct and self.down:
@@ -426,6 +445,8 @@ class ConvPlan:
 
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
 WINO = {"enabled": True}      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
+WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
+          "min_chunks": 64}   # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel)
 DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
 DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/exp_conv.py)
         "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)
@@ -566,6 +587,13 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
             CT //= 2
         pl.c2d_ct = CT
         pl.kname = "conv2ddirect_kernel<%d,%d>" % (nvt, CT)
+        # stride-1, undilated layers on even maps with enough tile groups for every block: Winograd F(2x2,3x3) (wino2d.hip)
+        wct = 2 if ct % 2 == 0 else 1
+        if (WINO2D["enabled"] and stride == 1 and dilation == 1 and pad == 1 and not (y.H | y.W) & 1 and
+                x.N * x.n_stride * 4 < 2 ** 32 and x.N * (y.H // 2) * (y.W // 2) // 64 >= WINO2D["min_chunks"]):
+            pl.wino = True
+            pl.slide_ct = wct
+            pl.kname = "wino2d_kernel<%d>" % wct
     elif k == 3 and stride == 1 and pad == dilation and TAP2D["enabled"]:
         tile = choose_tile_2d(y.H, y.W, dilation)
         if tile is not None:

@@ -11,6 +11,7 @@ class _Site:
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
         self.w = E.pack_conv_weight(w)
         self.w16 = E.pack_weight_t16(w) if tuple(w.shape[2:]) == (3, 3) else None      # 3x3 layers: LDS-free kernel's packing
+        self._weight, self._ww = w, None
         cp = E.cout_pad_of(w.shape[0])
         if bn is not None:
             self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
@@ -21,6 +22,15 @@ class _Site:
             self.shift = torch.zeros(cp, device=device)
             if conv.bias is not None:
                 self.shift[: conv.bias.numel()] = conv.bias.detach().to(device).float()
+
+
+def _w16_for(site, plan):
+    """The LDS-free packing `plan` reads: t16, or the Winograd-transformed weights (built on first use)."""
+    if not plan.wino:
+        return site.w16
+    if site._ww is None:
+        site._ww = plan.pack16(site._weight)
+    return site._ww
 
 
 def _half(n):       # conv k1/k3 stride 2 (pad k//2) and max_pool2d(1,2,0): floor((n-1)/2)+1
@@ -132,7 +142,7 @@ class BackboneRuntime:
 
         def conv(plan, x_, y_, res=None):
             c = Wt[plan]
-            p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None, w16=c.w16)
+            p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None, w16=_w16_for(c, p[plan]))
 
         t["img"].from_dense(x)
         conv("stem", "img", "stem")

@@ -151,6 +151,12 @@ int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_w
  * kernels' by fp32 rounding only (about twice the direct kernel's own error against fp64). */
 int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* Conv2d 3x3, stride 1, dilation 1, pad 1 (same parameter block as drc_conv2d_k3_direct_fwd; R, WT ignored) as Winograd
+ * F(2x2, 3x3): 16 instead of 36 multiplies per (cin, cout) pair and 2x2 output tile.  Needs even OH, OW and
+ * N * x_n_stride * 4 < 2^32; weights from drc_pack_weights_wino2d ([16 = xh*4+xw][ceil(Cin/16)][cout_pad][16]). */
+int drc_conv2d_k3_wino_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+int drc_pack_weights_wino2d(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream);
+
 /* Winograd weight transform U = (G x G x G) g of a 3x3x3 kernel, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]:
  * w [Cout][Cin][27] (transposed: [Cin][Cout][27]; flip reverses the taps -- data gradients) ->
  * out [64 = (xd*4+xh)*4+xw][ceil(Cin/16)][cout_pad][16], zero-padded. */

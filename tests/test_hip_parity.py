@@ -170,6 +170,51 @@ def test_conv3d_winograd_kernel_vs_oracle(dev, n, cin, cout, dims, with_res):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("n,cin,cout,hw,with_res", [(4, 32, 32, (112, 112), True), (3, 64, 64, (56, 56), False), (2, 128, 128, (28, 28), True),
+                                                     (5, 7, 33, (2, 30), True), (9, 64, 32, (4, 4), False), (2, 20, 40, (8, 4), True),
+                                                     (1, 16, 16, (2, 2), False)])
+def test_conv2d_winograd_kernel_vs_oracle(dev, n, cin, cout, hw, with_res):
+    """wino2d.hip (Winograd F(2x2,3x3), the default for stride-1 undilated 3x3 Conv2d layers on even maps with enough work)
+    against the direct convolution: partial tile groups, 1..4 cout groups, channel counts that are not multiples of 16, with
+    and without the residual.  Same tolerance as the direct kernels."""
+    from disprcnn_amd import ops, engine as E
+    x = synth.hash_uniform(f"W2{cin}{cout}{hw}:x", (n, cin) + hw)
+    w = synth.hash_uniform(f"W2{cin}{cout}:w", (cout, cin, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("W2:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("W2:b", (cout,), -0.5, 0.5)
+    res = synth.hash_uniform(f"W2{cout}{hw}:r", (n, cout) + hw) if with_res else None
+    ref = F.conv2d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref + res) if with_res else ref
+    saved = (E.WINO2D["enabled"], E.WINO2D["min_chunks"])
+    E.WINO2D["enabled"], E.WINO2D["min_chunks"] = True, 0
+    try:
+        xb = E.Blocked(n, cin, 1, *hw, 0, 1, 1, dev)
+        plan = E.plan_conv2d(xb, E.Blocked(n, cout, 1, *hw, 0, 1, 1, dev), 3, 1, 1, 1, cout, True)
+        got = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, 1, 1, with_res, res.to(dev) if with_res else None)
+    finally:
+        E.WINO2D["enabled"], E.WINO2D["min_chunks"] = saved
+    assert plan.wino and plan.c2d, "shape was expected to take the 2D Winograd kernel"
+    _close(got, ref)
+
+
+def test_winograd2d_weight_transform_vs_oracle(dev):
+    """drc_pack_weights_wino2d against U = (G x G) g in float64, incl. the in/out swap and tap flip of the data gradient."""
+    from disprcnn_amd import engine as E
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    for cout, cin, transposed, flip in [(32, 32, False, False), (20, 40, False, False), (24, 16, True, True)]:
+        w = synth.hash_uniform(f"WT2{cout}{cin}", (cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), -1, 1)
+        got = E.pack_weight_wino2d(w.to(dev), transposed, flip).cpu()
+        wc = w.transpose(0, 1) if transposed else w
+        wc = wc.flip(2, 3) if flip else wc
+        U = torch.einsum("ai,bj,ocij->aboc", G, G, wc.double())                   # [xh][xw][cout][cin]
+        cb, cp = (cin + 15) // 16, (cout + 15) // 16 * 16
+        ref = torch.zeros(16, cb * 16, cp, dtype=torch.float64)
+        ref[:, :cin, :cout] = U.reshape(16, cout, cin).transpose(1, 2)
+        ref = ref.view(16, cb, 16, cp).permute(0, 1, 3, 2)
+        assert got.shape == ref.shape
+        assert (got.double() - ref).abs().max().item() < 1e-6
+
+
 def test_winograd_weight_transform_vs_oracle(dev):
     """drc_pack_weights_wino against U = (G x G x G) g in float64, incl. the in/out swap and tap flip of the data gradient."""
     from disprcnn_amd import engine as E

@@ -131,3 +131,28 @@ def test_stride1_conv3d_kernel_selection():
     w = torch.zeros(32, 32, 3, 3, 3)
     with pytest.raises(ValueError):
         pl.run(x, E.pack_weight(w), torch.ones(32), torch.zeros(32), y, w16=E.pack_weight_t16(w))
+
+
+def test_conv2d_3x3_kernel_selection():
+    """2D Winograd for stride-1 undilated 3x3 layers on even maps with enough tile groups; the direct kernel for odd maps,
+    strides, dilations and small problems (the backbone's deep stages)."""
+    from disprcnn_amd import engine as E
+    dev = torch.device("cpu")
+
+    def plan(n, c, hw, stride=1, dil=1):
+        x = E.Blocked(n, c, 1, *hw, 0, max(dil, 1), max(dil, 1), dev)
+        oh, ow = (hw[0] - 1) // stride + 1, (hw[1] - 1) // stride + 1
+        return E.plan_conv2d(x, E.Blocked(n, c, 1, oh, ow, 0, 1, 1, dev), 3, stride, dil, dil, c, True)
+
+    assert plan(32, 32, (112, 112)).kname == "wino2d_kernel<2>"
+    assert plan(32, 128, (56, 56)).wino
+    assert not plan(2, 64, (94, 311)).wino            # odd width
+    assert not plan(2, 256, (24, 78)).wino            # too few tile groups per cout group
+    assert not plan(32, 32, (112, 112), stride=2).wino
+    assert not plan(32, 128, (56, 56), dil=2).wino
+    saved = E.WINO2D["enabled"]
+    E.WINO2D["enabled"] = False
+    try:
+        assert plan(32, 32, (112, 112)).kname.startswith("conv2ddirect")
+    finally:
+        E.WINO2D["enabled"] = saved
