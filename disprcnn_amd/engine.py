@@ -446,7 +446,8 @@ class ConvPlan:
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
 WINO = {"enabled": True}      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
 WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
-          "min_chunks": 64}   # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel)
+          "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
+                              #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
 DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
 DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/exp_conv.py)
         "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)

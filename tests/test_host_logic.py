@@ -147,7 +147,8 @@ def test_conv2d_3x3_kernel_selection():
     assert plan(32, 32, (112, 112)).kname == "wino2d_kernel<2>"
     assert plan(32, 128, (56, 56)).wino
     assert not plan(2, 64, (94, 311)).wino            # odd width
-    assert not plan(2, 256, (24, 78)).wino            # too few tile groups per cout group
+    assert plan(2, 256, (24, 78)).wino                # a deep backbone stage: few tile groups, still ahead of the direct kernel
+    assert not plan(2, 512, (12, 38)).wino            # too few tile groups per cout group
     assert not plan(32, 32, (112, 112), stride=2).wino
     assert not plan(32, 128, (56, 56), dil=2).wino
     saved = E.WINO2D["enabled"]
