@@ -6,7 +6,7 @@
 //   drc_roi_align_bwd   : its adjoint (csrc/cuda/ROIAlign_cuda.cu:177-254), atomicAdd scatter.
 //   drc_align_roi_pairs : the per-ROI box arithmetic of prepare_psmnet_input_and_target (disprcnn3d.py:118-146) on the
 //                         device, so no .tolist() host sync sits between the 2D detections and the crops.
-// All HBM-bound and tiny next to the regressor: one thread per output element, coalesced along x.
+// All HBM-bound and tiny next to the regressor; lanes run along x.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,17 +37,25 @@ __device__ __forceinline__ Bilin bilinear_setup(float y, float x, int height, in
     return b;
 }
 
+// One thread per output PIXEL (roi k, channel group, ph, pw), CC channels at a time: the sample geometry (4 positions + 4
+// weights per sample point) is computed once and applied to every channel of the group, lanes run along pw so the CC plane
+// stores are coalesced and neighbouring lanes gather neighbouring image columns (bin_w <= 1 px for rois up to 224 px wide).
+// Arithmetic per (sample, channel) and the accumulation order are the reference's, and the build uses -ffp-contract=off, so
+// the un-normalised output is BIT-IDENTICAL to csrc/cpu/ROIAlign_cpu.cpp (tests/golden/roi_golden.npz).
+template <int CC>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(const float* __restrict__ in, const float* __restrict__ rois,
                                                                  float* __restrict__ out, int K, int C, int H, int W, int PH, int PW,
                                                                  float spatial_scale, int sampling_ratio,
                                                                  const float* __restrict__ mean, const float* __restrict__ stdv) {
-    const long total = (long)K * C * PH * PW;
+    const int CG = C / CC;
+    const long total = (long)K * CG * PH * PW;
+    const long plane = (long)H * W, oplane = (long)PH * PW;
     for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
         long t = idx;
         const int pw = (int)(t % PW); t /= PW;
         const int ph = (int)(t % PH); t /= PH;
-        const int c = (int)(t % C);
-        const int k = (int)(t / C);
+        const int cg = (int)(t % CG);
+        const int k = (int)(t / CG);
         const float* r = rois + (long)k * 5;
         const int b = (int)r[0];
         // no rounding of the roi (ROIAlign_cpu.cpp:146-150); malformed rois forced to 1x1 (:157-158)
@@ -58,19 +66,29 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(const float* __
         const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
         const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
         const float count = (float)(gh * gw);
-        const float* src = in + ((long)b * C + c) * H * W;
-        float acc = 0.f;
+        const float* src = in + ((long)b * C + cg * CC) * plane;
+        float acc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = 0.f;
         for (int iy = 0; iy < gh; ++iy) {
             const float yy = rsh + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
             for (int ix = 0; ix < gw; ++ix) {
                 const float xx = rsw + pw * bin_w + (ix + 0.5f) * bin_w / (float)gw;
                 const Bilin q = bilinear_setup(yy, xx, H, W);
-                acc += q.w1 * src[q.p1] + q.w2 * src[q.p2] + q.w3 * src[q.p3] + q.w4 * src[q.p4];
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const float* sc = src + c * plane;
+                    acc[c] += q.w1 * sc[q.p1] + q.w2 * sc[q.p2] + q.w3 * sc[q.p3] + q.w4 * sc[q.p4];
+                }
             }
         }
-        acc /= count;
-        if (mean) acc = (acc - mean[c]) / stdv[c];
-        out[idx] = acc;
+        float* dst = out + ((long)k * C + cg * CC) * oplane + (long)ph * PW + pw;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            float v = acc[c] / count;
+            if (mean) v = (v - mean[cg * CC + c]) / stdv[cg * CC + c];
+            dst[c * oplane] = v;
+        }
     }
 }
 
@@ -147,9 +165,16 @@ int drc_roi_align_fwd(const float* input, const float* rois, float* out, int K, 
     if ((mean == nullptr) != (stdv == nullptr)) return -2;
     if (K == 0) return 0;   // empty rois -> empty output, nothing launched (ROIAlign_cuda.cu:278-281)
     if (!input || !rois || !out) return -1;
-    const long total = (long)K * C * PH * PW;
-    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, input, rois, out, K, C, H, W,
-                       PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+    const int cc = C % 4 == 0 ? 4 : (C % 3 == 0 ? 3 : 1);       // channels per thread (images: 3; FPN levels: 4)
+    const long total = (long)K * (C / cc) * PH * PW;
+    const dim3 grid(grid_for(total)), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (cc == 4)
+        hipLaunchKernelGGL(roi_align_fwd_kernel<4>, grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+    else if (cc == 3)
+        hipLaunchKernelGGL(roi_align_fwd_kernel<3>, grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+    else
+        hipLaunchKernelGGL(roi_align_fwd_kernel<1>, grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv);
     return (int)hipGetLastError();
 }
 

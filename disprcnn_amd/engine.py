@@ -37,7 +37,7 @@ def require_gpu(t, what):
 class Blocked:
     """Channel-blocked, zero-haloed tensor float[N][CB][D+2pd][H+2ph][W+2pw][16]."""
 
-    def __init__(self, N, C_, D, H, W, pd, ph, pw, device):
+    def __init__(self, N, C_, D, H, W, pd, ph, pw, device, storage=None):
         self.N, self.C, self.D, self.H, self.W = N, C_, D, H, W
         self.pd, self.ph, self.pw = pd, ph, pw
         self.cb = (C_ + CB - 1) // CB
@@ -47,7 +47,13 @@ class Blocked:
         self.cb_stride = self.Dp * self.d_stride
         self.n_stride = self.cb * self.cb_stride
         self.numel = N * self.n_stride
-        self.storage = torch.zeros(self.numel + SLACK_FLOATS, dtype=torch.float32, device=device)
+        if storage is None:
+            self.storage = torch.zeros(self.numel + SLACK_FLOATS, dtype=torch.float32, device=device)
+        else:
+            # a prefix view of a larger zero-haloed tensor of the same per-unit geometry (WorkspacePool): the first N units
+            if storage.numel() < self.numel + SLACK_FLOATS:
+                raise ValueError("Blocked: the given storage is too small for this geometry")
+            self.storage = storage.narrow(0, 0, self.numel + SLACK_FLOATS)
         self.device = device
 
     @property
@@ -76,6 +82,55 @@ class Blocked:
                                                  self.pd, self.ph, self.pw, _stream_ptr(self.device))
             _lib.check(st, "drc_blocked_to_dense")
         return out
+
+
+def bucket_units(n):
+    """Capacity bucket of a unit count: the smallest of {2^k, 3*2^(k-1)} >= n (at most 1/3 of a pool is idle)."""
+    n = max(int(n), 1)
+    k = 1
+    while k < n:
+        if k >= 2 and k + k // 2 >= n:
+            return k + k // 2
+        k *= 2
+    return k
+
+
+class WorkspacePool:
+    """HBM behind the workspaces of ONE geometry (per-unit dims fixed; unit = ROI pair or image).
+
+    Detection output has a different ROI count on every image (BASELINE configs[4]); a workspace per exact count would keep
+    a full set of zero-haloed activations alive for every count ever seen.  The pool instead owns each named tensor ONCE,
+    sized for `cap` units; the workspace of any N <= cap is a set of prefix views (units are outermost in the blocked layout,
+    the halo is zeroed at allocation and never written, so the first N units of a bigger tensor are a valid tensor).  A
+    count above `cap` replaces the pool by a bigger one (PSMNetRuntime).  `gen` counts the forward passes that used the
+    pool: a backward whose forward's generation is no longer current would read overwritten activations and refuses."""
+
+    def __init__(self, cap, device):
+        self.cap, self.device = int(cap), device
+        self.full = {}          # name -> Blocked sized for cap units
+        self.flat = {}          # name -> dense [cap, ...] tensor
+        self.gen = 0
+
+    def blocked(self, name, N, C_, D, H, W, pd, ph, pw):
+        if N > self.cap:
+            raise ValueError("WorkspacePool: more units than the pool was sized for")
+        full = self.full.get(name)
+        if full is None:
+            full = self.full[name] = Blocked(self.cap, C_, D, H, W, pd, ph, pw, self.device)
+        elif (full.C, full.D, full.H, full.W, full.pd, full.ph, full.pw) != (C_, D, H, W, pd, ph, pw):
+            raise ValueError(f"WorkspacePool: tensor {name!r} requested with another geometry")
+        return Blocked(N, C_, D, H, W, pd, ph, pw, self.device, storage=full.storage)
+
+    def dense(self, name, N, *shape):
+        full = self.flat.get(name)
+        if full is None:
+            full = self.flat[name] = torch.empty(self.cap, *shape, dtype=torch.float32, device=self.device)
+        elif tuple(full.shape[1:]) != tuple(shape):
+            raise ValueError(f"WorkspacePool: tensor {name!r} requested with another shape")
+        return full[:N]
+
+    def nbytes(self):
+        return 4 * (sum(b.storage.numel() for b in self.full.values()) + sum(t.numel() for t in self.flat.values()))
 
 
 class BlockedSlice:

@@ -5,10 +5,14 @@ Graph restated from the reference (stackhourglass.py:106-174, submodule.py:106-1
 schedule of launches over blocked, zero-haloed tensors.  Workspaces and launch plans are cached
 per input shape; halos are zeroed once at allocation and never written again.
 """
+from collections import OrderedDict
+
 import torch
 
 from ... import engine as E
 from .submodule import SPP_BRANCHES, TRUNK_STAGES
+
+WS_MAX_PLANS = 48        # launch-plan sets kept per runtime (one per exact unit count; they hold views, not memory)
 
 
 class _Conv:
@@ -68,12 +72,59 @@ class PSMNetRuntime:
         self._weights_version = None
         self._folds_version = None
         self._w = None
-        self._ws = {}      # workspaces: key -> dict of tensors/plans
+        self._ws = OrderedDict()   # workspaces: key (incl. the exact unit count) -> dict of tensor views/plans, LRU-capped
+        self._pools = {}           # geometry key (no unit count) -> E.WorkspacePool owning the HBM, sized for the largest count seen
         self._training = False
         self._tape = None       # list of recorded ops while a differentiable train-mode forward runs
 
     def invalidate(self):
         self._weights_version = None
+
+    # ------------------------------------------------------------------ bounded workspaces
+    def _pool_for(self, gkey, n):
+        """The pool of one geometry, grown (replaced) when a unit count exceeds its capacity; workspaces that viewed the old
+        pool are dropped with it, so HBM use is that of the largest count seen, not the sum over all counts seen."""
+        pool = self._pools.get(gkey)
+        if pool is None or pool.cap < n:
+            if pool is not None:
+                for k in [k for k, w in self._ws.items() if w.get("pool") is pool]:
+                    del self._ws[k]
+            pool = self._pools[gkey] = E.WorkspacePool(E.bucket_units(n), self.device)
+        return pool
+
+    def _ws_get(self, key):
+        ws = self._ws.get(key)
+        if ws is not None:
+            self._ws.move_to_end(key)
+        return ws
+
+    def _ws_put(self, key, ws):
+        self._ws[key] = ws
+        while len(self._ws) > WS_MAX_PLANS:
+            self._ws.popitem(last=False)
+        return ws
+
+    def workspace_bytes(self):
+        return sum(p.nbytes() for p in self._pools.values())
+
+    @staticmethod
+    def _stamp(*wss):
+        """A forward pass is about to overwrite these workspaces' tensors: advance their pools' generation."""
+        for ws in wss:
+            ws["pool"].gen += 1
+
+    @staticmethod
+    def _generations(*wss):
+        return [(ws["pool"], ws["pool"].gen) for ws in wss]
+
+    @staticmethod
+    def _check_generations(gens):
+        for pool, gen in gens:
+            if pool.gen != gen:
+                raise RuntimeError(
+                    "PSMNet backward: the workspace of this forward pass was reused by a later forward (another batch of the "
+                    "same geometry, or an eval pass) before backward() ran, so the saved activations are gone. Call backward() "
+                    "before the next forward of this model (one forward/backward pair in flight per geometry).")
 
     # ------------------------------------------------------------------ weights
     def _version(self):
@@ -149,7 +200,7 @@ class PSMNetRuntime:
         yt = t[y]
         raw = ws.setdefault("raw", {}).get(plan)
         if raw is None:
-            raw = E.Blocked(yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw, self.device)
+            raw = ws["pool"].blocked(("raw", plan), yt.N, yt.C, yt.D, yt.H, yt.W, yt.pd, yt.ph, yt.pw)
             ws["raw"][plan] = raw
         pl.run(t[x], c.w, c.unit_scale, c.zero_shift, raw, None, relu=False, w16=c.w16_for(pl))
         bn = c.bn
@@ -177,25 +228,28 @@ class PSMNetRuntime:
     # ------------------------------------------------------------------ 3D regressor
     def _ws3d(self, N, Dp, Hp, Wp):
         key = ("3d", N, Dp, Hp, Wp)
-        ws = self._ws.get(key)
+        ws = self._ws_get(key)
         if ws is not None:
             return ws
-        dev = self.device
-        B = lambda c, d, h, w: E.Blocked(N, c, d, h, w, 1, 1, 1, dev)
+        pool = self._pool_for(("3d", Dp, Hp, Wp), N)
         full = (Dp, Hp, Wp)
         half = tuple(-(-s // 2) for s in full)
         quart = tuple(-(-s // 2) for s in half)
         if tuple(2 * s for s in half) != full or tuple(2 * s for s in quart) != half:
             raise ValueError(f"cost-volume dims {full} must be divisible by 4 (D,H,W multiples of 16; SURVEY 8)")
         t = {}
-        t["cost"] = B(64, *full)
+
+        def B(name, c, d, h, w):
+            t[name] = pool.blocked(name, N, c, d, h, w, 1, 1, 1)
+
+        B("cost", 64, *full)
         for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t1", "cls_t2", "cls_t3"):
-            t[n] = B(32, *full)
+            B(n, 32, *full)
         for k in (1, 2, 3):
-            t[f"hg{k}.c1"] = B(64, *half); t[f"hg{k}.pre"] = B(64, *half); t[f"hg{k}.post"] = B(64, *half)
-            t[f"hg{k}.c3"] = B(64, *quart); t[f"hg{k}.c4"] = B(64, *quart)
+            B(f"hg{k}.c1", 64, *half); B(f"hg{k}.pre", 64, *half); B(f"hg{k}.post", 64, *half)
+            B(f"hg{k}.c3", 64, *quart); B(f"hg{k}.c4", 64, *quart)
         for k in (1, 2, 3):
-            t[f"costk{k}"] = torch.empty(N, *full, dtype=torch.float32, device=dev)
+            t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
         p = {}
         p["dres0.0"] = E.plan_conv3d(t["cost"], t["d0a"], 1, 32, True)
         p["dres0.2"] = E.plan_conv3d(t["d0a"], t["cost0a"], 1, 32, True)
@@ -210,9 +264,8 @@ class PSMNetRuntime:
             p[f"hg{k}.conv5"] = E.plan_deconv3d(t[f"hg{k}.c4"], t[f"hg{k}.post"], 64, True)
             p[f"hg{k}.conv6"] = E.plan_deconv3d(t[f"hg{k}.post"], t[f"out{k}"], 32, False)
             p[f"classif{k}.0"] = E.plan_conv3d(t[f"out{k}"], t[f"cls_t{k}"], 1, 32, True)
-        ws = dict(t=t, p=p, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
-        self._ws[key] = ws
-        return ws
+        ws = dict(t=t, p=p, pool=pool, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
+        return self._ws_put(key, ws)
 
     def _regress(self, ws, W):
         """dres0..dres4 + classif heads on ws['t']['cost'] -> dense cost3 [N,D',H',W'] (reference :130-144)."""
@@ -282,21 +335,24 @@ class PSMNetRuntime:
             return (z, z.clone(), z.clone()) if training else z       # empty ROI batch (reference: disprcnn3d.py:272-275)
         Wt = self._compile()
         ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
+        self._stamp(ws)
         E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
         costs = self._regress(ws, Wt)
         self._last_train = (ws, Wt, costs, mx, mn, (H, W))
+        self._last_gens = self._generations(ws)
         return self._heads(costs, N, H, W, mx, mn, training)
 
     # ------------------------------------------------------------------ 2D feature CNN
     def _ws2d(self, N, H, W, side=None):
         key = ("2d", N, H, W) if side is None else ("2d", N, H, W, side)
-        ws = self._ws.get(key)
+        ws = self._ws_get(key)
         if ws is not None:
             return ws
         if H % 4 or W % 4 or H // 4 < 56 or W // 4 < 56:
             raise ValueError("PSMNet needs H,W multiples of 4 and >= 224 (fixed AvgPool2d(56), reference submodule.py:76)")
-        dev = self.device
-        B2 = lambda c, h, w, pad=1: E.Blocked(N, c, 1, h, w, 0, pad, pad, dev)
+        pool = self._pool_for(("2d", H, W, side), N)
+        names = iter(range(1 << 30))
+        B2 = lambda c, h, w, pad=1: pool.blocked(("t", next(names)), N, c, 1, h, w, 0, pad, pad)   # allocation order is deterministic
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         t, p = {}, {}
         t["img"] = B2(3, H, W)
@@ -347,10 +403,9 @@ class PSMNetRuntime:
         t["feat"] = B2(32, H4, W4, 1)
         p["fe.lastconv.0"] = E.plan_conv2d(t["cat"], t["last0"], 3, 1, 1, 1, 128, True)
         p["fe.lastconv.2"] = E.plan_conv2d(t["last0"], t["feat"], 1, 1, 0, 1, 32, False)
-        ws = dict(t=t, p=p, sched=sched, spp=spp, skip=skip, dims=(H4, W4),
+        ws = dict(t=t, p=p, pool=pool, sched=sched, spp=spp, skip=skip, dims=(H4, W4),
                   flops=sum(pl.flops for pl in p.values()))
-        self._ws[key] = ws
-        return ws
+        return self._ws_put(key, ws)
 
     def _features(self, ws, W, images):
         """feature_extraction on a batch of images (left and right stacked) -> blocked [N,32,H/4,W/4] (halo 1)."""
@@ -408,12 +463,16 @@ class PSMNetRuntime:
         if training:
             # the reference runs feature_extraction(left) and feature_extraction(right) as two calls (stackhourglass.py:112-113):
             # batch statistics and running-stat updates are per call, so the two views must not share a batch here
-            featL = self._features(self._ws2d(N, H, W, "L"), Wt, left)
-            featR = self._features(self._ws2d(N, H, W, "R"), Wt, right)
+            wsL, wsR = self._ws2d(N, H, W, "L"), self._ws2d(N, H, W, "R")
+            self._stamp(ws3, wsL, wsR)
+            featL = self._features(wsL, Wt, left)
+            featR = self._features(wsR, Wt, right)
             E.cost_volume_blocked(featL.storage, featR.storage, ws3["t"]["cost"], mn // 4, mx // 4, featL.ph)
-            self._last_train_2d = (self._ws2d(N, H, W, "L"), self._ws2d(N, H, W, "R"))
+            self._last_train_2d = (wsL, wsR)
+            self._last_gens = self._generations(ws3, wsL, wsR)
         else:
             ws2 = self._ws2d(2 * N, H, W)
+            self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, torch.cat((left, right), 0))
             fv = feat.storage
             right_view = fv[N * feat.n_stride:]
@@ -425,7 +484,8 @@ class PSMNetRuntime:
 
 class _RegressorTrainFn(torch.autograd.Function):
     """Differentiable train-mode pass from the feature boundary: forward on the HIP engine (tape recorded), backward by
-    modeling/psmnet/train.py.  One forward/backward pair per input shape may be in flight (workspaces are reused)."""
+    modeling/psmnet/train.py.  One forward/backward pair per geometry may be in flight (workspaces are reused); a backward
+    whose workspace was overwritten by a later forward raises (WorkspacePool.gen)."""
 
     @staticmethod
     def forward(ctx, rt, out_hw, fl, fr, *params):
@@ -433,7 +493,7 @@ class _RegressorTrainFn(torch.autograd.Function):
         rt._need_input_grad = bool(fl.requires_grad or fr.requires_grad)
         try:
             preds = rt._forward_features_impl(fl.detach(), fr.detach(), out_hw, True)
-            ctx.tape, ctx.info = rt._tape, rt._last_train
+            ctx.tape, ctx.info, ctx.gens = rt._tape, rt._last_train, rt._last_gens
         finally:
             rt._tape = None
         ctx.rt, ctx.params, ctx.need_in = rt, params, rt._need_input_grad
@@ -444,6 +504,7 @@ class _RegressorTrainFn(torch.autograd.Function):
     def backward(ctx, g1, g2, g3):
         from .train import RegressorBackward
         rt = ctx.rt
+        rt._check_generations(ctx.gens)
         ws, Wt, costs, mx, mn, out_hw = ctx.info
         bw = RegressorBackward(rt, ws, Wt)
         rt._need_input_grad = ctx.need_in
@@ -466,7 +527,7 @@ class _PSMNetTrainFn(torch.autograd.Function):
         rt._need_input_grad = True          # the cost volume's gradient feeds the 2D CNN
         try:
             preds = rt._forward_images_impl(left.detach(), right.detach(), True)
-            ctx.tape, ctx.info, ctx.ws2 = rt._tape, rt._last_train, rt._last_train_2d
+            ctx.tape, ctx.info, ctx.ws2, ctx.gens = rt._tape, rt._last_train, rt._last_train_2d, rt._last_gens
         finally:
             rt._tape = None
         ctx.rt, ctx.params = rt, params
@@ -477,6 +538,7 @@ class _PSMNetTrainFn(torch.autograd.Function):
         from .train import FeaturesBackward, RegressorBackward
         from ... import ops
         rt = ctx.rt
+        rt._check_generations(ctx.gens)
         ws3, Wt, costs, mx, mn, out_hw = ctx.info
         rt._need_input_grad = True
         bw = RegressorBackward(rt, ws3, Wt)

@@ -20,9 +20,6 @@ from ... import engine as E
 from ..._lib import DrcWgradParams
 
 
-def _zeros_like_blocked(b, device):
-    return E.Blocked(b.N, b.C, b.D, b.H, b.W, b.pd, b.ph, b.pw, device)
-
 
 class Grads:
     """Gradient buffers (Blocked, same geometry as the forward tensors) with assign-or-accumulate bookkeeping."""
@@ -39,7 +36,7 @@ class Grads:
             return E.BlockedSlice(self.get(parent), ft.cb_off, ft.C)
         b = self.buf.get(name)
         if b is None:
-            b = _zeros_like_blocked(ft, self.device)
+            b = self.ws["pool"].blocked(("g", name), ft.N, ft.C, ft.D, ft.H, ft.W, ft.pd, ft.ph, ft.pw)
             self.buf[name] = b
         return b
 
@@ -156,7 +153,7 @@ class RegressorBackward:
             draw = self.ws.setdefault("draw", {}).get(plan)
             if draw is None:
                 halo = (1, 1, 1) if raw.pd > 0 else (0, 2, 2)      # 2D: room for the dilated data-gradient taps
-                draw = E.Blocked(raw.N, raw.C, raw.D, raw.H, raw.W, *halo, self.dev)
+                draw = self.ws["pool"].blocked(("draw", plan), raw.N, raw.C, raw.D, raw.H, raw.W, *halo)
                 self.ws["draw"][plan] = draw
             dres, acc = None, 0
             if res is not None:

@@ -52,6 +52,10 @@ def all_gather_rows(t):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
 
 
+_DTYPE_CODES = (torch.float32, torch.int64, torch.int32, torch.uint8, torch.bool, torch.float16, torch.float64, torch.int16, torch.int8,
+                torch.bfloat16)
+
+
 def gather_predictions(predictions, fields=("scores", "labels", "disparity")):
     """{image_id: BoxList} of this rank -> list of BoxLists ordered by image id on the main process (None elsewhere).
 
@@ -77,15 +81,19 @@ def gather_predictions(predictions, fields=("scores", "labels", "disparity")):
             continue
         parts = [predictions[i].get_field(f) for i in ids]
         shape = next((tuple(p_.shape[1:]) for p_ in parts), None)
-        dtype = next((p_.dtype for p_ in parts), torch.float32)
-        # ranks without images learn the trailing shape from the others: gather it first (rank-independent result)
-        meta = torch.tensor([[len(shape) if shape is not None else -1] + list(shape or ()) + [0] * (8 - len(shape or ()))],
-                            dtype=torch.int64, device=dev)
+        dtype = next((p_.dtype for p_ in parts), None)
+        # ranks without images learn the trailing shape AND the dtype from the others: gather both first (rank-independent
+        # result) -- an empty payload of the wrong dtype would put mismatched byte sizes into all_gather
+        meta = torch.tensor([[len(shape) if shape is not None else -1, _DTYPE_CODES.index(dtype) if dtype is not None else -1]
+                             + list(shape or ()) + [0] * (8 - len(shape or ()))], dtype=torch.int64, device=dev)
         meta = all_gather_rows(meta)
         known = meta[meta[:, 0] >= 0]
         if len(known) == 0:
             continue
-        shape = tuple(int(v) for v in known[0, 1:1 + int(known[0, 0])])
+        if bool((known[:, 1:] != known[0, 1:]).any()):
+            raise RuntimeError(f"gather_predictions: field {f!r} has different dtypes / trailing shapes on different ranks")
+        shape = tuple(int(v) for v in known[0, 2:2 + int(known[0, 0])])
+        dtype = _DTYPE_CODES[int(known[0, 1])]
         local = torch.cat(parts) if parts else torch.zeros((0,) + shape, dtype=dtype, device=dev)
         payload[f] = all_gather_rows(local)
     if not is_main_process():

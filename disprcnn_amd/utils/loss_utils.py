@@ -66,5 +66,7 @@ class PSMLoss(nn.Module):
 
 
 class EndPointErrorLoss(nn.Module):
-    def forward(self, disp_target, disp_pred, mask):
+    def forward(self, disp_target, disp_pred, mask=None):
+        if mask is None:          # reference stereo_utils.py:185-187: no mask = every pixel counts
+            mask = torch.ones_like(disp_target, dtype=torch.uint8)
         return _loss(disp_pred, disp_target, mask)

@@ -116,3 +116,44 @@ def test_gather_predictions_two_ranks():
     assert [m[2] for m in main] == [0.0, 100.0, 300.0]
     assert all(m[3] == ["disparity", "scores"] for m in main)
     assert [m[4] for m in main] == [0.0, 1.0, 3.0] and [m[5] for m in main] == [0.0, 0.1, 0.3]
+
+
+def _pred_empty_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disprcnn_amd.structures import BoxList
+        preds = {}
+        if rank == 0:                                              # fewer images than ranks: rank 1 holds nothing
+            for img, r in ((0, 2), (1, 0), (2, 3)):                # image 1 has no ROIs
+                bl = BoxList(torch.arange(r * 4, dtype=torch.float32).reshape(r, 4), (1242, 375))
+                bl.add_field("scores", torch.linspace(0.5, 1.0, r))
+                bl.add_field("labels", torch.arange(r, dtype=torch.int64) + 10 * img)
+                bl.add_field("disparity", torch.full((r, 4, 4), float(img)))
+                preds[img] = bl
+        got = comm.gather_predictions(preds)
+        if rank == 0:
+            q.put([(len(b), b.get_field("labels").dtype == torch.int64, b.get_field("labels").tolist(), tuple(b.get_field("disparity").shape))
+                   for b in got])
+        else:
+            assert got is None
+            q.put("none")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_predictions_rank_without_images_int64_field():
+    """A rank that holds no image must send an empty payload of the AGREED dtype (int64 'labels'), not float32: mismatched
+    byte sizes in all_gather are an error on gloo and undefined on RCCL."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pred_empty_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    main = next(r for r in res if r != "none")
+    assert [m[0] for m in main] == [2, 0, 3] and all(m[1] for m in main)
+    assert main[0][2] == [0, 1] and main[2][2] == [20, 21, 22]
+    assert main[2][3] == (3, 4, 4)

@@ -157,3 +157,26 @@ def test_conv2d_3x3_kernel_selection():
         assert plan(32, 32, (112, 112)).kname.startswith("conv2ddirect")
     finally:
         E.WINO2D["enabled"] = saved
+
+
+def test_workspace_pool_bucket_and_prefix_views():
+    """Bounded workspaces: capacity buckets waste at most 1/3, a workspace of N <= cap units is a prefix
+    view of the pool's tensor (same per-unit geometry, shared memory), and growing is the only way memory increases."""
+    from disprcnn_amd import engine as E
+    assert [E.bucket_units(n) for n in (0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 16, 17, 25, 33, 100, 256, 257)] == \
+        [1, 1, 2, 3, 4, 6, 6, 8, 12, 12, 16, 16, 24, 32, 48, 128, 256, 384]
+    assert all(n <= E.bucket_units(n) <= max(1.5 * n, 1) for n in range(1, 2000))
+    dev = torch.device("cpu")
+    pool = E.WorkspacePool(6, dev)
+    a = pool.blocked("x", 4, 32, 3, 4, 5, 1, 1, 1)
+    b = pool.blocked("x", 6, 32, 3, 4, 5, 1, 1, 1)
+    assert a.storage.data_ptr() == b.storage.data_ptr() and a.n_stride == b.n_stride and a.numel < b.numel
+    a.view6()[3, 1, 1, 1, 1, 7] = 5.0
+    assert b.view6()[3, 1, 1, 1, 1, 7].item() == 5.0           # same memory
+    n0 = pool.nbytes()
+    pool.blocked("x", 1, 32, 3, 4, 5, 1, 1, 1); pool.dense("c", 5, 3, 4)
+    assert pool.nbytes() == n0 + 4 * 6 * 12                      # a re-request allocates nothing; the dense tensor is sized for cap
+    with pytest.raises(ValueError):
+        pool.blocked("x", 7, 32, 3, 4, 5, 1, 1, 1)               # above capacity: the runtime replaces the pool
+    with pytest.raises(ValueError):
+        pool.blocked("x", 2, 16, 3, 4, 5, 1, 1, 1)               # same name, other geometry
