@@ -6,14 +6,19 @@ synthetic ROI feature pairs per GPU.  Headline workload = BASELINE.json's metric
 112x112 ROI, 48 disparities -> cost volume [64,12,28,28] per ROI, entered at the feature boundary.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N ...        (no WORLD_SIZE in the env: re-launches itself under torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  ROIs are independent units: they are sharded across ranks with no data-path
-collective (weak scaling: fixed ROIs per GPU); a barrier + max-over-ranks brackets the timed region.
+collective (weak scaling: fixed ROIs per GPU); a barrier + max-over-ranks brackets the timed region.  For world > 1 the
+only collective-bearing extra (the train step: one flat gradient all-reduce) runs on EVERY rank; the rank-0-only extras
+contain no collective.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +29,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOPS_PER_VOXEL_3D = 644544          # conv FLOPs (2*MAC) of dres0..classif3 per cost-volume voxel
+FLOPS_2D_PER_IMAGE = 22192734208     # feature_extraction conv FLOPs per 224x224 image
+FLOPS_BACKBONE_PAIR = 250.3e9        # R-50-FPN on one 2x3x375x1242 stereo pair
 PEAK_F32_TFLOPS = 157.3              # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -59,6 +66,76 @@ def cpu_baseline_config_a(sd, budget_s=12.0):
             "sample": f"{n} ROI pairs (batches of 4) of the same Config-A workload, {el:.1f} s wall, torch-CPU fp32 oracle"}
 
 
+def timed_steps(step, steps, warmup, world, sync):
+    """W untimed warm-up steps, then exactly K steps between (barrier + device sync) pairs; MAX over ranks."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    return out, elapsed
+
+
+def max_over_ranks(elapsed, world, dev):
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed
+
+
+def headline(total_rois, elapsed, args, world, N, roofline, cpu, extra):
+    return {
+        "metric": "ROI cost-volumes/sec (112x112x48)", "value": round(total_rois / elapsed, 1), "unit": "ROI cost-volumes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Config A: per ROI pair, features [32,28,28]x2 -> concat cost volume [64,12,28,28] -> "
+                               "3D stacked-hourglass regressor -> trilinear x4 + softmax + soft-argmin -> disparity [112,112]",
+                   "rois_per_step_per_gpu": N, "maxdisp": 48, "mindisp": 0, "parallelism": f"roi-shard x{world} (no collective)",
+                   "weights": "closed-form synthetic (disprcnn_amd.utils.synth), BN stats calibrated fixture"},
+        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+    }
+
+
+def dry_run_cpu(args, world, rank):
+    """The launcher / rank / barrier / max-over-ranks / collective-on-every-rank / rank-0-prints control flow of this file on
+    the gloo backend with a stand-in step (a sleep): what tests/test_bench_flow.py drives at world size 2.  No kernel runs
+    and no throughput is claimed -- the line is marked as a dry run."""
+    from disprcnn_amd.utils.comm import GradientSync
+    dev = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    _, elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup, world, lambda: None)
+    elapsed = max_over_ranks(elapsed, world, dev)
+    # the one collective-bearing extra (train step) is entered by every rank
+    w = torch.nn.Parameter(torch.zeros(1000))
+    w.grad = torch.full((1000,), float(rank + 1))
+    sync = GradientSync([w])
+    t0 = time.perf_counter()
+    sync()
+    allreduce_ms = (time.perf_counter() - t0) * 1e3
+    ok = bool(torch.allclose(w.grad, torch.full((1000,), (world + 1) / 2.0)))
+    if rank == 0:
+        line = headline(args.rois * args.steps * world, elapsed, args, world, args.rois, None, None,
+                        {"dry_run_cpu": True, "grad_sync_ok": ok, "grad_allreduce_ms": round(allreduce_ms, 3)})
+        line["data"] = "none (dry run of the control flow on CPU/gloo: no kernels executed, value is not a measurement)"
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,18 +143,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rois", type=int, default=256, help="ROI pairs per step per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the Config-B extra measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (Config B, stress, KITTI pair, train step, post-processing)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_flow.py: control flow on gloo, no kernels
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run (RCCL rendezvous on
+        # 127.0.0.1), the ranks print the single JSON line
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used only for the barrier / max-reduce
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; the data path has no collective (barrier / max-reduce only)
 
     import __graft_entry__ as g
     if rank == 0:
@@ -97,25 +187,9 @@ def main():
         return model.forward_from_features(fl, fr, (112, 112))
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        out, elapsed = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize)
     assert torch.isfinite(out).all()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = max_over_ranks(elapsed, world, dev)
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, same K steps, same inputs
     roofline = None
@@ -136,199 +210,208 @@ def main():
         achieved = flops / secs / 1e12
         # HBM bytes per launch of the same kernel from the committed PMC pass of this command (profiles/collect.sh):
         # FETCH_SIZE (x2: gfx950 128-B request correction) + WRITE_SIZE; null if that profile is absent
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            key = [k for k in tj if k.replace(" ", "") == dom.replace(" ", "")]
-            if key:
-                traffic = round(tj[key[0]]["fetch_bytes_corrected"] + tj[key[0]]["write_bytes"])
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, separate pass; profiles/r1_pmc.md)",
+        traffic, traffic_src = None, "no committed PMC pass"
+        for prof in ("r2_traffic.json", "r1_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                key = [k for k in tj if k.replace(" ", "") == dom.replace(" ", "")]
+                if key:
+                    traffic = round(tj[key[0]]["fetch_bytes_corrected"] + tj[key[0]]["write_bytes"])
+                    traffic_src = "profiles/" + prof.replace("_traffic.json", "_pmc.md")
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
+        # `achieved` = flops the kernel EXECUTES on the matrix cores per second.  For the direct kernels that is the algorithmic
+        # 2*27*Cin*Cout per voxel; the Winograd F(2x2x2,3x3x3) kernel executes 64 multiplies per 2x2x2 tile and
+        # (cin,cout) pair where the direct form needs 216, so its executed flops are 64/216 of the direct-convolution figure --
+        # that is what is compared with the MFMA peak (frac <= 1).  The direct-convolution-equivalent rate (the layer's
+        # algorithmic flops / time, which may exceed the peak) is reported separately and never as `frac`.
+        exec_ratio = 64.0 / 216.0 if dom.startswith("wino3d") else 1.0
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved * exec_ratio, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved * exec_ratio / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, separate pass; {traffic_src})",
                     "calls_per_step": calls // args.steps, "avg_launch_us": round(secs / calls * 1e6, 2),
-                    "algorithmic_flops_per_launch": flops / calls}
-        if dom.startswith("wino3d"):
-            # `achieved` prices the layer at the direct convolution's 2*27*Cin*Cout flops per voxel (the algorithmic figure of
-            # DESIGN.md section 3); Winograd F(2,3)^3 executes 64/216 of those multiplies on the matrix cores, so `frac` may
-            # exceed 1 -- `executed_frac` is what the MFMA pipe actually sustains against its peak
-            roofline["executed"] = round(achieved * 64 / 216, 2)
-            roofline["executed_frac"] = round(achieved * 64 / 216 / PEAK_F32_TFLOPS, 4)
-            roofline["note"] = "achieved = direct-convolution flops / time; the kernel is Winograd F(2x2x2,3x3x3): 64/216 of them are executed"
+                    "executed_flops_per_launch": flops / calls * exec_ratio,
+                    "direct_conv_equivalent_tflops": round(achieved, 2),
+                    "direct_conv_equivalent_flops_per_launch": flops / calls,
+                    "note": ("achieved/frac = executed MFMA flops (Winograd: 64/216 of the direct convolution's) vs the fp32 MFMA peak; "
+                             "direct_conv_equivalent_* = SURVEY 8d's algorithmic conv flops / time, not a roofline fraction")}
         extra["kernels"] = {k: {"calls_per_step": v[0] // args.steps, "avg_us": round(v[1] / v[0] * 1e6, 2),
                                 "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in agg.items()}
         step_flops = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * N
         extra["regressor_tflops_whole_step"] = round(step_flops * args.steps * world / elapsed / 1e12 / world, 2)
 
-        # ---- extra: Config B (224x224, D=96, full PSMNet incl. the 2D feature CNN), 16 ROI pairs per step
-        if not args.no_extra:
-            try:
-                mB, _ = build_model(dev, 48, -48, "B")
-                l, r = synth.synth_images(16, 224, 224, tag="benchB")
-                l, r = l.to(dev), r.to(dev)
-                with torch.no_grad():
-                    for _ in range(2):
-                        mB((l, r))
-                    torch.cuda.synchronize()
-                    tb = time.perf_counter()
-                    for _ in range(5):
-                        mB((l, r))
-                    torch.cuda.synchronize()
-                    tb = (time.perf_counter() - tb) / 5
-                extra["config_b_full_psmnet"] = {"roi_pairs_per_s": round(16 / tb, 1), "ms_per_16_roi_image": round(tb * 1e3, 2),
-                                                 "stereo_pairs_per_s_16roi": round(1 / tb, 2),
-                                                 "workload": "16 ROI crops 224x224, D=96 (-48..48): 2D CNN + cost volume + 3D + soft-argmin"}
-                # ---- extra: BASELINE configs[3] shape (64 ROIs/image at 224x224x96) -- in fp32: no fp16 path is built (the
-                # reference has no fp16 oracle), so this is the stress shape at the reference's own precision
-                l64, r64 = synth.synth_images(64, 224, 224, tag="benchB64")
-                l64, r64 = l64.to(dev), r64.to(dev)
-                with torch.no_grad():
-                    mB((l64, r64))
-                    torch.cuda.synchronize()
-                    ts = time.perf_counter()
-                    for _ in range(3):
-                        mB((l64, r64))
-                    torch.cuda.synchronize()
-                    ts = (time.perf_counter() - ts) / 3
-                extra["stress_64roi_224x224x96_f32"] = {"roi_pairs_per_s": round(64 / ts, 1), "ms_per_64_roi_image": round(ts * 1e3, 2),
-                                                        "regressor_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / ts / 1e12, 1)}
-                del l64, r64
-                # ---- extra: BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
-                # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
-                from types import SimpleNamespace as NS
-                from disprcnn_amd.modeling.backbone import build_backbone
-                from disprcnn_amd.modeling.detector.disprcnn3d import DispRCNN3D, default_cfg
-                from disprcnn_amd.structures import BoxList, ImageList
-                bb = build_backbone(NS(MODEL=NS(BACKBONE=NS(CONV_BODY="R-50-FPN"), RESNETS=NS(BACKBONE_OUT_CHANNELS=256, RES2_OUT_CHANNELS=256))))
-                bsd = synth.synth_backbone_state(bb.state_dict())
-                bnf = os.path.join(ROOT, "tests", "golden", "bn_stats_backbone.npz")
-                if os.path.exists(bnf):
-                    synth.load_bn_stats(bsd, bnf)
-                bb.load_state_dict(bsd)
-                bb = bb.to(dev).eval()
-                det = DispRCNN3D(default_cfg(48, -48, 224))
-                det.dispnet = mB
-                det = det.to(dev).eval()
-                Wi, Hi = 1242, 375
-                pair = synth.hash_uniform("benchpair", (2, 3, Hi, Wi), 0.0, 1.0).to(dev)
-                u = synth.hash_uniform("benchboxes", (16, 4), 0.0, 1.0)
-                x1 = 20 + u[:, 0] * (Wi - 400); y1 = 10 + u[:, 1] * (Hi - 240)
-                lb = torch.stack([x1, y1, x1 + 40 + u[:, 2] * 260, y1 + 30 + u[:, 3] * 170], 1)
-                rb = lb.clone(); rb[:, [0, 2]] -= 2 + 78 * u[:, 0:1]
-                rb[:, [0, 2]] = rb[:, [0, 2]].clamp(min=0)
-
-                def pair_step():
-                    feats = bb(pair)
-                    out = det({"left": ImageList(pair[:1], [(Hi, Wi)]), "right": ImageList(pair[1:], [(Hi, Wi)])},
-                              {"left": [BoxList(lb, (Wi, Hi))], "right": [BoxList(rb, (Wi, Hi))]})
-                    return feats, out
-                with torch.no_grad():
-                    for _ in range(2):
-                        pair_step()
-                    torch.cuda.synchronize()
-                    tp = time.perf_counter()
-                    for _ in range(5):
-                        pair_step()
-                    torch.cuda.synchronize()
-                    tp = (time.perf_counter() - tp) / 5
-                    torch.cuda.synchronize(); t1 = time.perf_counter()
-                    for _ in range(5):
-                        bb(pair)
-                    torch.cuda.synchronize(); tbb = (time.perf_counter() - t1) / 5
-                extra["kitti_pair_r50fpn_plus_16roi"] = {
-                    "stereo_pairs_per_s": round(1.0 / tp, 2), "ms_per_pair": round(tp * 1e3, 2), "backbone_ms": round(tbb * 1e3, 2),
-                    "backbone_tflops": round(250.3e9 / tbb / 1e12, 2),
-                    "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
-                del bb, det
-                # ---- extra: one TRAIN step of the disparity stage (reference: PSMNet.train() + PSMLoss, trainer.do_train): forward with
-                # per-GPU batch-stat BatchNorm, 3-head smooth-L1 loss, full backward (dgrad + MFMA wgrad) on the HIP engine, gradient
-                # sync (GradientSync: a no-op at world size 1), optimizer step; 64 ROI pairs of Config A from the feature boundary, and 8 ROI crops of
-                # Config B through the 2D CNN as well
-                from disprcnn_amd.utils.loss_utils import PSMLoss
-                from disprcnn_amd.utils.comm import GradientSync
-                tr = {}
-                for tag, mdl, nroi in (("config_a_from_features_64roi", model, 64), ("config_b_full_psmnet_8roi", mB, 8)):
-                    mdl.train()
-                    sync = GradientSync(mdl.parameters())
-                    if tag.startswith("config_a"):
-                        fl_, fr_ = synth.synth_features(nroi, 32, 28, 28, tag="trainA")
-                        fl_, fr_ = fl_.to(dev), fr_.to(dev)
-                        tgt = synth.hash_uniform("trainA:t", (nroi, 112, 112), 0.0, 47.0).to(dev)
-                        fwd = lambda: mdl.forward_from_features(fl_, fr_, (112, 112))
-                        fl3 = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * nroi
-                    else:
-                        li, ri = synth.synth_images(nroi, 224, 224, tag="trainB")
-                        li, ri = li.to(dev), ri.to(dev)
-                        tgt = synth.hash_uniform("trainB:t", (nroi, 224, 224), -47.0, 47.0).to(dev)
-                        fwd = lambda: mdl({"left": li, "right": ri})
-                        fl3 = FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * nroi
-                    msk = torch.ones_like(tgt, dtype=torch.uint8)
-                    crit = PSMLoss()
-                    opt = torch.optim.SGD(mdl.parameters(), lr=1e-7, momentum=0.9)   # the parameters change every step: weights are re-packed
-
-                    def train_step():
-                        opt.zero_grad(set_to_none=True)
-                        loss = crit(fwd(), {"disparity": tgt, "mask": msk})
-                        loss.backward()
-                        sync()
-                        opt.step()
-                        return loss
-                    for _ in range(2):
-                        train_step()
-                    torch.cuda.synchronize(); t1 = time.perf_counter()
-                    for _ in range(3):
-                        train_step()
-                    torch.cuda.synchronize(); tt = (time.perf_counter() - t1) / 3
-                    tr[tag] = {"ms_per_step": round(tt * 1e3, 2), "roi_pairs_per_s": round(nroi / tt, 1),
-                               "regressor_tflops_fwd_bwd": round(3 * fl3 / tt / 1e12, 2)}
-                    mdl.eval()
-                tr["workload"] = "forward (batch-stat BN) + PSMLoss + backward + gradient sync + SGD step; regressor FLOPs counted as 3x forward"
+    # ---- extras.  The train step is the only one with a collective (one flat gradient all-reduce): EVERY rank enters it.
+    # The others have none and run on rank 0 at world size 1 only (the scaling runs stay short; their numbers do not depend on N).
+    if not args.no_extra:
+        try:
+            tr = train_step_extra(dev, model, world)
+            if rank == 0:
                 extra["train_step"] = tr
-                del mB
-                # ---- extra: post-processing: 16 images 375x1242, 16 ROI maps 224x224 each -> full-image disparity maps
-                from disprcnn_amd import ops as _ops
-                gpp = torch.Generator().manual_seed(0)
-                nimg, nr, ih, iw = 16, 16, 375, 1242
-                x1 = torch.rand(nimg * nr, generator=gpp) * (iw - 260); y1 = torch.rand(nimg * nr, generator=gpp) * (ih - 180)
-                lbp = torch.stack([x1, y1, x1 + 60 + torch.rand(nimg * nr, generator=gpp) * 190, y1 + 40 + torch.rand(nimg * nr, generator=gpp) * 130], 1)
-                rbp = lbp.clone(); rbp[:, 0] = (lbp[:, 0] - 30).clamp(min=0); rbp[:, 2] = lbp[:, 2] - 25
-                dpp = (torch.rand(nimg * nr, 224, 224, generator=gpp) * 96 - 48).to(dev)
-                b6 = _ops.integer_roi_boxes(lbp.to(dev), rbp.to(dev))
-                for _ in range(3):
-                    _ops.disparity_paste(dpp, b6, [nr] * nimg, ih, iw)
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                for _ in range(20):
-                    _ops.disparity_paste(dpp, b6, [nr] * nimg, ih, iw)
-                torch.cuda.synchronize(); tp = (time.perf_counter() - t1) / 20
-                pbytes = nimg * ih * iw * 4 + dpp.numel() * 4
-                extra["post_process_16img_x16roi"] = {"us_per_call": round(tp * 1e6, 1), "images_per_s": round(nimg / tp, 1),
-                                                      "algorithmic_GB_per_s": round(pbytes / tp / 1e9, 1),
-                                                      "workload": "drc_disparity_paste_fwd: 256 ROI maps 224^2 -> 16 maps 375x1242 (one launch; bytes = maps read once + outputs written once)"}
-            except Exception as ex:  # report, never hide
-                extra["config_b_full_psmnet"] = extra.get("config_b_full_psmnet") or {"error": repr(ex)}
+        except Exception as ex:  # report, never hide -- but every rank must leave through the same door
+            extra["train_step"] = {"error": repr(ex)}
+        if rank == 0 and world == 1:
+            try:
+                rank0_extras(dev, extra)
+            except Exception as ex:
                 extra["extra_error"] = repr(ex)
+        elif rank == 0:
+            extra["skipped_for_world_gt_1"] = ["config_b_full_psmnet", "stress_64roi_224x224x96", "kitti_pair_r50fpn_plus_16roi", "post_process_16img_x16roi"]
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline_config_a(sd)
 
     if rank == 0:
-        total_rois = N * args.steps * world
-        line = {
-            "metric": "ROI cost-volumes/sec (112x112x48)", "value": round(total_rois / elapsed, 1), "unit": "ROI cost-volumes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Config A: per ROI pair, features [32,28,28]x2 -> concat cost volume [64,12,28,28] -> "
-                                   "3D stacked-hourglass regressor -> trilinear x4 + softmax + soft-argmin -> disparity [112,112]",
-                       "rois_per_step_per_gpu": N, "maxdisp": 48, "mindisp": 0, "parallelism": f"roi-shard x{world} (no collective)",
-                       "weights": "closed-form synthetic (disprcnn_amd.utils.synth), BN stats calibrated fixture"},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
-        }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(headline(N * args.steps * world, elapsed, args, world, N, roofline, cpu, extra)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _time(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def train_step_extra(dev, model_a, world):
+    """One TRAIN step of the disparity stage (reference: PSMNet.train() + PSMLoss, trainer.do_train): forward with per-GPU
+    batch-stat BatchNorm, 3-head smooth-L1 loss, full backward (dgrad + MFMA wgrad) on the HIP engine, gradient sync (ONE flat
+    20.9 MB all-reduce over RCCL/xGMI; a no-op at world size 1), optimizer step.  64 ROI pairs of Config A from the feature
+    boundary, and 8 ROI crops of Config B through the 2D CNN as well.  Runs on EVERY rank (the all-reduce must be matched);
+    the all-reduce time is measured with events around the sync."""
+    from disprcnn_amd.utils import synth
+    from disprcnn_amd.utils.loss_utils import PSMLoss
+    from disprcnn_amd.utils.comm import GradientSync
+    mB, _ = build_model(dev, 48, -48, "B")
+    tr = {}
+    for tag, mdl, nroi in (("config_a_from_features_64roi", model_a, 64), ("config_b_full_psmnet_8roi", mB, 8)):
+        mdl.train()
+        sync = GradientSync(mdl.parameters())
+        if tag.startswith("config_a"):
+            fl_, fr_ = synth.synth_features(nroi, 32, 28, 28, tag="trainA")
+            fl_, fr_ = fl_.to(dev), fr_.to(dev)
+            tgt = synth.hash_uniform("trainA:t", (nroi, 112, 112), 0.0, 47.0).to(dev)
+            fwd = lambda: mdl.forward_from_features(fl_, fr_, (112, 112))      # noqa: E731
+            fl3 = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * nroi
+        else:
+            li, ri = synth.synth_images(nroi, 224, 224, tag="trainB")
+            li, ri = li.to(dev), ri.to(dev)
+            tgt = synth.hash_uniform("trainB:t", (nroi, 224, 224), -47.0, 47.0).to(dev)
+            fwd = lambda: mdl({"left": li, "right": ri})                       # noqa: E731
+            fl3 = FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * nroi
+        msk = torch.ones_like(tgt, dtype=torch.uint8)
+        crit = PSMLoss()
+        opt = torch.optim.SGD(mdl.parameters(), lr=1e-7, momentum=0.9)   # the parameters change every step: weights are re-packed
+        sync_ms = []
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(fwd(), {"disparity": tgt, "mask": msk})
+            loss.backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); sync(); e1.record()
+            sync_ms.append((e0, e1))
+            opt.step()
+            return loss
+        tt = _time(train_step, 2, 3)
+        ar = sum(a_.elapsed_time(b_) for a_, b_ in sync_ms[-3:]) / 3
+        tr[tag] = {"ms_per_step": round(tt * 1e3, 2), "roi_pairs_per_s_per_gpu": round(nroi / tt, 1),
+                   "regressor_tflops_fwd_bwd": round(3 * fl3 / tt / 1e12, 2),
+                   "grad_allreduce_ms": round(ar, 3) if world > 1 else 0.0}
+        mdl.eval()
+    tr["workload"] = ("forward (batch-stat BN) + PSMLoss + backward + gradient sync (one flat fp32 all-reduce of 5.2 M parameters, "
+                      f"world {world}) + SGD step; per-GPU batch; regressor FLOPs counted as 3x forward")
+    del mB
+    return tr
+
+
+def rank0_extras(dev, extra):
+    from disprcnn_amd.utils import synth
+    # ---- Config B (224x224, D=96, full PSMNet incl. the 2D feature CNN), 16 ROI pairs per step
+    mB, _ = build_model(dev, 48, -48, "B")
+    l, r = synth.synth_images(16, 224, 224, tag="benchB")
+    l, r = l.to(dev), r.to(dev)
+    with torch.no_grad():
+        tb = _time(lambda: mB((l, r)), 2, 5)
+    fl_b = (FLOPS_PER_VOXEL_3D * 24 * 56 * 56 + 2 * FLOPS_2D_PER_IMAGE) * 16
+    extra["config_b_full_psmnet"] = {"roi_pairs_per_s": round(16 / tb, 1), "ms_per_16_roi_image": round(tb * 1e3, 2),
+                                     "stereo_pairs_per_s_16roi": round(1 / tb, 2),
+                                     "direct_conv_equivalent_tflops": round(fl_b / tb / 1e12, 1),
+                                     "workload": "16 ROI crops 224x224, D=96 (-48..48): 2D CNN + cost volume + 3D + soft-argmin"}
+    # ---- BASELINE configs[3] shape (64 ROIs/image at 224x224x96) in fp32 (the reference's own precision)
+    l64, r64 = synth.synth_images(64, 224, 224, tag="benchB64")
+    l64, r64 = l64.to(dev), r64.to(dev)
+    with torch.no_grad():
+        ts = _time(lambda: mB((l64, r64)), 1, 3)
+    extra["stress_64roi_224x224x96_f32"] = {"roi_pairs_per_s": round(64 / ts, 1), "ms_per_64_roi_image": round(ts * 1e3, 2),
+                                            "regressor_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / ts / 1e12, 1)}
+    del l64, r64
+    # ---- BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
+    # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
+    from types import SimpleNamespace as NS
+    from disprcnn_amd.modeling.backbone import build_backbone
+    from disprcnn_amd.modeling.detector.disprcnn3d import DispRCNN3D, default_cfg
+    from disprcnn_amd.structures import BoxList, ImageList
+    bb = build_backbone(NS(MODEL=NS(BACKBONE=NS(CONV_BODY="R-50-FPN"), RESNETS=NS(BACKBONE_OUT_CHANNELS=256, RES2_OUT_CHANNELS=256))))
+    bsd = synth.synth_backbone_state(bb.state_dict())
+    bnf = os.path.join(ROOT, "tests", "golden", "bn_stats_backbone.npz")
+    if os.path.exists(bnf):
+        synth.load_bn_stats(bsd, bnf)
+    bb.load_state_dict(bsd)
+    bb = bb.to(dev).eval()
+    det = DispRCNN3D(default_cfg(48, -48, 224))
+    det.dispnet = mB
+    det = det.to(dev).eval()
+    Wi, Hi = 1242, 375
+    pair = synth.hash_uniform("benchpair", (2, 3, Hi, Wi), 0.0, 1.0).to(dev)
+    u = synth.hash_uniform("benchboxes", (16, 4), 0.0, 1.0)
+    x1 = 20 + u[:, 0] * (Wi - 400); y1 = 10 + u[:, 1] * (Hi - 240)
+    lb = torch.stack([x1, y1, x1 + 40 + u[:, 2] * 260, y1 + 30 + u[:, 3] * 170], 1)
+    rb = lb.clone(); rb[:, [0, 2]] -= 2 + 78 * u[:, 0:1]
+    rb[:, [0, 2]] = rb[:, [0, 2]].clamp(min=0)
+
+    def pair_step():
+        feats = bb(pair)
+        out = det({"left": ImageList(pair[:1], [(Hi, Wi)]), "right": ImageList(pair[1:], [(Hi, Wi)])},
+                  {"left": [BoxList(lb, (Wi, Hi))], "right": [BoxList(rb, (Wi, Hi))]})
+        return feats, out
+    with torch.no_grad():
+        tp = _time(pair_step, 2, 5)
+        tbb = _time(lambda: bb(pair), 1, 5)
+    fl_pair = FLOPS_BACKBONE_PAIR + fl_b
+    extra["kitti_pair_r50fpn_plus_16roi"] = {
+        "stereo_pairs_per_s": round(1.0 / tp, 2), "ms_per_pair": round(tp * 1e3, 2), "backbone_ms": round(tbb * 1e3, 2),
+        "backbone_tflops": round(FLOPS_BACKBONE_PAIR / tbb / 1e12, 2),
+        "roofline": {"bound": "mfma", "achieved": round(fl_pair / tp / 1e12, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(fl_pair / tp / 1e12 / PEAK_F32_TFLOPS, 4),
+                     "flops_per_pair": fl_pair,
+                     "note": ("whole stereo-pair pipeline, direct-convolution-equivalent conv flops (SURVEY 8a/8d: backbone 250.3 G + 16 x "
+                              "(2 x 22.19 G 2D CNN + 48.51 G regressor)) / wall time; an upper bound on the executed MFMA fraction because the "
+                              "Winograd layers execute 64/216 (3D) and 16/36 (2D) of their share; per-kernel MFMA-busy and HBM bytes: "
+                              "profiles/r2_pair_*.md")},
+        "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
+    del bb, det, mB
+    # ---- post-processing (SURVEY f2): 16 images 375x1242, 16 ROI maps 224x224 each -> full-image disparity maps
+    from disprcnn_amd import ops as _ops
+    gpp = torch.Generator().manual_seed(0)
+    nimg, nr, ih, iw = 16, 16, 375, 1242
+    x1 = torch.rand(nimg * nr, generator=gpp) * (iw - 260); y1 = torch.rand(nimg * nr, generator=gpp) * (ih - 180)
+    lbp = torch.stack([x1, y1, x1 + 60 + torch.rand(nimg * nr, generator=gpp) * 190, y1 + 40 + torch.rand(nimg * nr, generator=gpp) * 130], 1)
+    rbp = lbp.clone(); rbp[:, 0] = (lbp[:, 0] - 30).clamp(min=0); rbp[:, 2] = lbp[:, 2] - 25
+    dpp = (torch.rand(nimg * nr, 224, 224, generator=gpp) * 96 - 48).to(dev)
+    b6 = _ops.integer_roi_boxes(lbp.to(dev), rbp.to(dev))
+    tp = _time(lambda: _ops.disparity_paste(dpp, b6, [nr] * nimg, ih, iw), 3, 20)
+    pbytes = nimg * ih * iw * 4 + dpp.numel() * 4
+    extra["post_process_16img_x16roi"] = {"us_per_call": round(tp * 1e6, 1), "images_per_s": round(nimg / tp, 1),
+                                          "algorithmic_GB_per_s": round(pbytes / tp / 1e9, 1),
+                                          "workload": "drc_disparity_paste_fwd: 256 ROI maps 224^2 -> 16 maps 375x1242 (one launch; bytes = maps read once + outputs written once)"}
 
 
 if __name__ == "__main__":
