@@ -316,7 +316,7 @@ def test_site_backward_vs_torch_autograd(dev, kind, cin, cout, k, stride, pad, d
         plan = E.plan_deconv3d(t["x"], t["y"], cout, relu)
     else:
         plan = E.plan_conv2d(t["x"], t["y"], k, stride, pad, dil, cout, relu)
-    ws = {"t": t, "p": {"s": plan}}
+    ws = {"t": t, "p": {"s": plan}, "pool": E.WorkspacePool(n, dev)}
     rt = PSMNetRuntime.__new__(PSMNetRuntime)
     rt.device, rt._training, rt._tape, rt._need_input_grad = dev, True, [], True
     W = {"s": _Conv(conv, bn, dev, kind == "deconv3d")}
