@@ -148,6 +148,107 @@ __global__ void align_roi_pairs_kernel(const float* __restrict__ lbox, const flo
     geom[i * 4 + 0] = x1; geom[i * 4 + 1] = x1p; geom[i * 4 + 2] = x1 + mw; geom[i * 4 + 3] = x1p + mw;
 }
 
+
+// ---- training targets of the disparity stage (DispRCNN3D.prepare_psmnet_input_and_target, disprcnn3d.py:52-112)
+// The reference builds, per ROI and on the host: Masker(0.7, padding 1) paste of the 28x28 mask probabilities into a full-size
+// uint8 image (roi_heads/mask_head/inference.py:90-190), AND with the ground-truth mask, slice to the ROI, bilinear resize
+// (align_corners=True) to res x res, .byte();  DisparityMap.crop -> minus (x1 - x1p) -> resize (align_corners=True, values times
+// res / width; structures/disparity.py:38-77).  Here one thread per target pixel evaluates both directly from the inputs:
+// nothing full-size is materialised, no .tolist().
+struct PasteBox { int bx0, by0, bw, bh; };
+
+// expand_boxes + .to(int32) of paste_mask_in_image: box grown by (M + 2*pad) / M about its centre, truncated toward zero
+__device__ __forceinline__ PasteBox paste_box(const float* __restrict__ b, int M, int pad) {
+    const float scale = (float)((double)(M + 2 * pad) / (double)M);
+    float w_half = (b[2] - b[0]) * 0.5f, h_half = (b[3] - b[1]) * 0.5f;
+    const float xc = (b[2] + b[0]) * 0.5f, yc = (b[3] + b[1]) * 0.5f;
+    w_half *= scale; h_half *= scale;
+    const int x0 = (int)(xc - w_half), x1 = (int)(xc + w_half), y0 = (int)(yc - h_half), y1 = (int)(yc + h_half);
+    PasteBox q;
+    q.bx0 = x0; q.by0 = y0;
+    q.bw = max(x1 - x0 + 1, 1); q.bh = max(y1 - y0 + 1, 1);
+    return q;
+}
+
+// Masker value at image pixel (Y, X): F.interpolate(padded mask, (bh, bw), bilinear, align_corners=False) > thresh inside the
+// pasted window, 0 elsewhere
+__device__ __forceinline__ int masker_at(const float* __restrict__ prob, int M, int pad, const PasteBox& q, int Y, int X, int H, int W, float thresh) {
+    const int x_lo = max(q.bx0, 0), x_hi = min(q.bx0 + q.bw, W), y_lo = max(q.by0, 0), y_hi = min(q.by0 + q.bh, H);
+    if (X < x_lo || X >= x_hi || Y < y_lo || Y >= y_hi) return 0;
+    const int P = M + 2 * pad;
+    const float sy = (float)P / (float)q.bh, sx = (float)P / (float)q.bw;
+    float fy = sy * ((float)(Y - q.by0) + 0.5f) - 0.5f, fx = sx * ((float)(X - q.bx0) + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < P - 1 ? 1 : 0), x1 = x0 + (x0 < P - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    auto at = [&](int yy, int xx) -> float {          // padded mask: zero border of width `pad`
+        yy -= pad; xx -= pad;
+        return (yy >= 0 && yy < M && xx >= 0 && xx < M) ? prob[yy * M + xx] : 0.f;
+    };
+    const float top = (1.f - lx) * at(y0, x0) + lx * at(y0, x1);
+    const float bot = (1.f - lx) * at(y1, x0) + lx * at(y1, x1);
+    return ((1.f - ly) * top + ly * bot) > thresh ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void roi_train_targets_kernel(const float* __restrict__ disp_maps, const uint8_t* __restrict__ gt_masks,
+                                                                     const float* __restrict__ mask_probs, int M, int pad, float thresh,
+                                                                     const float* __restrict__ det_boxes, const float* __restrict__ rois_l,
+                                                                     const int32_t* __restrict__ geom, int R, int H, int W, int res,
+                                                                     float* __restrict__ targets, uint8_t* __restrict__ masks) {
+    const long total = (long)R * res * res;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        const int j = (int)(idx % res), i = (int)((idx / res) % res), r = (int)(idx / ((long)res * res));
+        const int b = (int)rois_l[r * 5 + 0];
+        const int x1 = geom[r * 4 + 0], x1p = geom[r * 4 + 1], mw = geom[r * 4 + 2] - geom[r * 4 + 0];
+        const int y1 = (int)rois_l[r * 5 + 2], y2 = (int)rois_l[r * 5 + 4];
+        const int hc = y2 - y1;
+        // ---- disparity target: crop (zero beyond the image) - (x1 - x1p), resized with align_corners=True, values * res / mw
+        float tv = 0.f;
+        if (hc > 0 && mw > 0) {
+            const float sh = res > 1 ? (float)(hc - 1) / (float)(res - 1) : 0.f, sw = res > 1 ? (float)(mw - 1) / (float)(res - 1) : 0.f;
+            const float fy = sh * (float)i, fx = sw * (float)j;
+            int y0 = (int)fy, x0 = (int)fx;
+            y0 = y0 < hc - 1 ? y0 : hc - 1; x0 = x0 < mw - 1 ? x0 : mw - 1;
+            const int yp = y0 < hc - 1 ? 1 : 0, xp = x0 < mw - 1 ? 1 : 0;
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float off = (float)(x1 - x1p);
+            const float* dm = disp_maps + (long)b * H * W;
+            auto at = [&](int yy, int xx) -> float {
+                const int Y = y1 + yy, X = x1 + xx;
+                return ((Y >= 0 && Y < H && X >= 0 && X < W) ? dm[(long)Y * W + X] : 0.f) - off;
+            };
+            const float top = (1.f - lx) * at(y0, x0) + lx * at(y0, x0 + xp);
+            const float bot = (1.f - lx) * at(y0 + yp, x0) + lx * at(y0 + yp, x0 + xp);
+            tv = ((1.f - ly) * top + ly * bot) / (float)mw * (float)res;
+        }
+        targets[idx] = tv;
+        // ---- mask: (Masker paste & ground truth)[y1:y2, x1:x1+mw] (slice clipped to the image), resized (align_corners=True), .byte()
+        const int mh = min(y2, H) - max(y1, 0), mwc = min(x1 + mw, W) - max(x1, 0);
+        uint8_t mv = 0;
+        if (mh > 0 && mwc > 0) {
+            const float sh = res > 1 ? (float)(mh - 1) / (float)(res - 1) : 0.f, sw = res > 1 ? (float)(mwc - 1) / (float)(res - 1) : 0.f;
+            const float fy = sh * (float)i, fx = sw * (float)j;
+            int y0 = (int)fy, x0 = (int)fx;
+            y0 = y0 < mh - 1 ? y0 : mh - 1; x0 = x0 < mwc - 1 ? x0 : mwc - 1;
+            const int yp = y0 < mh - 1 ? 1 : 0, xp = x0 < mwc - 1 ? 1 : 0;
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const PasteBox q = paste_box(det_boxes + (long)r * 4, M, pad);
+            const float* prob = mask_probs + (long)r * M * M;
+            const uint8_t* gm = gt_masks + (long)b * H * W;
+            const int Y0 = max(y1, 0) + y0, X0 = max(x1, 0) + x0;
+            auto at = [&](int Y, int X) -> float {
+                return (gm[(long)Y * W + X] != 0 && masker_at(prob, M, pad, q, Y, X, H, W, thresh)) ? 1.f : 0.f;
+            };
+            const float top = (1.f - lx) * at(Y0, X0) + lx * at(Y0, X0 + xp);
+            const float bot = (1.f - lx) * at(Y0 + yp, X0) + lx * at(Y0 + yp, X0 + xp);
+            const float v = (1.f - ly) * top + ly * bot;
+            mv = (uint8_t)(int)v;                       // .byte(): truncation -- only an interpolated 1.0 survives
+        }
+        masks[idx] = mv;
+    }
+}
+
 inline unsigned grid_for(long work) {
     long b = (work + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
@@ -186,6 +287,18 @@ int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, 
     const long total = (long)K * C * PH * PW;
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, grad_out, rois, grad_in, K, C,
                        H, W, PH, PW, spatial_scale, sampling_ratio);
+    return (int)hipGetLastError();
+}
+
+int drc_roi_train_targets_fwd(const float* disp_maps, const uint8_t* gt_masks, const float* mask_probs, int mask_size, int padding,
+                              float mask_thresh, const float* det_boxes, const float* rois_left, const int32_t* geom, int R, int H, int W,
+                              int res, float* targets, uint8_t* masks, void* stream) {
+    if (R < 0 || H <= 0 || W <= 0 || res <= 0 || mask_size <= 0 || padding < 0) return -2;
+    if (R == 0) return 0;
+    if (!disp_maps || !gt_masks || !mask_probs || !det_boxes || !rois_left || !geom || !targets || !masks) return -1;
+    const long total = (long)R * res * res;
+    hipLaunchKernelGGL(roi_train_targets_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, disp_maps, gt_masks, mask_probs,
+                       mask_size, padding, mask_thresh, det_boxes, rois_left, geom, R, H, W, res, targets, masks);
     return (int)hipGetLastError();
 }
 

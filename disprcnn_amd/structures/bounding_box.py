@@ -13,6 +13,7 @@ class BoxList:
             raise ValueError("only mode 'xyxy' is supported on this path")
         self.bbox, self.size, self.mode = bbox, tuple(image_size), mode    # size = (width, height)
         self.extra_fields = {}
+        self.PixelWise_map = {}                     # full-image maps ('disparity': DisparityMap), reference bounding_box.py:39,80-94
 
     @property
     def width(self):
@@ -34,6 +35,15 @@ class BoxList:
     def fields(self):
         return list(self.extra_fields)
 
+    def add_map(self, name, data):
+        self.PixelWise_map[name] = data
+
+    def get_map(self, name):
+        return self.PixelWise_map[name]
+
+    def has_map(self, name):
+        return name in self.PixelWise_map
+
     def to(self, device):
         out = BoxList(self.bbox.to(device), self.size, self.mode)
         for k, v in self.extra_fields.items():
@@ -44,6 +54,7 @@ class BoxList:
         out = BoxList(self.bbox[item].reshape(-1, 4), self.size, self.mode)
         for k, v in self.extra_fields.items():
             out.add_field(k, v[item] if torch.is_tensor(v) else v)
+        out.PixelWise_map = dict(self.PixelWise_map)      # image-level maps are not indexed by ROI
         return out
 
     def __len__(self):

@@ -242,6 +242,17 @@ int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, 
 int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const int32_t* img_idx, int R, int img_w, int img_h,
                         float* rois_left, float* rois_right, int32_t* geom, void* stream);
 
+/* Training targets of the disparity stage -- replaces the per-ROI host loop of DispRCNN3D.prepare_psmnet_input_and_target
+ * (reference modeling/detector/disprcnn3d.py:52-112) incl. Masker(thresh, padding) (roi_heads/mask_head/inference.py:90-190) and
+ * DisparityMap.crop / .resize (structures/disparity.py:38-77).
+ *   disp_maps [B,H,W] f32 ground-truth disparity, gt_masks [B,H,W] u8 (union of the instance masks, 0/1),
+ *   mask_probs [R,mask_size,mask_size] f32 (the 2D stage's 'mask' field), det_boxes [R,4] the left detections (xyxy, float),
+ *   rois_left [R,5] and geom [R,4] as written by drc_align_roi_pairs
+ *   -> targets [R,res,res] f32 (ROI-normalised disparity, offset x1-x1p removed, scaled by res/width), masks [R,res,res] u8. */
+int drc_roi_train_targets_fwd(const float* disp_maps, const uint8_t* gt_masks, const float* mask_probs, int mask_size, int padding,
+                              float mask_thresh, const float* det_boxes, const float* rois_left, const int32_t* geom, int R, int H, int W,
+                              int res, float* targets, uint8_t* masks, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * f2. Post-processing: per-ROI disparities [R][S][S] -> full-image maps, replacing DisparityMapProcessor
  * (modeling/psmnet/inference.py:18-47), DispRCNN3D.roi_disp_postprocess (modeling/detector/disprcnn3d.py:161-190) and the
