@@ -148,8 +148,8 @@ class DispRCNN3D(nn.Module):
         gt_masks = torch.stack(gt_masks).to(dev).contiguous()
         if tuple(disp_maps.shape[1:]) != (h, w) or tuple(gt_masks.shape[1:]) != (h, w):
             raise ValueError("ground-truth disparity maps / masks must have the image size of the detections")
-        probs = torch.cat([a.get_field("mask").reshape(len(a), -1) for a in left_result]).to(dev).float().contiguous()
-        M = int(round(probs.shape[1] ** 0.5))
+        M = next(int(a.get_field("mask").shape[-1]) for a in left_result if len(a))
+        probs = torch.cat([a.get_field("mask").reshape(len(a), M * M) for a in left_result]).to(dev).float().contiguous()
         st = _lib.lib().drc_roi_train_targets_fwd(E._ptr(disp_maps), E._ptr(gt_masks), E._ptr(probs), M, self.mask_padding, self.mask_threshold,
                                                   E._ptr(lb), E._ptr(rois_l), E._ptr(geom), R, int(h), int(w), res, E._ptr(targets), E._ptr(masks),
                                                   E._stream_ptr(dev))
