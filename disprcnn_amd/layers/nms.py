@@ -1,0 +1,27 @@
+"""nms -- drop-in for ``disprcnn.layers.nms`` (= ``disprcnn._C.nms``, reference layers/nms.py:8, csrc/nms.h:12-28).
+
+``nms(dets[N,4] xyxy, scores[N], threshold) -> int64 indices of the kept boxes, ascending`` (the CUDA op sorts the kept original
+indices, csrc/cuda/nms.cu:126-130; the CPU op returns nonzero(), csrc/cpu/nms_cpu.cpp:64).  GPU only: the suppression bitmask
+and the greedy walk run in libdisprcnn_hip.so (drc_nms_sorted_fwd); torch supplies the score sort and the final compaction
+(whose data-dependent output length is the one host sync, as in the reference)."""
+import torch
+
+from .. import _lib
+from .. import engine as E
+
+
+def nms(dets, scores, threshold, strict=True):
+    """strict=True: suppress when IoU > threshold (the reference's CUDA op); False: >= (its CPU op)."""
+    E.require_gpu(dets, "nms")
+    if dets.dim() != 2 or dets.shape[1] != 4 or scores.shape != dets.shape[:1]:
+        raise RuntimeError("nms expects dets [N,4] and scores [N]")
+    n = dets.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=dets.device)
+    order = torch.sort(scores.float(), 0, descending=True, stable=True)[1]
+    boxes = dets.float().index_select(0, order).contiguous()
+    mask = torch.empty(n * ((n + 63) // 64), dtype=torch.int64, device=dets.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=dets.device)
+    st = _lib.lib().drc_nms_sorted_fwd(E._ptr(boxes), n, float(threshold), int(bool(strict)), E._ptr(mask), E._ptr(keep), E._stream_ptr(dets.device))
+    _lib.check(st, "drc_nms_sorted_fwd")
+    return torch.sort(order[keep.bool()])[0]

@@ -242,6 +242,13 @@ int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, 
 int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const int32_t* img_idx, int R, int img_w, int img_h,
                         float* rois_left, float* rois_right, int32_t* geom, void* stream);
 
+/* f4. Greedy NMS -- replaces disprcnn._C.nms for GPU tensors (reference csrc/nms.h:12-28 -> csrc/cuda/nms.cu:23-131; CPU twin
+ * csrc/cpu/nms_cpu.cpp:5-75).  boxes_sorted [n,4] xyxy in DESCENDING score order (the caller sorts: torch.sort is plumbing);
+ * IoU uses the legacy +1 pixel convention; a box is suppressed by an earlier kept box when IoU > thresh (strict = 1, the CUDA
+ * op's test) or >= thresh (strict = 0, the CPU op's).  mask_ws: n * ceil(n/64) uint64 of scratch; keep [n] u8 out (1 = kept).
+ * n <= 32768.  The greedy walk runs on the device (the reference copies the mask to the host). */
+int drc_nms_sorted_fwd(const float* boxes_sorted, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream);
+
 /* Training targets of the disparity stage -- replaces the per-ROI host loop of DispRCNN3D.prepare_psmnet_input_and_target
  * (reference modeling/detector/disprcnn3d.py:52-112) incl. Masker(thresh, padding) (roi_heads/mask_head/inference.py:90-190) and
  * DisparityMap.crop / .resize (structures/disparity.py:38-77).

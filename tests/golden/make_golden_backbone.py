@@ -98,5 +98,40 @@ def main():
     np.savez_compressed(os.path.join(HERE, "backbone_golden.npz"), **out)
 
 
+def main_r101():
+    """R-101-FPN (the conv body of the shipped 2D config, configs/kitti/car/vob/mask.yaml:5): calibrated BN statistics + sampled
+    pyramids at 96x160 and 75x131 -> backbone_r101_golden.npz / bn_stats_backbone_r101.npz (the R-50 fixtures stay as they are)."""
+    cfg.MODEL.BACKBONE.CONV_BODY = "R-101-FPN"
+    cfg.MODEL.RESNETS.BACKBONE_OUT_CHANNELS = 256
+    model = build_backbone(cfg)
+    sd = backbone_state(model.state_dict())
+    model.load_state_dict(sd, strict=True)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.reset_running_stats(); m.momentum = None
+    model.train()
+    with torch.no_grad():
+        for p in range(2):
+            model(synth.hash_uniform(f"bb:cal{p}", (2, 3, 192, 320), -2.0, 2.0))
+    model.eval()
+    bn = {k: v.numpy().copy() for k, v in model.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    np.savez_compressed(os.path.join(HERE, "bn_stats_backbone_r101.npz"), **bn)
+    out = {"keys": np.array(list(model.state_dict().keys())), "n_params": np.array(sum(p.numel() for p in model.parameters()))}
+    for tag, shape in (("small", (2, 3, 96, 160)), ("odd", (1, 3, 75, 131))):
+        x = synth.hash_uniform("bb:" + tag, shape, -2.0, 2.0)
+        with torch.no_grad():
+            feats = model.body(x)
+            outs = model(x)
+        for i, f in enumerate(feats):
+            sample(out, f"{tag}_c{i + 2}", f)
+        for i, o in enumerate(outs):
+            sample(out, f"{tag}_p{i + 2}", o)
+        print("R-101", tag, [tuple(o.shape) for o in outs], float(outs[0].abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "backbone_r101_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--r101" in sys.argv:
+        main_r101()
+    else:
+        main()

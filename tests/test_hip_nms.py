@@ -1,0 +1,46 @@
+"""GPU parity of drc_nms_sorted_fwd / layers.nms against the indices recorded from the reference's own nms_cpu and
+against the oracle; integer output: exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms_oracle as N
+from tests.golden.make_golden_nms import CASES, proposals
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nms_golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("tag,n,thr", CASES)
+def test_nms_vs_reference_kernel_golden(dev, tag, n, thr):
+    from disprcnn_amd.layers import nms
+    dets, scores = proposals(tag, n)
+    keep = nms(dets.to(dev), scores.to(dev), thr, strict=False).cpu().numpy()          # the CPU op's >= (what the fixture was recorded with)
+    assert keep.dtype == np.int64 and np.array_equal(keep, G[f"{tag}_keep"])
+    keep_s = nms(dets.to(dev), scores.to(dev), thr).cpu().numpy()                       # the CUDA op's > (default on the GPU)
+    assert np.array_equal(keep_s, N.nms(dets.numpy(), scores.numpy(), thr, strict=True))
+
+
+def test_nms_edge_cases(dev):
+    from disprcnn_amd.layers import nms
+    assert tuple(nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.5).shape) == (0,)
+    d = torch.tensor([[10., 10., 50., 50.]] * 3, device=dev)
+    s = torch.tensor([0.3, 0.9, 0.5], device=dev)
+    assert nms(d, s, 0.5).tolist() == [1] and nms(d, s, 1.0, strict=False).tolist() == [1] and nms(d, s, 1.0).tolist() == [0, 1, 2]
+    # suppression chains across 64-box blocks: a ladder of shifted boxes, each overlapping only its neighbours
+    n = 300
+    x = torch.arange(n, dtype=torch.float32) * 6
+    dets = torch.stack([x, torch.zeros(n), x + 20, torch.full((n,), 20.)], 1)
+    scores = torch.linspace(1.0, 0.1, n)
+    ref = N.nms(dets.numpy(), scores.numpy(), 0.4, strict=True)
+    assert np.array_equal(nms(dets.to(dev), scores.to(dev), 0.4).cpu().numpy(), ref) and 0 < len(ref) < n
+    with pytest.raises(RuntimeError):
+        nms(torch.zeros(3, 4), torch.zeros(3), 0.5)                                   # CPU tensors: no fallback

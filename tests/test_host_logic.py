@@ -180,3 +180,34 @@ def test_workspace_pool_bucket_and_prefix_views():
         pool.blocked("x", 7, 32, 3, 4, 5, 1, 1, 1)               # above capacity: the runtime replaces the pool
     with pytest.raises(ValueError):
         pool.blocked("x", 2, 16, 3, 4, 5, 1, 1, 1)               # same name, other geometry
+
+
+def test_reference_init_statistics():
+    """SURVEY a9 (stackhourglass.py:90-104): Conv2d / Conv3d weights ~ N(0, sqrt(2 / (prod(kernel) * out_channels))), BatchNorm
+    gamma = 1 / beta = 0, and ConvTranspose3d -- not an nn.Conv3d instance -- keeps torch's default kaiming-uniform init
+    (bound 1 / sqrt(fan_in), fan_in = weight.size(1) * prod(kernel))."""
+    import math
+    from torch import nn
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    torch.manual_seed(0)
+    m = PSMNet(48, -48)
+    checked = {"conv": 0, "deconv": 0, "bn": 0}
+    for name, mod in m.named_modules():
+        if isinstance(mod, nn.ConvTranspose3d):
+            w = mod.weight
+            bound = 1.0 / math.sqrt(w.shape[1] * math.prod(w.shape[2:]))
+            assert w.abs().max().item() <= bound * (1 + 1e-6), name
+            assert abs(w.std().item() / (bound / math.sqrt(3)) - 1) < 0.03 and abs(w.mean().item()) < 0.02 * bound, name
+            checked["deconv"] += 1
+        elif isinstance(mod, (nn.Conv2d, nn.Conv3d)):
+            w = mod.weight
+            std = math.sqrt(2.0 / (math.prod(mod.kernel_size) * mod.out_channels))
+            if w.numel() >= 4096:
+                assert abs(w.std().item() / std - 1) < 0.06, (name, w.std().item(), std)
+                assert abs(w.mean().item()) < 0.05 * std, name
+            assert mod.bias is None, name                                   # every conv on the path is bias-free (SURVEY 8a checklist)
+            checked["conv"] += 1
+        elif isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            assert torch.equal(mod.weight, torch.ones_like(mod.weight)) and torch.equal(mod.bias, torch.zeros_like(mod.bias)), name
+            checked["bn"] += 1
+    assert checked["deconv"] == 6 and checked["conv"] > 60 and checked["bn"] > 60, checked
