@@ -18,7 +18,7 @@ def nms(dets, scores, threshold, strict=True):
     n = dets.shape[0]
     if n == 0:
         return torch.empty(0, dtype=torch.int64, device=dets.device)
-    order = torch.sort(scores.float(), 0, descending=True, stable=True)[1]
+    order = torch.sort(scores.float(), dim=0, descending=True, stable=True)[1]
     boxes = dets.float().index_select(0, order).contiguous()
     mask = torch.empty(n * ((n + 63) // 64), dtype=torch.int64, device=dets.device)
     keep = torch.empty(n, dtype=torch.uint8, device=dets.device)
