@@ -121,6 +121,17 @@ class WorkspacePool:
             raise ValueError(f"WorkspacePool: tensor {name!r} requested with another geometry")
         return Blocked(N, C_, D, H, W, pd, ph, pw, self.device, storage=full.storage)
 
+    def blocked16(self, name, N, C_, D, H, W, pd, ph, pw):
+        """fp16-storage tensor (Blocked16) of the pool."""
+        if N > self.cap:
+            raise ValueError("WorkspacePool: more units than the pool was sized for")
+        full = self.full.get(name)
+        if full is None:
+            full = self.full[name] = Blocked16(self.cap, C_, D, H, W, pd, ph, pw, self.device)
+        elif not isinstance(full, Blocked16) or (full.C, full.D, full.H, full.W, full.pd, full.ph, full.pw) != (C_, D, H, W, pd, ph, pw):
+            raise ValueError(f"WorkspacePool: tensor {name!r} requested with another geometry")
+        return Blocked16(N, C_, D, H, W, pd, ph, pw, self.device, storage=full.storage)
+
     def dense(self, name, N, *shape):
         full = self.flat.get(name)
         if full is None:
@@ -130,7 +141,7 @@ class WorkspacePool:
         return full[:N]
 
     def nbytes(self):
-        return 4 * (sum(b.storage.numel() for b in self.full.values()) + sum(t.numel() for t in self.flat.values()))
+        return sum(b.storage.numel() * b.storage.element_size() for b in self.full.values()) + 4 * sum(t.numel() for t in self.flat.values())
 
 
 class BlockedSlice:
@@ -764,3 +775,156 @@ def bn_apply(raw, y, res, mean, invstd, gamma, beta, relu):
                                          _ptr(res.storage) if res is not None else None, _geom8(res) if res is not None else None,
                                          _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), int(relu), _stream_ptr(raw.device))
     _lib.check(st, "drc_bn_apply_blocked")
+
+
+# ------------------------------------------------------------------------------------------- fp16-storage regressor (conv16.hip)
+CB16 = 32      # fp16 channels per 64-byte voxel line
+
+
+class Blocked16:
+    """fp16-storage twin of Blocked: half[N][ceil(C/32)][D+2pd][H+2ph][W+2pw][32], zero halo (same byte geometry as the fp32
+    layout with 16 channels per line).  Strides are in ELEMENTS (halfs)."""
+
+    def __init__(self, N, C_, D, H, W, pd, ph, pw, device, storage=None):
+        self.N, self.C, self.D, self.H, self.W = N, C_, D, H, W
+        self.pd, self.ph, self.pw = pd, ph, pw
+        self.cb = (C_ + CB16 - 1) // CB16
+        self.Dp, self.Hp, self.Wp = D + 2 * pd, H + 2 * ph, W + 2 * pw
+        self.h_stride = self.Wp * CB16
+        self.d_stride = self.Hp * self.h_stride
+        self.cb_stride = self.Dp * self.d_stride
+        self.n_stride = self.cb * self.cb_stride
+        self.numel = N * self.n_stride
+        if storage is None:
+            self.storage = torch.zeros(self.numel + 2 * SLACK_FLOATS, dtype=torch.float16, device=device)
+        else:
+            if storage.numel() < self.numel + 2 * SLACK_FLOATS:
+                raise ValueError("Blocked16: the given storage is too small for this geometry")
+            self.storage = storage.narrow(0, 0, self.numel + 2 * SLACK_FLOATS)
+        self.device = device
+
+    @property
+    def interior_off(self):
+        return self.pd * self.d_stride + self.ph * self.h_stride + self.pw * CB16
+
+    def view6(self):
+        return self.storage[: self.numel].view(self.N, self.cb, self.Dp, self.Hp, self.Wp, CB16)
+
+    def from_dense(self, dense):
+        """dense [N,C,D,H,W] fp32/fp16 -> interior (torch ops: test plumbing, not on the product path)."""
+        v = self.view6()
+        n, c = dense.shape[:2]
+        pad_c = self.cb * CB16 - c
+        d = torch.nn.functional.pad(dense.to(torch.float16), (0, 0, 0, 0, 0, 0, 0, pad_c)) if pad_c else dense.to(torch.float16)
+        d = d.view(n, self.cb, CB16, self.D, self.H, self.W).permute(0, 1, 3, 4, 5, 2)
+        v[:, :, self.pd:self.pd + self.D, self.ph:self.ph + self.H, self.pw:self.pw + self.W, :] = d
+        return self
+
+    def to_dense(self):
+        v = self.view6()[:, :, self.pd:self.pd + self.D, self.ph:self.ph + self.H, self.pw:self.pw + self.W, :]
+        return v.permute(0, 1, 5, 2, 3, 4).reshape(self.N, self.cb * CB16, self.D, self.H, self.W)[:, : self.C].float()
+
+
+def pack_weight16(w, transposed=False):
+    """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) fp32 -> [K taps][ceil(Cin/32)][cout_pad][32] fp16: lane (cout j, g) of the
+    f16 MFMA's A operand reads channels 8g..8g+7 as one 16-byte load."""
+    if transposed:
+        w = w.transpose(0, 1)
+    cout, cin = w.shape[:2]
+    K = int(math.prod(w.shape[2:]))
+    cb = (cin + CB16 - 1) // CB16
+    cout_pad = (cout + CB - 1) // CB * CB
+    wp = torch.zeros(K, cb * CB16, cout_pad, dtype=torch.float32, device=w.device)
+    wp[:, :cin, :cout] = w.detach().float().reshape(cout, cin, K).permute(2, 1, 0)
+    return wp.view(K, cb, CB16, cout_pad).permute(0, 1, 3, 2).contiguous().to(torch.float16)
+
+
+def choose_tile16(OH, OW):
+    """(R, WT) with R*WT <= 64 output voxels per wave: least MFMA padding, then the largest tile, then the widest rows."""
+    best = None
+    for r in range(1, OH + 1):
+        for wt in range(1, min(OW, 64 // r) + 1):
+            nvt = -(-(r * wt) // 16)
+            waste = (-(-OH // r)) * (-(-OW // wt)) * nvt * 16 / (OH * OW)
+            key = (-round(waste, 2), r * wt, wt)
+            if best is None or key > best[0]:
+                best = (key, r, wt)
+    return best[1], best[2]
+
+
+class ConvPlan16:
+    """A resolved conv16 launch (tap-grid classes as in ConvPlan).  dense1: the 32 -> 1 classifier conv, whose single cout is
+    written as a dense fp32 [N,D,H,W] volume (+ an optional dense fp32 residual)."""
+
+    def __init__(self, x, y_geom, classes, in_mul, out_mul, grid_dhw, cout, relu, dense1=False):
+        p = DrcTapconvParams()
+        OD, OH, OW = grid_dhw
+        p.N, p.OD, p.OH, p.OW = x.N, OD, OH, OW
+        p.in_mul, p.out_mul = in_mul, out_mul
+        p.cb_in = x.cb
+        p.cout_pad = (cout + CB - 1) // CB * CB
+        p.relu = int(relu)
+        p.n_classes = len(classes)
+        p.R, p.WT = choose_tile16(OH, OW)
+        p.reserved = 1 if dense1 else 0
+        for ci, c in enumerate(classes):
+            k = p.cls[ci]
+            k.nd, k.nh, k.nw = c["n"]
+            k.dd0, k.dh0, k.dw0 = c["first"]
+            k.sd, k.sh, k.sw = c["step"]
+            k.wbase = c["wbase"]
+            k.wsd, k.wsh, k.wsw = c["wstep"]
+            k.out_off_d, k.out_off_h, k.out_off_w = c["off"]
+        self.p, self.device, self.dense1 = p, x.device, dense1
+        ntaps = sum(c["n"][0] * c["n"][1] * c["n"][2] for c in classes)
+        self.flops = 2 * x.N * OD * OH * OW * ntaps * x.C * cout
+        self.kname = "conv16_kernel<%d,%d>" % (min(-(-(p.R * p.WT) // 16), 4), 2 if (p.cout_pad // 16) % 2 == 0 else 1)
+
+    def run(self, x, w16, scale, shift, y, res=None):
+        p = self.p
+        p.x, p.w = x.storage.data_ptr(), w16.data_ptr()
+        p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
+        if self.dense1:
+            p.y = y.data_ptr()
+            p.res = res.data_ptr() if res is not None else None
+            p.scale = p.shift = None
+        else:
+            p.y = y.storage.data_ptr()
+            p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
+            p.y_off0 = y.interior_off
+            p.scale, p.shift = scale.data_ptr(), shift.data_ptr()
+            if res is not None:
+                p.res = res.storage.data_ptr()
+                p.r_n_stride, p.r_cb_stride, p.r_d_stride, p.r_h_stride = res.n_stride, res.cb_stride, res.d_stride, res.h_stride
+                p.r_off0 = res.interior_off
+            else:
+                p.res = None
+        if TIMING is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        st = _lib.lib().drc_conv16_fwd(C.byref(p), _stream_ptr(self.device))
+        _lib.check(st, "drc_conv16_fwd")
+        if TIMING is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            TIMING.append((self.kname, self.flops, e0, e1))
+
+
+def plan_conv3d16(x, y, stride, cout, relu):
+    assert (x.pd, x.ph, x.pw) == (1, 1, 1)
+    return ConvPlan16(x, y, taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)), stride, 1, (y.D, y.H, y.W), cout, relu)
+
+
+def plan_deconv3d16(x, y, cout, relu):
+    assert (x.pd, x.ph, x.pw) == (1, 1, 1) and (y.D, y.H, y.W) == (2 * x.D, 2 * x.H, 2 * x.W)
+    return ConvPlan16(x, y, taps_deconv3d_k3s2(), 1, 2, (x.D, x.H, x.W), cout, relu)
+
+
+def plan_conv3d16_cout1(x):
+    return ConvPlan16(x, None, taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)), 1, 1, (x.D, x.H, x.W), 1, False, dense1=True)
+
+
+def cost_volume16_blocked(left, right, out, lo4, hi4, in_blocked_pad=-1):
+    """left/right fp32 NCHW (in_blocked_pad < 0) or fp32 blocked 2D storage (halo in_blocked_pad) -> out: Blocked16 [N,64,D',H',W'] halo 1."""
+    st = _lib.lib().drc_cost_volume16_blocked_fwd(_ptr(left), _ptr(right), _ptr(out.storage), out.N, out.C // 2, out.D, out.H, out.W,
+                                                  lo4, hi4, in_blocked_pad, _stream_ptr(out.device))
+    _lib.check(st, "drc_cost_volume16_blocked_fwd")

@@ -295,6 +295,100 @@ class PSMNetRuntime:
             prev = t[f"costk{k}"]
         return t["costk1"], t["costk2"], t["costk3"]
 
+    # ------------------------------------------------------------------ fp16-storage regressor (BASELINE configs[3]; eval only)
+    def _weights16(self, W):
+        """fp16 packings of the regressor's weights (conv16.hip), rebuilt with the packed fp32 weights."""
+        if getattr(self, "_w16_version", None) == self._weights_version and getattr(self, "_w16", None) is not None:
+            return self._w16
+        m, dev = self.model, self.device
+        out = {}
+        for name, c in W.items():
+            if isinstance(c, _Conv) and not name.startswith("fe."):
+                out[name] = E.pack_weight16(c.conv.weight.detach().to(device=dev, dtype=torch.float32), c.transposed)
+        for k in (1, 2, 3):
+            out[f"classif{k}.2"] = E.pack_weight16(getattr(m, f"classif{k}")[2].weight.detach().to(device=dev, dtype=torch.float32))
+        self._w16, self._w16_version = out, self._weights_version
+        return out
+
+    def _ws3d16(self, N, Dp, Hp, Wp):
+        key = ("3d16", N, Dp, Hp, Wp)
+        ws = self._ws_get(key)
+        if ws is not None:
+            return ws
+        pool = self._pool_for(("3d16", Dp, Hp, Wp), N)
+        full = (Dp, Hp, Wp)
+        half = tuple(-(-s // 2) for s in full)
+        quart = tuple(-(-s // 2) for s in half)
+        if tuple(2 * s for s in half) != full or tuple(2 * s for s in quart) != half:
+            raise ValueError(f"cost-volume dims {full} must be divisible by 4 (D,H,W multiples of 16; SURVEY 8)")
+        t = {}
+
+        def B(name, c, d, h, w):
+            t[name] = pool.blocked16(name, N, c, d, h, w, 1, 1, 1)
+
+        B("cost", 64, *full)
+        for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t1", "cls_t2", "cls_t3"):
+            B(n, 32, *full)
+        for k in (1, 2, 3):
+            B(f"hg{k}.c1", 64, *half); B(f"hg{k}.pre", 64, *half); B(f"hg{k}.post", 64, *half)
+            B(f"hg{k}.c3", 64, *quart); B(f"hg{k}.c4", 64, *quart)
+            t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
+        p = {}
+        p["dres0.0"] = E.plan_conv3d16(t["cost"], t["d0a"], 1, 32, True)
+        p["dres0.2"] = E.plan_conv3d16(t["d0a"], t["cost0a"], 1, 32, True)
+        p["dres1.0"] = E.plan_conv3d16(t["cost0a"], t["d1a"], 1, 32, True)
+        p["dres1.2"] = E.plan_conv3d16(t["d1a"], t["cost0"], 1, 32, False)
+        for k in (1, 2, 3):
+            src = t["cost0"] if k == 1 else t[f"out{k - 1}"]
+            p[f"hg{k}.conv1"] = E.plan_conv3d16(src, t[f"hg{k}.c1"], 2, 64, True)
+            p[f"hg{k}.conv2"] = E.plan_conv3d16(t[f"hg{k}.c1"], t[f"hg{k}.pre"], 1, 64, True)
+            p[f"hg{k}.conv3"] = E.plan_conv3d16(t[f"hg{k}.pre"], t[f"hg{k}.c3"], 2, 64, True)
+            p[f"hg{k}.conv4"] = E.plan_conv3d16(t[f"hg{k}.c3"], t[f"hg{k}.c4"], 1, 64, True)
+            p[f"hg{k}.conv5"] = E.plan_deconv3d16(t[f"hg{k}.c4"], t[f"hg{k}.post"], 64, True)
+            p[f"hg{k}.conv6"] = E.plan_deconv3d16(t[f"hg{k}.post"], t[f"out{k}"], 32, False)
+            p[f"classif{k}.0"] = E.plan_conv3d16(t[f"out{k}"], t[f"cls_t{k}"], 1, 32, True)
+            p[f"classif{k}.2"] = E.plan_conv3d16_cout1(t[f"cls_t{k}"])
+        ws = dict(t=t, p=p, pool=pool, flops=sum(pl.flops for pl in p.values()))
+        return self._ws_put(key, ws)
+
+    def _regress16(self, ws, W):
+        """The schedule of _regress on fp16-storage tensors (eval: BatchNorm folded into the fp32 epilogue)."""
+        t, p = ws["t"], ws["p"]
+        W16 = self._weights16(W)
+
+        def run(plan, wname, x, y, res=None):
+            c = W[wname]
+            p[plan].run(t[x], W16[wname], c.scale, c.shift, t[y], t[res] if res else None)
+
+        run("dres0.0", "dres0.0", "cost", "d0a")
+        run("dres0.2", "dres0.2", "d0a", "cost0a")
+        run("dres1.0", "dres1.0", "cost0a", "d1a")
+        run("dres1.2", "dres1.2", "d1a", "cost0", res="cost0a")
+        for k, hg in ((1, "dres2"), (2, "dres3"), (3, "dres4")):
+            src = "cost0" if k == 1 else f"out{k - 1}"
+            postsqu = None if k == 1 else f"hg{k - 1}.post"
+            presqu = f"hg{k}.pre" if k == 1 else "hg1.pre"
+            run(f"hg{k}.conv1", hg + ".conv1", src, f"hg{k}.c1")
+            run(f"hg{k}.conv2", hg + ".conv2", f"hg{k}.c1", f"hg{k}.pre", res=postsqu)
+            run(f"hg{k}.conv3", hg + ".conv3", f"hg{k}.pre", f"hg{k}.c3")
+            run(f"hg{k}.conv4", hg + ".conv4", f"hg{k}.c3", f"hg{k}.c4")
+            run(f"hg{k}.conv5", hg + ".conv5", f"hg{k}.c4", f"hg{k}.post", res=presqu)
+            run(f"hg{k}.conv6", hg + ".conv6", f"hg{k}.post", f"out{k}", res="cost0")
+        prev = None
+        for k in (1, 2, 3):
+            run(f"classif{k}.0", f"classif{k}.0", f"out{k}", f"cls_t{k}")
+            p[f"classif{k}.2"].run(t[f"cls_t{k}"], W16[f"classif{k}.2"], None, None, t[f"costk{k}"], prev)
+            prev = t[f"costk{k}"]
+        return t["costk1"], t["costk2"], t["costk3"]
+
+    def _use_f16(self, training):
+        mode = getattr(self.model, "regressor_storage", "f32")
+        if mode not in ("f32", "f16"):
+            raise ValueError("PSMNet.regressor_storage must be 'f32' or 'f16'")
+        if mode == "f16" and training:
+            raise RuntimeError("the fp16-storage regressor is an inference path (BASELINE configs[3]); train in fp32 like the reference")
+        return mode == "f16"
+
     def _check_disp(self):
         mx, mn = self.model.maxdisp, self.model.mindisp
         if (mx - mn) % 16 != 0 or mx % 4 != 0 or mn % 4 != 0:
@@ -334,6 +428,11 @@ class PSMNetRuntime:
             z = torch.empty(0, H, W, dtype=torch.float32, device=self.device)
             return (z, z.clone(), z.clone()) if training else z       # empty ROI batch (reference: disprcnn3d.py:272-275)
         Wt = self._compile()
+        if self._use_f16(training):
+            ws = self._ws3d16(N, (mx - mn) // 4, Hp, Wp)
+            self._stamp(ws)
+            E.cost_volume16_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, -1)
+            return self._heads(self._regress16(ws, Wt), N, H, W, mx, mn, False)
         ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
         self._stamp(ws)
         E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
@@ -459,6 +558,15 @@ class PSMNetRuntime:
         if N == 0:
             return disp
         Wt = self._compile()
+        if self._use_f16(training):
+            # fp32 2D feature CNN (its output is the cost volume's input), fp16-storage cost volume + 3D regressor
+            ws3 = self._ws3d16(N, (mx - mn) // 4, H // 4, W // 4)
+            ws2 = self._ws2d(2 * N, H, W)
+            self._stamp(ws3, ws2)
+            feat = self._features(ws2, Wt, torch.cat((left, right), 0))
+            fv = feat.storage
+            E.cost_volume16_blocked(fv, fv[N * feat.n_stride:], ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
+            return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
         ws3 = self._ws3d(N, (mx - mn) // 4, H // 4, W // 4)
         if training:
             # the reference runs feature_extraction(left) and feature_extraction(right) as two calls (stackhourglass.py:112-113):

@@ -50,6 +50,9 @@ class PSMNet(nn.Module):
         self.classif1, self.classif2, self.classif3 = _head(), _head(), _head()
         reference_init_(self)
         self._rt = None
+        # "f32" (the reference's precision, default) or "f16": cost volume + 3D regressor on fp16-storage tensors with fp32
+        # accumulation (inference only; BASELINE configs[3]).  Not a constructor argument: the reference signature is kept.
+        self.regressor_storage = "f32"
 
     # ------------------------------------------------------------------ engine plumbing
     def _runtime(self, device):

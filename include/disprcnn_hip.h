@@ -242,6 +242,18 @@ int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, 
 int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const int32_t* img_idx, int R, int img_w, int img_h,
                         float* rois_left, float* rois_right, int32_t* geom, void* stream);
 
+/* fp16-STORAGE regressor (BASELINE configs[3]: 64 ROIs at 224x224x96, "fp16"): activations as
+ * half[N][ceil(C/32)][D+2][H+2][W+2][32] (zero halo; strides and offsets of the params in ELEMENTS = halfs, voxel stride 32),
+ * weights half [taps][ceil(Cin/32)][cout_pad][32], BN scale/shift fp32, fp32 accumulation on v_mfma_f32_16x16x32_f16.
+ * Same tap-grid classes as drc_tapconv_fwd (Conv3d k3 stride 1|2, the 8 parity classes of ConvTranspose3d k3 s2); R*WT <= 64.
+ * params.reserved = 1 ("dense1"): only cout 0 is produced, as dense fp32 y[N,OD,OH,OW] (+ dense fp32 res) -- the 32 -> 1
+ * classifier conv with the cumulative head add (stackhourglass.py:78-88,142-144).  No reference counterpart (fp32-only). */
+int drc_conv16_fwd(const drc_tapconv_params* p, void* stream);
+/* fp32 features (NCHW if in_blocked_pad < 0, else the fp32 blocked 2D layout with that halo) -> fp16 blocked cost volume
+ * [N][2][Dp+2][Hp+2][Wp+2][32] (block 0 = left, block 1 = shifted right; stackhourglass.py:115-128); C <= 32. */
+int drc_cost_volume16_blocked_fwd(const float* left, const float* right, void* cost16, int N, int C, int Dp, int Hp, int Wp,
+                                  int mindisp4, int maxdisp4, int in_blocked_pad, void* stream);
+
 /* f4. Greedy NMS -- replaces disprcnn._C.nms for GPU tensors (reference csrc/nms.h:12-28 -> csrc/cuda/nms.cu:23-131; CPU twin
  * csrc/cpu/nms_cpu.cpp:5-75).  boxes_sorted [n,4] xyxy in DESCENDING score order (the caller sorts: torch.sort is plumbing);
  * IoU uses the legacy +1 pixel convention; a box is suppressed by an earlier kept box when IoU > thresh (strict = 1, the CUDA

@@ -1,0 +1,129 @@
+"""GPU tests of the fp16-STORAGE regressor (BASELINE configs[3]: 64 ROIs at 224x224x96, "fp16").
+
+The reference is fp32-only (config/defaults.py:22), so there is no fp16 oracle: single layers are held to the fp32 convolution of
+the SAME fp16-rounded operands (what fp16 storage + fp32 accumulation must reproduce up to the output rounding, 2^-11 relative),
+and the whole path to the fp32 oracle / the fp32 HIP path with the bound SURVEY 8c proposes: mean |err| <= 5e-2 px.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import psmnet_oracle as O
+from disprcnn_amd.utils import synth
+from tests.helpers import state_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _h(t):
+    return t.half().float()
+
+
+@pytest.mark.parametrize("cin,cout,stride,transposed,dims,with_res", [
+    (64, 32, 1, False, (4, 12, 28), True), (32, 32, 1, False, (3, 28, 28), False), (32, 64, 2, False, (12, 28, 28), False),
+    (64, 64, 2, False, (6, 14, 14), True), (64, 64, 1, False, (3, 7, 7), True), (64, 64, 1, True, (3, 7, 7), True),
+    (64, 32, 1, True, (6, 14, 14), False), (24, 40, 1, False, (2, 5, 9), True), (24, 16, 1, True, (3, 9, 30), True),
+    (40, 48, 2, False, (6, 10, 18), False), (32, 32, 1, False, (2, 56, 56), True)])
+def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, transposed, dims, with_res):
+    from disprcnn_amd import engine as E
+    n = 2
+    x = _h(synth.hash_uniform(f"h{cin}{cout}{stride}{transposed}:x", (n, cin) + dims))
+    w = _h(synth.hash_uniform(f"h{cin}{cout}:w", (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), -0.1, 0.1))
+    scale = synth.hash_uniform("h:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("h:b", (cout,), -0.5, 0.5)
+    ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1) if transposed else F.conv3d(x, w, None, stride, 1)
+    ref = ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    res = _h(synth.hash_uniform("h:r", tuple(ref.shape))) if with_res else None
+    ref = F.relu(ref + res) if with_res else ref
+    xb = E.Blocked16(n, cin, *dims, 1, 1, 1, dev).from_dense(x.to(dev))
+    od = tuple(ref.shape[2:])
+    yb = E.Blocked16(n, cout, *od, 1, 1, 1, dev)
+    rb = E.Blocked16(n, cout, *od, 1, 1, 1, dev).from_dense(res.to(dev)) if with_res else None
+    plan = E.plan_deconv3d16(xb, yb, cout, with_res) if transposed else E.plan_conv3d16(xb, yb, stride, cout, with_res)
+    cp = E.cout_pad_of(cout)
+    sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
+    sc[:cout] = scale.to(dev); sh[:cout] = shift.to(dev)
+    plan.run(xb, E.pack_weight16(w.to(dev), transposed), sc, sh, yb, rb)
+    got = yb.to_dense().cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    tol = 1e-3 * ref.abs().max().item() + 1e-3                       # fp16 output rounding (2^-11 relative) + fp32 summation order
+    assert err <= tol, (err, tol)
+    v = yb.view6()
+    assert v[:, :, 0].abs().sum() == 0 and v[:, :, :, 0].abs().sum() == 0 and v[:, :, :, :, -1].abs().sum() == 0     # halo intact
+
+
+def test_conv16_classifier_dense_head_and_cost_volume(dev):
+    from disprcnn_amd import engine as E
+    n, dims = 2, (6, 12, 20)
+    x = _h(synth.hash_uniform("hc1:x", (n, 32) + dims))
+    w = _h(synth.hash_uniform("hc1:w", (1, 32, 3, 3, 3), -0.1, 0.1))
+    prev = synth.hash_uniform("hc1:p", (n,) + dims)
+    ref = F.conv3d(x, w, None, 1, 1)[:, 0] + prev
+    xb = E.Blocked16(n, 32, *dims, 1, 1, 1, dev).from_dense(x.to(dev))
+    out = torch.empty(n, *dims, device=dev)
+    plan = E.plan_conv3d16_cout1(xb)
+    plan.run(xb, E.pack_weight16(w.to(dev)), None, None, out, prev.to(dev))
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5          # fp32 output: only summation order
+    # cost volume: the fp16 rounding of the reference volume, exactly (pure data movement)
+    fl, fr = synth.synth_features(2, 32, 28, 28, tag="h:cv")
+    for mx, mn in ((48, 0), (24, -24)):
+        cv = E.Blocked16(2, 64, (mx - mn) // 4, 28, 28, 1, 1, 1, dev)
+        E.cost_volume16_blocked(fl.to(dev), fr.to(dev), cv, mn // 4, mx // 4, -1)
+        assert torch.equal(cv.to_dense().cpu(), _h(O.cost_volume(fl, fr, mx, mn)))
+
+
+def _model(dev, case, mx, mn, storage):
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    m = PSMNet(mx, mn)
+    m.load_state_dict(state_for(case), strict=True)
+    m.regressor_storage = storage
+    return m.to(dev).eval()
+
+
+def test_config_a_f16_vs_fp32_oracle(dev):
+    """Config A from the feature boundary, fp16 storage vs the CPU fp32 oracle: stated bound mean <= 5e-2 px."""
+    sd = state_for("A")
+    m = _model(dev, "A", 48, 0, "f16")
+    fl, fr = synth.synth_features(4, 32, 28, 28, tag="f16A")
+    with torch.no_grad():
+        got = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
+        ref = O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)
+    err = (got - ref).abs()
+    print("Config A f16 storage: mean/max |err| px", err.mean().item(), err.max().item())
+    assert err.mean().item() <= 5e-2 and torch.isfinite(got).all()
+    with pytest.raises(RuntimeError, match="inference path"):
+        m.train().forward_from_features(fl.to(dev), fr.to(dev), (112, 112))
+
+
+def test_stress_shape_64_rois_f16_vs_fp32(dev):
+    """BASELINE configs[3]: 64 ROI crops 224x224, D=96 through the full PSMNet with the fp16-storage regressor, against the fp32 HIP
+    path on all 64 ROIs (itself held to the reference goldens) and against the CPU fp32 oracle on a sampled pair of ROIs."""
+    sd = state_for("B")
+    left, right = synth.synth_images(64, 224, 224, tag="stress16")
+    m16 = _model(dev, "B", 48, -48, "f16")
+    with torch.no_grad():
+        got = m16((left.to(dev), right.to(dev))).cpu()
+    bytes16 = m16._rt.workspace_bytes()
+    del m16
+    torch.cuda.empty_cache()
+    m32 = _model(dev, "B", 48, -48, "f32")
+    with torch.no_grad():
+        ref = m32((left.to(dev), right.to(dev))).cpu()
+    bytes32 = m32._rt.workspace_bytes()
+    err = (got - ref).abs()
+    print(f"stress 64 ROIs f16 vs f32 HIP: mean/max |err| px {err.mean().item():.4f} {err.max().item():.4f}; "
+          f"workspace {bytes16 / 2**30:.1f} GiB vs {bytes32 / 2**30:.1f} GiB")
+    assert err.mean().item() <= 5e-2 and torch.isfinite(got).all()
+    pick = [3, 41]
+    with torch.no_grad():
+        oref = O.psmnet_forward(sd, left[pick], right[pick], 48, -48)
+    oerr = (got[pick] - oref).abs()
+    print("stress f16 vs CPU fp32 oracle (2 ROIs): mean/max |err| px", oerr.mean().item(), oerr.max().item())
+    assert oerr.mean().item() <= 5e-2
