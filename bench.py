@@ -352,7 +352,20 @@ def rank0_extras(dev, extra):
         ts = _time(lambda: mB((l64, r64)), 1, 3)
     extra["stress_64roi_224x224x96_f32"] = {"roi_pairs_per_s": round(64 / ts, 1), "ms_per_64_roi_image": round(ts * 1e3, 2),
                                             "regressor_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / ts / 1e12, 1)}
-    del l64, r64
+    # ---- the same shape with the fp16-STORAGE regressor (configs[3] as named: "fp16"): fp16 cost volume + 3D regressor on the f16
+    # matrix cores with fp32 accumulation, fp32 2D CNN; accuracy bound in tests/test_hip_f16.py (mean <= 1e-1 px vs fp32)
+    mB.regressor_storage = "f16"
+    with torch.no_grad():
+        out16 = mB((l64, r64))
+        t16 = _time(lambda: mB((l64, r64)), 1, 3)
+    mB.regressor_storage = "f32"
+    with torch.no_grad():
+        err16 = (out16 - mB((l64, r64))).abs().mean().item()
+    extra["stress_64roi_224x224x96_f16_storage"] = {"roi_pairs_per_s": round(64 / t16, 1), "ms_per_64_roi_image": round(t16 * 1e3, 2),
+                                                    "regressor_direct_conv_equivalent_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / t16 / 1e12, 1),
+                                                    "mean_abs_err_px_vs_f32_path": round(err16, 4),
+                                                    "dtype": "f16 storage / f32 accumulate (v_mfma_f32_16x16x32_f16) for cost volume + 3D regressor; 2D CNN f32"}
+    del l64, r64, out16
     # ---- BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
     # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
     from types import SimpleNamespace as NS
