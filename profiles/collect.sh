@@ -5,7 +5,7 @@
 # --kernel-trace only (never combined with sys/runtime traces).  Raw CSVs land in gpurun_out/prof_<tag>/ (scratch);
 # profiles/summarize.py turns them into the small summaries committed under profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -41,8 +41,8 @@ def main(out, tag):
         for r in csv.DictReader(open(tr[0])):
             rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(sum(v) for v in rows.values()) or 1
-    lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-             "Command: `python bench.py --steps 10 --warmup 3 --no-cpu --no-extra` (plus the instrumented repeat of the same 10 steps)", ""]
+    cmd = os.environ.get("PROF_CMD", "python bench.py --steps 10 --warmup 3 --no-cpu --no-extra` (plus the instrumented repeat of the same 10 steps)")
+    lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "", f"Command: `{cmd}`" if not cmd.endswith(")") else f"Command: `{cmd}", ""]
     bl = os.path.join(out, "bench_line.json")
     if os.path.exists(bl):
         lines += ["bench.py line of this run:", "", "```", open(bl).read().strip(), "```", ""]
