@@ -64,6 +64,7 @@ _SIGS = {
     "drc_tapconv3d_slide_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_tapconv3d_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_deconv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_deconv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),

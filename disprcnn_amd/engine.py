@@ -265,6 +265,17 @@ def pack_weight_wino2d(w, transposed=False, flip=False):
     return out
 
 
+_DECONV_TAP_ORDER = [((1, 2, 0)[a] * 3 + (1, 2, 0)[b]) * 3 + (1, 2, 0)[c] for a in range(3) for b in range(3) for c in range(3)]
+
+
+def pack_weight_deconv_direct(w, transposed=True, flip=False):
+    """ConvTranspose3d weight [Cin,Cout,3,3,3] (or, for the data gradient of a stride-2 Conv3d, its weight read as one) ->
+    [cb_in][27][cout_pad][16]: the t16 packing re-ordered channel-block-major with the taps in deconvdirect.hip's use order."""
+    t16 = pack_layouts(w, transposed, flip, want_tap=False)[1]               # [27][cb][cout_pad][16]
+    order = torch.tensor(_DECONV_TAP_ORDER, device=t16.device)
+    return t16.index_select(0, order).permute(1, 0, 2, 3).contiguous()
+
+
 def pack_conv_weight(w, transposed=False):
     """The packing the engine's plan for this convolution expects (pointwise for 1x1 Conv2d, tap layout otherwise)."""
     return pack_weight_pw(w) if is_pointwise(w.shape, transposed) else pack_weight(w, transposed)
@@ -389,6 +400,7 @@ class ConvPlan:
         self.direct = False
         self.wino = False
         self.c2d = False
+        self.deconv_direct = False
         OD, OH, OW = grid_dhw
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
         p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
@@ -434,19 +446,26 @@ class ConvPlan:
             else:
                 self.kname = "tapslide_kernel<%d,%d>" % (nvt, self.slide_ct)
 
+    @property
+    def needs_t16(self):
+        """True when this plan's kernel reads the [tap][cb][cout][16] packing (the LDS-free kernels) instead of the tap layout."""
+        return bool(self.direct and (self.slide or self.down or self.c2d or self.deconv_direct))
+
     def pack16(self, w, transposed=False, flip=False):
         """The weight packing this plan's LDS-free kernel reads (None when the plan runs an LDS-staged kernel)."""
         if self.wino:
             return pack_weight_wino2d(w, transposed, flip) if self.c2d else pack_weight_wino(w, transposed, flip)
-        if self.direct and (self.slide or self.down or self.c2d):
+        if self.deconv_direct:
+            return pack_weight_deconv_direct(w, transposed, flip)
+        if self.needs_t16:
             return pack_layouts(w, transposed, flip, want_tap=False)[1]
         return None
 
     def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
         p = self.p
-        if self.direct and (self.slide or self.down or self.c2d):
+        if self.needs_t16:
             points = (16 if self.c2d else 64) if self.wino else (9 if self.c2d else 27)
-            if w16 is None or w16.shape[0] != points:
+            if w16 is None or w16.shape[1 if self.deconv_direct else 0] != points:
                 raise ValueError("this plan runs an LDS-free kernel: pass w16 = plan.pack16(weight)")
             w = w16
         relu_saved = p.relu
@@ -494,6 +513,9 @@ class ConvPlan:
         elif self.down:
             st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_fwd")
+        elif self.deconv_direct:
+            st = _lib.lib().drc_deconv3d_k3s2_direct_fwd(C.byref(p), self.deconv_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_deconv3d_k3s2_direct_fwd")
         elif self.fused_deconv:
             st = _lib.lib().drc_deconv3d_k3s2_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_deconv3d_k3s2_fwd")
@@ -572,6 +594,7 @@ def plan_conv3d(x, y, stride, cout, relu):
 
 
 FUSED_DECONV = {"enabled": True}
+DECONV_DIRECT = {"enabled": True}     # LDS-free fused transposed conv (deconvdirect.hip) instead of the LDS-staged tapdeconv.hip
 
 
 DECONV_TILE = None    # development override (tools/exp_conv.py)
@@ -604,6 +627,21 @@ def plan_deconv3d(x, y, cout, relu):
         pl.p.R, pl.p.WT = choose_tile_deconv(x.H, x.W)
         nvt = -(-(pl.p.R * pl.p.WT) // 16)
         pl.kname = "tapdeconv_kernel<%d,%d>" % (nvt, 2 if nvt <= 3 and (pl.p.cout_pad // 16) % 2 == 0 else 1)
+        if DIRECT["enabled"] and DECONV_DIRECT["enabled"]:
+            # 32 input voxels per wave; two cout tiles per wave when the cout tiles pair up (every layer of the regressor)
+            ct = pl.p.cout_pad // 16
+            CT = 2 if ct % 2 == 0 else 1
+            slots = 32
+            best = None
+            for r in range(1, x.H + 1):
+                for wt in range(1, min(x.W, slots // r) + 1):
+                    waste = (-(-x.H // r)) * (-(-x.W // wt)) * slots / (x.H * x.W)
+                    key = (-round(waste, 3), wt, r * wt)
+                    if best is None or key > best[0]:
+                        best = (key, r, wt)
+            pl.deconv_direct, pl.direct, pl.deconv_ct = True, True, CT
+            pl.p.R, pl.p.WT = best[1], best[2]
+            pl.kname = "deconvdirect_kernel<%d,%d>" % (slots // 16, CT)
     return pl
 
 
@@ -840,13 +878,15 @@ def pack_weight16(w, transposed=False):
 
 
 def choose_tile16(OH, OW):
-    """(R, WT) with R*WT <= 64 output voxels per wave: least MFMA padding, then the largest tile, then the widest rows."""
+    """(R, WT) with R*WT <= 64 output voxels per wave: four voxel tiles per weight load whenever the map allows (a 16-voxel tile
+    re-loads the weights four times as often: measured 788 vs ~250 us per full-resolution layer), then the least MFMA padding,
+    then the widest rows."""
     best = None
     for r in range(1, OH + 1):
         for wt in range(1, min(OW, 64 // r) + 1):
             nvt = -(-(r * wt) // 16)
             waste = (-(-OH // r)) * (-(-OW // wt)) * nvt * 16 / (OH * OW)
-            key = (-round(waste, 2), r * wt, wt)
+            key = (min(nvt, 4) if waste <= 1.35 else 0, -round(waste, 2), r * wt, wt)
             if best is None or key > best[0]:
                 best = (key, r, wt)
     return best[1], best[2]

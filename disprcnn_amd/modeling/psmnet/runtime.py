@@ -25,13 +25,13 @@ class _Conv:
         self.cin = w.shape[0] if transposed else w.shape[1]
         # the 3x3x3 Conv3d layers (stride 1 and 2) and the 3x3 Conv2d layers run on the LDS-free kernels, which read weights in
         # their own packing: both packings come out of one launch
-        need16 = (w.dim() == 5 and not transposed) or (w.dim() == 4 and tuple(w.shape[2:]) == (3, 3))
+        need16 = w.dim() == 5 or (w.dim() == 4 and tuple(w.shape[2:]) == (3, 3))
         if E.is_pointwise(w.shape, transposed):
             self.w, self.w16 = E.pack_weight_pw(w), None
         elif w.is_cuda:
             self.w, self.w16 = E.pack_layouts(w, transposed, want_t16=need16)
         else:
-            self.w, self.w16 = E.pack_weight(w, transposed), (E.pack_weight_t16(w) if need16 else None)
+            self.w, self.w16 = E.pack_weight(w, transposed), (E.pack_weight_t16(w, transposed) if need16 else None)
         self._ww = None
         cout_pad = E.cout_pad_of(self.cout)
         self.cout_pad, self.device = cout_pad, device
@@ -50,9 +50,9 @@ class _Conv:
 
     def w16_for(self, plan):
         """The LDS-free packing `plan` reads: t16, or the Winograd-transformed weights (built on first use)."""
-        if not plan.wino:
+        if not (plan.wino or plan.deconv_direct):
             return self.w16
-        if self._ww is None:
+        if self._ww is None:       # Winograd-transformed / transposed-conv-ordered packings come from the plan that reads them
             self._ww = plan.pack16(self.conv.weight.detach().to(device=self.device, dtype=torch.float32), self.transposed)
         return self._ww
 

@@ -117,11 +117,14 @@ class RegressorBackward:
             cache[plan_name] = ent
         # transformed weights, both packings from one launch (drc_pack_weights: in/out swap and tap flip are index arithmetic)
         pl = ent["plan"]
-        need16 = pl.direct and (pl.slide or pl.down or pl.c2d)
+        need16 = pl.needs_t16
         if deconv:                      # ConvTranspose weight [Cin,Cout,k] read as Conv[out=Cin, in=Cout]
             wp, w16 = E.pack_layouts(wt, False, False, want_t16=need16)
         elif stride == 2:               # Conv weight [Cout,Cin,k] as the transposed conv's [in=Cout, out=Cin]
-            wp, w16 = E.pack_layouts(wt, True, False, want_t16=need16)
+            if pl.deconv_direct:
+                wp, w16 = E.pack_layouts(wt, True, False, want_t16=False)[0], pl.pack16(wt, True, False)
+            else:
+                wp, w16 = E.pack_layouts(wt, True, False, want_t16=need16)
         elif pl.pointwise:              # 1x1: in/out swap only
             wp, w16 = E.pack_layouts(wt, True, False, want_tap=False)[1][0], None
         elif pl.wino:                   # stride 1 as Winograd: in/out swap + flipped taps inside the weight transform

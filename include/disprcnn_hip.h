@@ -145,6 +145,14 @@ int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, vo
  * per-lane address of the float4 B fragment.  Weights packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16). */
 int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* ConvTranspose3d(k3, s2, p1, output_padding 1) with all 8 output-parity classes from one register-resident set of B
+ * fragments, both MFMA operands straight from global memory (deconvdirect.hip; reference stackhourglass.py:22-30).  Params as
+ * for drc_deconv3d_k3s2_fwd (8 classes of engine.taps_deconv3d_k3s2, OD/OH/OW = INPUT dims, y exactly twice as large) but
+ * R*WT <= 32 input voxels per wave, cout_tiles_per_wave in {1, 2} dividing cout_pad/16; weights
+ * [cb_in][27][cout_pad][16]: the t16 layout of the ConvTranspose weight [Cin,Cout,3,3,3] re-ordered channel-block-major with the
+ * taps in the kernel's use order i = (a*3 + b)*3 + c -> tap ((K[a]*3 + K[b])*3 + K[c]), K = {1, 2, 0} (engine.pack_weight_deconv_direct). */
+int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+
 /* The stride-1 3x3x3 convolution of drc_tapconv3d_direct_fwd (same parameter block; R, WT and lds_bytes_per_wave ignored) as
  * Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: 64 instead of 216 multiplies per (cin, cout) pair and 2x2x2 output tile.
  * Needs even OD, OH, OW and N * x_n_stride * 4 < 2^32; weights from drc_pack_weights_wino.  Results differ from the direct

@@ -233,6 +233,33 @@ def test_winograd_weight_transform_vs_oracle(dev):
         assert (got.double() - ref).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("cin,cout,dims", [(64, 64, (3, 7, 7)), (64, 32, (6, 14, 14)), (16, 48, (2, 5, 9)), (24, 16, (3, 9, 30)), (64, 64, (1, 4, 4))])
+def test_deconv_lds_staged_variant_vs_oracle(dev, cin, cout, dims):
+    """tapdeconv.hip (LDS-staged fused transposed conv, the round-1 default) stays selectable with engine.DECONV_DIRECT off; the
+    default LDS-free deconvdirect.hip is what test_conv3d_layer_vs_oracle's transposed cases run."""
+    from disprcnn_amd import ops, engine as E
+    x = synth.hash_uniform(f"TD{cin}{cout}:x", (2, cin) + dims)
+    w = synth.hash_uniform(f"TD{cin}{cout}:w", (cin, cout, 3, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("TD:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("TD:b", (cout,), -0.5, 0.5)
+    ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    res = synth.hash_uniform("TD:r", tuple(ref.shape))
+    ref = F.relu(ref + res)
+    saved = E.DECONV_DIRECT["enabled"]
+    try:
+        E.DECONV_DIRECT["enabled"] = True
+        xb = E.Blocked(2, cin, *dims, 1, 1, 1, dev)
+        yb = E.Blocked(2, cout, *(2 * d for d in dims), 1, 1, 1, dev)
+        assert E.plan_deconv3d(xb, yb, cout, True).deconv_direct
+        E.DECONV_DIRECT["enabled"] = False
+        plan = E.plan_deconv3d(xb, yb, cout, True)
+        assert plan.fused_deconv and not plan.deconv_direct
+        got = ops.conv3d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, True, res.to(dev), True)
+    finally:
+        E.DECONV_DIRECT["enabled"] = saved
+    _close(got, ref)
+
+
 @pytest.mark.parametrize("kind,cin,cout,stride,dims", [("3d", 32, 32, 1, (6, 28, 28)), ("3d", 64, 32, 1, (4, 12, 28)), ("3d", 32, 64, 2, (12, 28, 28)),
                                                        ("3d", 16, 48, 2, (6, 10, 18)), ("2d", 32, 32, 1, (40, 56)), ("2d", 128, 128, 1, (28, 28))])
 def test_lds_staged_variants_vs_oracle(dev, kind, cin, cout, stride, dims):
