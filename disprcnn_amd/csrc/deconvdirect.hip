@@ -13,9 +13,12 @@
 //   * a tap streams its weights (CT float4 per lane from [cb][27 combinations in use order][cout][16], DD_AHEAD taps ahead) against them: 4*VT*CT MFMAs into
 //     the accumulators of its parity class (8 classes x VT x CT tiles);
 //   * 8*VT + 27*CT loads per 108*VT*CT MFMAs (70 per 432 at VT = 2, CT = 2): the vector-memory path idles, nothing touches LDS.
-// Epilogue per class: BN scale/shift, residual, ReLU, one float4 store per (voxel, cout tile) at output (2i + parity).
+// Epilogue per class: BN scale/shift, residual, ReLU, one float4 store per (voxel, cout tile) at output (2i + parity); in the last
+// channel block the taps run class by class and a finished class's epilogue overlaps the next class's MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
 
@@ -30,12 +33,28 @@ namespace {
 
 // the 27 (class, shift, tap) combinations, class-major so that consecutive taps reuse accumulators late (dependent MFMAs on one
 // accumulator are VT*CT*... issues apart anyway); per dimension: parity p, shift s, kernel index k
-struct Combo { int cls, pos, tap; };
+struct Combo { int cls, pos, tap; bool last_of_class; };
 constexpr int kP[3] = {0, 1, 1}, kS[3] = {0, 0, 1}, kK[3] = {1, 2, 0};
-constexpr Combo combo(int i) {
+constexpr Combo combo_raw(int i) {
     const int a = i / 9, b = (i / 3) % 3, c = i % 3;
-    return Combo{(kP[a] * 2 + kP[b]) * 2 + kP[c], (kS[a] * 2 + kS[b]) * 2 + kS[c], (kK[a] * 3 + kK[b]) * 3 + kK[c]};
+    return Combo{(kP[a] * 2 + kP[b]) * 2 + kP[c], (kS[a] * 2 + kS[b]) * 2 + kS[c], (kK[a] * 3 + kK[b]) * 3 + kK[c], false};
 }
+// use order: class-major (class 7 = odd/odd/odd with 8 taps first ... class 0 with one tap last), so that in the last channel
+// block a class is complete -- and its epilogue can run in the shadow of the next classes' MFMAs -- as early as possible
+struct ComboTable { Combo c[27]; };
+constexpr ComboTable make_table() {
+    ComboTable t{};
+    int i = 0;
+    for (int cls = 7; cls >= 0; --cls) {
+        int first = i;
+        for (int r = 0; r < 27; ++r)
+            if (combo_raw(r).cls == cls) t.c[i++] = combo_raw(r);
+        t.c[i - 1].last_of_class = true;
+        (void)first;
+    }
+    return t;
+}
+constexpr ComboTable kTab = make_table();
 
 template <int VT, int CT>
 __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_tapconv_params p) {
@@ -101,8 +120,34 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
                 for (int vt = 0; vt < VT; ++vt) B[pos][vt] = *(const f32x4*)(sp + lane_vo[vt]);
             }
         };
-        // all 27 taps of one channel block against the B fragments in registers; weights DD_AHEAD taps ahead
-        auto block = [&](const f32x4 (&B)[8][VT], int cb) __attribute__((always_inline)) {
+        f32x4 bn_sc[CT], bn_sh[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
+            bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
+        }
+        // class (pd, ph, pw) -> output voxel (2*id + pd, 2*r + ph, 2*c + pw): a uniform 64-bit base per (class, cout tile) plus the
+        // 32-bit byte offset of slot vt's even-corner output voxel (no per-store 64-bit lane arithmetic to hoist and spill)
+        unsigned yv[VT], rv[VT];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) {
+            yv[vt] = (unsigned)((2 * (ih0 + rr[vt]) * (int)p.y_h_stride + 2 * (iw0 + cc[vt]) * 16 + g * 4) * 4);
+            rv[vt] = (unsigned)((2 * (ih0 + rr[vt]) * (int)p.r_h_stride + 2 * (iw0 + cc[vt]) * 16 + g * 4) * 4);
+        }
+        auto y_base = [&](int c, int ct) __attribute__((always_inline)) {
+            return (char*)(p.y + p.y_off0 + (int64_t)n * p.y_n_stride + (int64_t)(ct0 + ct) * p.y_cb_stride + (int64_t)(2 * id + (c >> 2)) * p.y_d_stride +
+                           (int64_t)((c >> 1) & 1) * p.y_h_stride + (c & 1) * 16);
+        };
+        auto r_base = [&](int c, int ct) __attribute__((always_inline)) {
+            return (const char*)(p.res + p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)(ct0 + ct) * p.r_cb_stride + (int64_t)(2 * id + (c >> 2)) * p.r_d_stride +
+                                 (int64_t)((c >> 1) & 1) * p.r_h_stride + (c & 1) * 16);
+        };
+        f32x4 resq[VT][CT];
+        // all 27 taps of one channel block against the B fragments in registers; weights DD_AHEAD taps ahead.  LAST (the final
+        // channel block): the residual of a class is requested when its first tap starts and its epilogue (BN, residual, ReLU,
+        // stores) follows its last tap, i.e. runs in the shadow of the next class's MFMAs.
+        auto block = [&](const f32x4 (&B)[8][VT], int cb, auto last_tag) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_tag)::value;
             const char* wb = (const char*)p.w + (size_t)cb * 27u * w_tap_b;            // uniform: SGPR base + lane offset + immediate
             f32x4 wq[DD_AHEAD + 1][CT];
 #pragma unroll
@@ -111,11 +156,19 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
                 for (int ct = 0; ct < CT; ++ct) wq[a][ct] = *(const f32x4*)(wb + (unsigned)a * w_tap_b + ct * 1024 + wlane);
 #pragma unroll
             for (int i = 0; i < 27; ++i) {
-                const Combo q = combo(i);
+                constexpr int dummy_ = 0; (void)dummy_;
+                const Combo q = kTab.c[i];
                 if (i + DD_AHEAD < 27) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         wq[(i + DD_AHEAD) % (DD_AHEAD + 1)][ct] = *(const f32x4*)(wb + (unsigned)(i + DD_AHEAD) * w_tap_b + ct * 1024 + wlane);
+                }
+                if (LAST && p.res && (i == 0 || kTab.c[i > 0 ? i - 1 : 0].last_of_class)) {
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            resq[vt][ct] = *(const f32x4*)(r_base(q.cls, ct) + rv[vt]);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -125,45 +178,36 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
                         for (int ct = 0; ct < CT; ++ct)
                             acc[q.cls][vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i % (DD_AHEAD + 1)][ct][s], B[q.pos][vt][s], acc[q.cls][vt][ct], 0, 0, 0);
                 // keep the loads where they are written: without the fence the scheduler sinks every weight load to its use (three
-                // weight registers in total, a full L2 round trip exposed per tap: 598 us instead of ~300 for conv6 at 256 ROIs)
+                // weight registers in total, a full L2 round trip exposed per tap: 598 us instead of ~410 for conv6 at 256 ROIs)
                 __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        load_b(bA, 0);
-#pragma unroll 1
-        for (int cb = 0; cb < p.cb_in; cb += 2) {
-            load_b(bB, cb + 1 < p.cb_in ? cb + 1 : cb);
-            block(bA, cb);
-            if (cb + 1 < p.cb_in) {
-                load_b(bA, cb + 2 < p.cb_in ? cb + 2 : cb + 1);
-                block(bB, cb + 1);
-            }
-        }
-
-        // ---- epilogue: class (pd, ph, pw) -> output voxel (2*id + pd, 2*r + ph, 2*c + pw)
-        f32x4 bn_sc[CT], bn_sh[CT];
+                if (LAST && q.last_of_class) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            bn_sc[ct] = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
-            bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
-        }
+                    for (int vt = 0; vt < VT; ++vt) {
+                        if (!valid[vt]) continue;
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt) {
-            if (!valid[vt]) continue;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int od = 2 * id + (c >> 2), oh = 2 * (ih0 + rr[vt]) + ((c >> 1) & 1), ow = 2 * (iw0 + cc[vt]) + (c & 1);
-                const int64_t yo = p.y_off0 + (int64_t)n * p.y_n_stride + (int64_t)od * p.y_d_stride + (int64_t)oh * p.y_h_stride + (int64_t)ow * 16 + g * 4;
-                const int64_t ro = p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)od * p.r_d_stride + (int64_t)oh * p.r_h_stride + (int64_t)ow * 16 + g * 4;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    f32x4 v_ = acc[c][vt][ct] * bn_sc[ct] + bn_sh[ct];
-                    if (p.res) v_ += *(const f32x4*)(p.res + ro + (int64_t)(ct0 + ct) * p.r_cb_stride);
-                    if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
-                    *(f32x4*)(p.y + yo + (int64_t)(ct0 + ct) * p.y_cb_stride) = v_;
+                        for (int ct = 0; ct < CT; ++ct) {
+                            f32x4 v_ = acc[q.cls][vt][ct] * bn_sc[ct] + bn_sh[ct];
+                            if (p.res) v_ += resq[vt][ct];
+                            if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
+                            *(f32x4*)(y_base(q.cls, ct) + yv[vt]) = v_;
+                        }
+                    }
                 }
             }
+        };
+        // straight-line control flow (accumulators that merge from several paths get shuttled through VGPRs and spill): every block
+        // but the last runs out of set A while set B receives the next block, then B is copied to A (64 moves per 432 MFMAs)
+        load_b(bA, 0);
+#pragma unroll 1
+        for (int cb = 0; cb + 1 < p.cb_in; ++cb) {
+            load_b(bB, cb + 1);
+            block(bA, cb, std::false_type{});
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos)
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) bA[pos][vt] = bB[pos][vt];
         }
+        block(bA, p.cb_in - 1, std::true_type{});
     }
 }
 
@@ -190,7 +234,9 @@ extern "C" int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* pp, int co
     if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
     if (p.n_classes != 8 || p.in_mul != 1 || p.out_mul != 2) return -4;
     if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 32) return -3;
-    if ((int64_t)(p.OH + 2) * p.x_h_stride * 4 >= (1LL << 31)) return -5;       // 32-bit lane offsets within a slice
+    if ((int64_t)(p.OH + 2) * p.x_h_stride * 4 >= (1LL << 31) || (int64_t)(2 * p.OH + 2) * p.y_h_stride * 4 >= (1LL << 31) ||
+        (p.res && (int64_t)(2 * p.OH + 2) * p.r_h_stride * 4 >= (1LL << 31)))
+        return -5;                                                             // 32-bit lane offsets within a slice
     const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;
     const int nvt = (p.R * p.WT + 15) / 16;
     hipStream_t s = (hipStream_t)stream;

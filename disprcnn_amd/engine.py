@@ -265,7 +265,15 @@ def pack_weight_wino2d(w, transposed=False, flip=False):
     return out
 
 
-_DECONV_TAP_ORDER = [((1, 2, 0)[a] * 3 + (1, 2, 0)[b]) * 3 + (1, 2, 0)[c] for a in range(3) for b in range(3) for c in range(3)]
+def _deconv_tap_order():
+    """deconvdirect.hip's use order of the 27 taps: class-major (output-parity class 7 first ... class 0 last); within a class the
+    (parity, shift, k) combinations (0,0,1), (1,0,2), (1,1,0) per dimension in lexicographic order."""
+    P, K = (0, 1, 1), (1, 2, 0)
+    raw = [((P[a] * 2 + P[b]) * 2 + P[c], (K[a] * 3 + K[b]) * 3 + K[c]) for a in range(3) for b in range(3) for c in range(3)]
+    return [tap for cls in range(7, -1, -1) for (c_, tap) in raw if c_ == cls]
+
+
+_DECONV_TAP_ORDER = _deconv_tap_order()
 
 
 def pack_weight_deconv_direct(w, transposed=True, flip=False):
