@@ -9,6 +9,7 @@ from disprcnn_amd import engine as E, ops
 
 torch.manual_seed(0)
 dev = torch.device("cuda:0")
+
 E.SLIDE["min_od"], E.SLIDE["min_units"] = 2, 1
 worst = 0.0
 for (n, cin, cout, d, h, w) in [(1, 16, 16, 2, 2, 2), (2, 32, 32, 4, 6, 6), (3, 20, 40, 6, 4, 10), (5, 64, 32, 12, 28, 28), (2, 64, 64, 6, 14, 14),
