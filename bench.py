@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+DEFAULT_ROIS = 1024                  # ROI pairs per step and GPU: 64 images x 16 ROIs (BASELINE configs[1] has 16 ROIs per image)
 FLOPS_PER_VOXEL_3D = 644544          # conv FLOPs (2*MAC) of dres0..classif3 per cost-volume voxel
 FLOPS_2D_PER_IMAGE = 22192734208     # feature_extraction conv FLOPs per 224x224 image
 FLOPS_BACKBONE_PAIR = 250.3e9        # R-50-FPN on one 2x3x375x1242 stereo pair
@@ -141,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rois", type=int, default=256, help="ROI pairs per step per GPU")
+    ap.add_argument("--rois", type=int, default=DEFAULT_ROIS, help="ROI pairs per step per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (Config B, stress, KITTI pair, train step, post-processing)")
     ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_flow.py: control flow on gloo, no kernels
@@ -240,6 +241,17 @@ def main():
                                 "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in agg.items()}
         step_flops = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * N
         extra["regressor_tflops_whole_step"] = round(step_flops * args.steps * world / elapsed / 1e12 / world, 2)
+        # batch sensitivity of the same workload (round 1's headline used 256 ROI pairs per step): tile-group rounds and per-launch
+        # tails amortise with the batch; 288 GB of HBM hold far more than 1024 ROIs' activations (1.6 GB)
+        if not args.no_extra:
+            bs = {}
+            for nb in (256, 512):
+                if nb >= N:
+                    continue
+                with torch.no_grad():
+                    tb_ = _time(lambda: model.forward_from_features(fl[:nb], fr[:nb], (112, 112)), 2, 5)
+                bs[str(nb)] = {"roi_pairs_per_s": round(nb / tb_, 1), "ms_per_step": round(tb_ * 1e3, 3)}
+            extra["batch_sensitivity_rois_per_step"] = bs
 
     # ---- extras.  The train step is the only one with a collective (one flat gradient all-reduce): EVERY rank enters it.
     # The others have none and run on rank 0 at world size 1 only (the scaling runs stay short; their numbers do not depend on N).

@@ -2,7 +2,7 @@
 
 At the golden fixtures' own batch size (2 ROIs) the launch heuristics send the stride-1 3x3x3 layers to the generic kernel, so
 the reference-recorded whole-path goldens never touched wino3d / the LDS-free kernels.  Here the recorded inputs are
-replicated to the bench's batch (256 ROI pairs per step; 16 crops for Config B) -- ROIs are independent units, so every replica
+replicated to the bench's batch (bench.DEFAULT_ROIS ROI pairs per step; 16 crops for Config B) -- ROIs are independent units, so every replica
 must reproduce the reference's output -- and the kernel names of every launch plan are asserted to be exactly the bench's.
 Tolerances as in test_hip_parity.py: mean <= 1e-3 px, max <= 2e-2 px vs the reference's fp32 outputs.
 """
@@ -38,19 +38,20 @@ def _assert_bench_kernels(ws):
     for k in (1, 2, 3):
         assert p[f"hg{k}.conv4"].direct and p[f"hg{k}.conv4"].slide and not p[f"hg{k}.conv4"].wino      # 3x7x7: odd dims -> tapdirect
         assert p[f"hg{k}.conv1"].kname.startswith("downdirect_kernel") and p[f"hg{k}.conv3"].kname.startswith("downdirect_kernel")
-        assert p[f"hg{k}.conv5"].fused_deconv and p[f"hg{k}.conv6"].fused_deconv
+        assert p[f"hg{k}.conv5"].deconv_direct and p[f"hg{k}.conv6"].deconv_direct
     return {n: pl.kname for n, pl in p.items()}
 
 
 @pytest.mark.parametrize("case,mx,mn", [("A", 48, 0), ("At", 48, 0), ("A2", 24, -24)])
 def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn):
-    """256 ROI pairs = the recorded 2-ROI input replicated 128 times: the bench's plans (Winograd on the ten even stride-1
-    layers, LDS-free direct / stride-2 kernels, fused transposed conv) reproduce the reference's recorded disparities and
-    sampled intermediates in EVERY replica."""
+    """The bench's batch (bench.DEFAULT_ROIS ROI pairs per step) = the recorded 2-ROI input replicated: the bench's plans (Winograd
+    on the ten even stride-1 layers, LDS-free direct / stride-2 kernels, LDS-free fused transposed conv) reproduce the reference's
+    recorded disparities and sampled intermediates in EVERY replica."""
+    import bench
     z = golden_npz()
     m = _model(dev, "At" if case == "At" else "A", mx, mn)
     fl, fr = synth.synth_features(2, 32, 28, 28, tag="caseA")
-    N = 256
+    N = bench.DEFAULT_ROIS
     fl, fr = fl.repeat(N // 2, 1, 1, 1).to(dev), fr.repeat(N // 2, 1, 1, 1).to(dev)
     with torch.no_grad():
         pred = m.forward_from_features(fl, fr, (112, 112)).cpu()
@@ -60,37 +61,40 @@ def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn):
     assert names["hg1.conv1"] == "downdirect_kernel<7,4>" and names["dres0.0"] == "wino3d_kernel<2>", names
     ref = torch.from_numpy(z[f"{case}_pred"])
     err = (pred.view(N // 2, 2, 112, 112) - ref[None]).abs()
-    print(case, "N=256 mean/max err px", err.mean().item(), err.max().item())
+    print(case, f"N={N} mean/max err px", err.mean().item(), err.max().item())
     assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
     # replicas agree with each other bitwise (no cross-ROI state, FMA order independent of the position in the batch)
-    assert torch.equal(pred[0:2], pred[254:256]) and torch.equal(pred[0:2], pred[100:102])
+    assert torch.equal(pred[0:2], pred[N - 2:N]) and torch.equal(pred[0:2], pred[100:102])
     vox = Dp * 28 * 28
     cost3 = ws["t"]["costk3"].cpu().reshape(N // 2, 2 * vox)
     idx = torch.from_numpy(z[f"{case}_cost3_idx"]); val = torch.from_numpy(z[f"{case}_cost3_val"])
-    for rep in (0, 63, 127):
+    for rep in (0, 63, N // 2 - 1):
         assert (cost3[rep][idx] - val).abs().max().item() < 1e-3 * max(1.0, val.abs().max().item())
     out3 = ws["t"]["out3"].to_dense().cpu().reshape(N // 2, -1)
     idx = torch.from_numpy(z[f"{case}_out3_idx"]); val = torch.from_numpy(z[f"{case}_out3_val"])
-    for rep in (0, 63, 127):
+    for rep in (0, 63, N // 2 - 1):
         assert (out3[rep][idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4
 
 
-def test_config_a_n256_distinct_rois_vs_oracle_subset(dev):
-    """One bench-sized step on 256 DISTINCT synthetic ROI pairs (the bench's own inputs); a sampled subset of ROIs is checked
-    against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py)."""
+def test_config_a_bench_batch_distinct_rois_vs_oracle_subset(dev):
+    """One bench-sized step on DISTINCT synthetic ROI pairs (the bench's own inputs, bench.DEFAULT_ROIS of them); a sampled subset
+    of ROIs is checked against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py).  The round-1 batch of 256
+    is checked the same way: the launch heuristics depend on the batch."""
+    import bench
     sd = state_for("A")
     m = _model(dev, "A", 48, 0)
-    fl, fr = synth.synth_features(256, 32, 28, 28, tag="bench0")
-    with torch.no_grad():
-        pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
-    _assert_bench_kernels(m._rt._ws[("3d", 256, 12, 28, 28)])
-    pick = [0, 37, 128, 255]
-    with torch.no_grad():
-        ref = O.psmnet_from_features(sd, fl[pick], fr[pick], 48, 0, 112, 112)
-    err = (pred[pick] - ref).abs()
-    print("N=256 subset mean/max err px", err.mean().item(), err.max().item())
-    assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
-    assert torch.isfinite(pred).all() and pred.min() >= 0 and pred.max() <= 47
+    for N in (bench.DEFAULT_ROIS, 256):
+        fl, fr = synth.synth_features(N, 32, 28, 28, tag="bench0")
+        with torch.no_grad():
+            pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
+        _assert_bench_kernels(m._rt._ws[("3d", N, 12, 28, 28)])
+        pick = [0, 37, N // 2, N - 1]
+        with torch.no_grad():
+            ref = O.psmnet_from_features(sd, fl[pick], fr[pick], 48, 0, 112, 112)
+        err = (pred[pick] - ref).abs()
+        print(f"N={N} subset mean/max err px", err.mean().item(), err.max().item())
+        assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (N, err.mean().item(), err.max().item())
+        assert torch.isfinite(pred).all() and pred.min() >= 0 and pred.max() <= 47
 
 
 def test_config_b_golden_replicated_to_16_crops(dev):
