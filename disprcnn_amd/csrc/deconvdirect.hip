@@ -7,7 +7,7 @@
 // k = 0 at input i + 1).  Per dimension that is three (parity, input shift, k) combinations -- (0,0,1), (1,0,2), (1,1,0) -- and
 // 27 in 3D: exactly the 27 taps, each used once, i.e. 27 MACs per (cin, cout) pair and INPUT voxel and no multiply wasted.
 // tapdeconv.hip stages the input tile through LDS per 8-channel phase and issues 16 / 8 MFMAs per tap step (62 TFLOP/s, 63 %
-// LDS bank conflicts, bound by memory-instruction issue).  Here a wave owns VT*16 input voxels of one slice and CT*16 couts:
+// LDS bank conflicts, bound by memory-instruction issue).  Here a wave owns VT*16 consecutive input voxels and CT*16 couts:
 //   * the eight shifted B fragments (input shifts {0,1}^3) of a 16-channel block are loaded ONCE -- 8*VT coalesced float4 per
 //     lane -- one channel block ahead (second register set), and stay in registers for all 27 taps;
 //   * a tap streams its weights (CT float4 per lane from [cb][27 combinations in use order][cout][16], DD_AHEAD taps ahead) against them: 4*VT*CT MFMAs into
@@ -63,39 +63,42 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
     const int j = lane & 15;
     const int g = lane >> 4;
 
-    // logical grid = the INPUT grid (OD, OH, OW of the params are the input dims; the output is exactly twice as large)
-    const int n_wt = (p.OW + p.WT - 1) / p.WT, n_rt = (p.OH + p.R - 1) / p.R;
+    // logical grid = the INPUT grid (OD, OH, OW of the params are the input dims; the output is exactly twice as large).  A tile is
+    // VT*16 CONSECUTIVE voxels of the flattened (n, d, h, w) index -- every lane carries its own voxel offset, the eight input
+    // shifts and the eight output parities are uniform offsets on top -- so only the very last tile of a launch is ragged
+    // (per-slice 2x14 tiles wasted 12.5 % of conv6's MFMA slots, 4x7 tiles 24 % of conv5's).
+    const long voxels = (long)p.N * p.OD * p.OH * p.OW;
+    const long tiles = (voxels + VT * 16 - 1) / (VT * 16);
     const int n_cg = p.cout_pad / 16 / CT;
-    const long items = (long)p.N * p.OD * n_rt * n_wt * n_cg;
-    const int nslots = p.R * p.WT;
+    const long items = tiles * n_cg;
     const unsigned w_tap_b = (unsigned)p.cout_pad * 64;    // bytes per (cb, combination): weights are packed [cb][27 combinations][cout][16]
     const long workers = (long)gridDim.x * DD_WAVES;
     const long wid = (long)blockIdx.x * DD_WAVES + wave;
 
 #pragma unroll 1
     for (long it = wid; it < items; it += workers) {
-        long t = it;
-        const int cg = (int)(t % n_cg); t /= n_cg;
-        const int wt_i = (int)(t % n_wt); t /= n_wt;
-        const int rt_i = (int)(t % n_rt); t /= n_rt;
-        const int id = (int)(t % p.OD);
-        const int n = (int)(t / p.OD);
-        const int ih0 = rt_i * p.R, iw0 = wt_i * p.WT, ct0 = cg * CT;
+        const int cg = (int)(it % n_cg);
+        const long tile = it / n_cg;
+        const int ct0 = cg * CT;
 
-        // per-lane byte offset of input voxel slot (vt, j) at shift (0,0,0): padded coordinates = logical + 1
-        unsigned lane_vo[VT];
+        // per-lane byte offsets of input voxel slot (vt, j) at shift (0,0,0) (padded coordinates = logical + 1) and of its even-corner
+        // output / residual voxel
+        unsigned lane_vo[VT], yv[VT], rv[VT];
         bool valid[VT];
-        int rr[VT], cc[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) {
-            const int s = vt * 16 + j;
-            int r = s / p.WT, c = s - r * p.WT;
-            valid[vt] = s < nslots && ih0 + r < p.OH && iw0 + c < p.OW;
-            if (!valid[vt]) { r = 0; c = 0; }
-            rr[vt] = r; cc[vt] = c;
-            lane_vo[vt] = (unsigned)(((ih0 + r + 1) * (int)p.x_h_stride + (iw0 + c + 1) * 16 + g * 4) * 4);
+            long q = tile * (VT * 16) + vt * 16 + j;
+            valid[vt] = q < voxels;
+            if (!valid[vt]) q = 0;
+            const int c = (int)(q % p.OW); q /= p.OW;
+            const int r = (int)(q % p.OH); q /= p.OH;
+            const int id = (int)(q % p.OD);
+            const int n = (int)(q / p.OD);
+            lane_vo[vt] = (unsigned)((n * p.x_n_stride + (int64_t)(id + 1) * p.x_d_stride + (int64_t)(r + 1) * p.x_h_stride + (c + 1) * 16 + g * 4) * 4);
+            yv[vt] = (unsigned)((n * p.y_n_stride + (int64_t)(2 * id) * p.y_d_stride + (int64_t)(2 * r) * p.y_h_stride + 2 * c * 16 + g * 4) * 4);
+            rv[vt] = (unsigned)((n * p.r_n_stride + (int64_t)(2 * id) * p.r_d_stride + (int64_t)(2 * r) * p.r_h_stride + 2 * c * 16 + g * 4) * 4);
         }
-        const char* xs = (const char*)(p.x + (int64_t)n * p.x_n_stride + (int64_t)(id + 1) * p.x_d_stride);
+        const char* xs = (const char*)p.x;
         const unsigned wlane = (unsigned)(((ct0 * 16 + j) * 16 + g * 4) * 4);      // this lane's byte offset inside a combination's weights
 
         f32x4 acc[8][VT][CT];
@@ -127,20 +130,14 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
             bn_sh[ct] = *(const f32x4*)(p.shift + (ct0 + ct) * 16 + g * 4);
         }
         // class (pd, ph, pw) -> output voxel (2*id + pd, 2*r + ph, 2*c + pw): a uniform 64-bit base per (class, cout tile) plus the
-        // 32-bit byte offset of slot vt's even-corner output voxel (no per-store 64-bit lane arithmetic to hoist and spill)
-        unsigned yv[VT], rv[VT];
-#pragma unroll
-        for (int vt = 0; vt < VT; ++vt) {
-            yv[vt] = (unsigned)((2 * (ih0 + rr[vt]) * (int)p.y_h_stride + 2 * (iw0 + cc[vt]) * 16 + g * 4) * 4);
-            rv[vt] = (unsigned)((2 * (ih0 + rr[vt]) * (int)p.r_h_stride + 2 * (iw0 + cc[vt]) * 16 + g * 4) * 4);
-        }
+        // lane's 32-bit even-corner offset (no per-store 64-bit lane arithmetic to hoist and spill)
         auto y_base = [&](int c, int ct) __attribute__((always_inline)) {
-            return (char*)(p.y + p.y_off0 + (int64_t)n * p.y_n_stride + (int64_t)(ct0 + ct) * p.y_cb_stride + (int64_t)(2 * id + (c >> 2)) * p.y_d_stride +
-                           (int64_t)((c >> 1) & 1) * p.y_h_stride + (c & 1) * 16);
+            return (char*)(p.y + p.y_off0 + (int64_t)(ct0 + ct) * p.y_cb_stride + (int64_t)(c >> 2) * p.y_d_stride + (int64_t)((c >> 1) & 1) * p.y_h_stride +
+                           (c & 1) * 16);
         };
         auto r_base = [&](int c, int ct) __attribute__((always_inline)) {
-            return (const char*)(p.res + p.r_off0 + (int64_t)n * p.r_n_stride + (int64_t)(ct0 + ct) * p.r_cb_stride + (int64_t)(2 * id + (c >> 2)) * p.r_d_stride +
-                                 (int64_t)((c >> 1) & 1) * p.r_h_stride + (c & 1) * 16);
+            return (const char*)(p.res + p.r_off0 + (int64_t)(ct0 + ct) * p.r_cb_stride + (int64_t)(c >> 2) * p.r_d_stride + (int64_t)((c >> 1) & 1) * p.r_h_stride +
+                                 (c & 1) * 16);
         };
         f32x4 resq[VT][CT];
         // all 27 taps of one channel block against the B fragments in registers; weights DD_AHEAD taps ahead.  LAST (the final
@@ -213,8 +210,8 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
 
 template <int VT, int CT>
 int launch(const drc_tapconv_params& p, hipStream_t stream) {
-    const long n_wt = (p.OW + p.WT - 1) / p.WT, n_rt = (p.OH + p.R - 1) / p.R;
-    const long items = (long)p.N * p.OD * n_rt * n_wt * (p.cout_pad / 16 / CT);
+    const long voxels = (long)p.N * p.OD * p.OH * p.OW;
+    const long items = ((voxels + VT * 16 - 1) / (VT * 16)) * (p.cout_pad / 16 / CT);
     long workers = 256L * DD_WAVES;                      // one wave per SIMD (the two B sets + 8 accumulator classes fill the file)
     if (workers > items) workers = items;
     if (workers < 1) workers = 1;
@@ -233,14 +230,12 @@ extern "C" int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* pp, int co
     if (p.N == 0) return 0;
     if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
     if (p.n_classes != 8 || p.in_mul != 1 || p.out_mul != 2) return -4;
-    if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 32) return -3;
-    if ((int64_t)(p.OH + 2) * p.x_h_stride * 4 >= (1LL << 31) || (int64_t)(2 * p.OH + 2) * p.y_h_stride * 4 >= (1LL << 31) ||
-        (p.res && (int64_t)(2 * p.OH + 2) * p.r_h_stride * 4 >= (1LL << 31)))
-        return -5;                                                             // 32-bit lane offsets within a slice
+    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32) || (int64_t)p.N * p.y_n_stride * 4 >= (1LL << 32) ||
+        (p.res && (int64_t)p.N * p.r_n_stride * 4 >= (1LL << 32)))
+        return -5;                                                             // 32-bit lane offsets over the whole batch
     const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;
-    const int nvt = (p.R * p.WT + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    if (CT == 2 && ct % 2 == 0 && nvt <= 2) return launch<2, 2>(p, s);
-    if (CT == 1 && nvt <= 2) return launch<2, 1>(p, s);
-    return -3;
+    if (CT == 2 && ct % 2 == 0) return launch<2, 2>(p, s);
+    if (CT == 1) return launch<2, 1>(p, s);
+    return -2;
 }

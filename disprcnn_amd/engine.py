@@ -635,21 +635,14 @@ def plan_deconv3d(x, y, cout, relu):
         pl.p.R, pl.p.WT = choose_tile_deconv(x.H, x.W)
         nvt = -(-(pl.p.R * pl.p.WT) // 16)
         pl.kname = "tapdeconv_kernel<%d,%d>" % (nvt, 2 if nvt <= 3 and (pl.p.cout_pad // 16) % 2 == 0 else 1)
-        if DIRECT["enabled"] and DECONV_DIRECT["enabled"]:
-            # 32 input voxels per wave; two cout tiles per wave when the cout tiles pair up (every layer of the regressor)
+        if (DIRECT["enabled"] and DECONV_DIRECT["enabled"] and x.N * x.n_stride * 4 < 2 ** 32 and y.N * y.n_stride * 4 < 2 ** 32):
+            # LDS-free kernel: 32 consecutive voxels of the flattened (n,d,h,w) index per wave (no tile shape), two cout tiles per wave
+            # when the cout tiles pair up (every layer of the regressor)
             ct = pl.p.cout_pad // 16
             CT = 2 if ct % 2 == 0 else 1
-            slots = 32
-            best = None
-            for r in range(1, x.H + 1):
-                for wt in range(1, min(x.W, slots // r) + 1):
-                    waste = (-(-x.H // r)) * (-(-x.W // wt)) * slots / (x.H * x.W)
-                    key = (-round(waste, 3), wt, r * wt)
-                    if best is None or key > best[0]:
-                        best = (key, r, wt)
             pl.deconv_direct, pl.direct, pl.deconv_ct = True, True, CT
-            pl.p.R, pl.p.WT = best[1], best[2]
-            pl.kname = "deconvdirect_kernel<%d,%d>" % (slots // 16, CT)
+            pl.p.R, pl.p.WT = 1, min(x.W, 32)
+            pl.kname = "deconvdirect_kernel<2,%d>" % CT
     return pl
 
 

@@ -147,8 +147,9 @@ int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_w
 
 /* ConvTranspose3d(k3, s2, p1, output_padding 1) with all 8 output-parity classes from one register-resident set of B
  * fragments, both MFMA operands straight from global memory (deconvdirect.hip; reference stackhourglass.py:22-30).  Params as
- * for drc_deconv3d_k3s2_fwd (8 classes of engine.taps_deconv3d_k3s2, OD/OH/OW = INPUT dims, y exactly twice as large) but
- * R*WT <= 32 input voxels per wave, cout_tiles_per_wave in {1, 2} dividing cout_pad/16; weights
+ * for drc_deconv3d_k3s2_fwd (8 classes of engine.taps_deconv3d_k3s2, OD/OH/OW = INPUT dims, y exactly twice as large); R, WT are
+ * ignored (a wave takes 32 consecutive voxels of the flattened (n,d,h,w) index); needs N * {x,y,r}_n_stride * 4 < 2^32;
+ * cout_tiles_per_wave in {1, 2} dividing cout_pad/16; weights
  * [cb_in][27][cout_pad][16]: the t16 layout of the ConvTranspose weight [Cin,Cout,3,3,3] re-ordered channel-block-major with the
  * taps in the kernel's use order i = (a*3 + b)*3 + c -> tap ((K[a]*3 + K[b])*3 + K[c]), K = {1, 2, 0} (engine.pack_weight_deconv_direct). */
 int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
