@@ -39,6 +39,12 @@ class DrcTapconvParams(C.Structure):
                 ("cls", DrcTapClass * DRC_MAX_CLASSES)]
 
 
+class DrcCostvolSrc(C.Structure):
+    _fields_ = [("left", C.c_void_p), ("right", C.c_void_p),
+                ("n_stride", C.c_int64), ("cb_stride", C.c_int64), ("h_stride", C.c_int64),
+                ("cbi", C.c_int32), ("pad", C.c_int32), ("lo4", C.c_int32), ("Wp", C.c_int32)]
+
+
 class DrcWgradParams(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p),
                 ("a_n_stride", C.c_int64), ("a_cb_stride", C.c_int64), ("a_d_stride", C.c_int64), ("a_h_stride", C.c_int64),
@@ -68,6 +74,7 @@ _SIGS = {
     "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_conv3d_k3_wino_costvol_fwd": (_I, [C.POINTER(DrcTapconvParams), C.POINTER(DrcCostvolSrc), _I, _P]),
     "drc_disparity_paste_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "drc_roi_depth_maps_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "drc_conv2d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),

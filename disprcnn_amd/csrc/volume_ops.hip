@@ -191,6 +191,36 @@ __global__ __launch_bounds__(kThreads) void dense_to_blocked_kernel(const float*
     }
 }
 
+// The same conversion with one block per (n, d, y) line: the C channel rows of the line (W contiguous floats each) are read once,
+// coalesced along x, transposed through LDS (row stride 16*CB + 1: conflict-free) and written as CB rows of W x 64 contiguous
+// bytes.  The thread-per-float4 form above gathers four plane-strided scalars per lane (8x over-fetch on the read side).
+__global__ __launch_bounds__(kThreads) void dense_to_blocked_rows_kernel(const float* __restrict__ dense, float* __restrict__ blk, int C,
+                                                                         int D, int H, int W, int pd, int ph, int pw) {
+    extern __shared__ float d2b_lds[];                      // [W][16*CB + 1]
+    const int CB = (C + 15) / 16, cs = 16 * CB + 1;
+    int t = blockIdx.x;
+    const int y = t % H; t /= H;
+    const int d = t % D;
+    const int n = t / D;
+    const long plane = (long)D * H * W;
+    const int xl = threadIdx.x & 31, sub = threadIdx.x >> 5, nsub = kThreads >> 5;
+    for (int c = sub; c < 16 * CB; c += nsub) {
+        const float* src = dense + ((long)n * C + c) * plane + ((long)d * H + y) * W;
+        for (int x = xl; x < W; x += 32) d2b_lds[x * cs + c] = c < C ? src[x] : 0.f;
+    }
+    __syncthreads();
+    const long bW = W + 2 * pw, bH = H + 2 * ph, bD = D + 2 * pd;
+    const int total = CB * W * 4;
+    for (int idx = threadIdx.x; idx < total; idx += kThreads) {
+        const int q = idx & 3;
+        const int x = (idx >> 2) % W;
+        const int cb = (idx >> 2) / W;
+        const float* s4 = d2b_lds + x * cs + cb * 16 + q * 4;
+        *(f32x4*)(blk + ((((long)n * CB + cb) * bD + (d + pd)) * bH * bW + (long)(y + ph) * bW + (x + pw)) * 16 + q * 4) =
+            (f32x4){s4[0], s4[1], s4[2], s4[3]};
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void blocked_to_dense_kernel(const float* __restrict__ blk, float* __restrict__ dense, int N, int C,
                                                                     int D, int H, int W, int pd, int ph, int pw) {
     const int CB = (C + 15) / 16;
@@ -571,7 +601,12 @@ int drc_dense_to_blocked(const float* dense, float* blk, int N, int C, int D, in
     const long total = (long)N * ((C + 15) / 16) * D * H * W * 4;
     if (total == 0) return 0;
     if (!dense || !blk) return -1;
-    hipLaunchKernelGGL(dense_to_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, dense, blk, N, C, D, H, W, pd, ph, pw);
+    const size_t lds = (size_t)W * (((C + 15) / 16) * 16 + 1) * sizeof(float);
+    const long lines = (long)N * D * H;
+    if (W >= 8 && lds <= 64 * 1024 && lines < (1L << 31))
+        hipLaunchKernelGGL(dense_to_blocked_rows_kernel, dim3((unsigned)lines), dim3(kThreads), lds, (hipStream_t)stream, dense, blk, C, D, H, W, pd, ph, pw);
+    else
+        hipLaunchKernelGGL(dense_to_blocked_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, dense, blk, N, C, D, H, W, pd, ph, pw);
     return done();
 }
 

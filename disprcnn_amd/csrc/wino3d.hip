@@ -30,8 +30,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int CT>
-__global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv_params p) {
+// CV = the cost volume fused into the input loads (dres0[0], stackhourglass.py:115-130): instead of a materialised
+// [N][2C/16][D'+2][H'+2][W'+2][16] volume the patch loads read the blocked 2D feature maps directly -- channel blocks
+// < cbi from the left map at (y, x), the others from the right map at (y, x - i), i = lo4 + slice -- and a load whose voxel
+// is outside the volume or fails the validity test 0 <= x - i < W' is pointed at a halo voxel of the map (zero).
+template <int CT, bool CV>
+__device__ __forceinline__ void wino3d_body(const drc_tapconv_params& p, const drc_costvol_src& cv) {
     // per wave: the in-plane inverse (2x2 x CT float4 per lane) of depth frequencies 0..2 of the tile group in flight; the
     // last frequency combines them along depth and runs the epilogue.  Written once, read once.
     __shared__ __attribute__((aligned(16))) f32x4 z_lds[WN_WAVES][3][4 * CT][64];
@@ -84,8 +88,11 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
         q.ht = tile % TH; tile /= TH;
         q.dt = tile % TD;
         q.n = tile / TD;
-        q.xo = (unsigned)((q.n * p.x_n_stride + (2 * q.dt + cls.dd0) * p.x_d_stride + (2 * q.ht + cls.dh0) * p.x_h_stride +
-                           (int64_t)(2 * q.wt + cls.dw0) * 16 + g * 4) * 4);
+        if constexpr (CV)
+            q.xo = (unsigned)((q.n * cv.n_stride + (2 * q.ht - 1 + cv.pad) * cv.h_stride + (int64_t)(2 * q.wt - 1 + cv.pad) * 16 + g * 4) * 4);
+        else
+            q.xo = (unsigned)((q.n * p.x_n_stride + (2 * q.dt + cls.dd0) * p.x_d_stride + (2 * q.ht + cls.dh0) * p.x_h_stride +
+                               (int64_t)(2 * q.wt + cls.dw0) * 16 + g * 4) * 4);
         return q;
     };
     // depth butterfly of frequency xd: slice a + sgn * slice b  (d0-d2, d1+d2, d2-d1, d1-d3)
@@ -98,6 +105,39 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
         for (int w = 0; w < 4; ++w) {
             ra[w] = *(const f32x4*)(sa + ((int64_t)h * p.x_h_stride + w * 16) * 4 + xo);
             rb[w] = *(const f32x4*)(sb + ((int64_t)h * p.x_h_stride + w * 16) * 4 + xo);
+        }
+    };
+    // the same row of the two slices, read from the feature maps (CV): patch voxel (slice s, row h, column w) of tile
+    // (dt, ht, wt) is volume voxel (d, y, x) = (2dt-1+s, 2ht-1+h, 2wt-1+w); disparity i = lo4 + d, xs = x - i.  The eight
+    // column offsets of a step (two slices x four columns; a voxel outside the volume or failing 0 <= xs < W' is pointed at
+    // halo column 0 of its row) are worked out once per step, ahead of its first row load; the row term is wave-uniform.
+    unsigned cvo[2][4];
+    auto cv_offsets = [&](int cb, int xd, const Geo& q) __attribute__((always_inline)) {
+        const bool right = cb >= cv.cbi;                                  // wave-uniform
+        const int d0 = 2 * q.dt - 1, x0 = 2 * q.wt - 1;
+        const int k = x0 - cv.lo4 - d0;                                   // xs = k - s + w
+        const unsigned zrow = q.xo - (unsigned)((x0 + cv.pad) * 64);
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+            const int s = ab == 0 ? slice_a(xd) : slice_b(xd);
+            const int d = d0 + s;
+            const bool ind = (unsigned)d < (unsigned)p.OD;
+            const unsigned rs = q.xo - (right ? (unsigned)((cv.lo4 + d) * 64) : 0u);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const bool ok = ind && (unsigned)(x0 + w) < (unsigned)cv.Wp && (unsigned)(k - s + w) < (unsigned)cv.Wp;
+                cvo[ab][w] = ok ? rs + (unsigned)(w * 64) : zrow;
+                asm volatile("" : "+v"(cvo[ab][w]));
+            }
+        }
+    };
+    auto load_row_cv = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], int cb, int h) __attribute__((always_inline)) {
+        const bool right = cb >= cv.cbi;
+        const char* base = (const char*)((right ? cv.right : cv.left) + (int64_t)(right ? cb - cv.cbi : cb) * cv.cb_stride + (int64_t)h * cv.h_stride);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            ra[w] = *(const f32x4*)(base + cvo[0][w]);
+            rb[w] = *(const f32x4*)(base + cvo[1][w]);
         }
     };
     auto bfly_row = [&](f32x4 (&t)[4], const f32x4 (&ra)[4], const f32x4 (&rb)[4], float sgn) __attribute__((always_inline)) {
@@ -178,6 +218,10 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
         sa = (const char*)(p.x + (int64_t)c.cb * p.x_cb_stride + (int64_t)slice_a(c.xd) * p.x_d_stride);
         sb = (const char*)(p.x + (int64_t)c.cb * p.x_cb_stride + (int64_t)slice_b(c.xd) * p.x_d_stride);
     };
+    auto ld = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], const char* sa, const char* sb, const Cursor& c, int h, const Geo& q) __attribute__((always_inline)) {
+        if constexpr (CV) load_row_cv(ra, rb, c.cb, h);
+        else load_row(ra, rb, sa, sb, h, q.xo);
+    };
     Cursor c0 = {0, 0, 0};                 // the step whose MFMAs run
     Cursor c1 = advance(c0);               // the step whose rows are being transformed (rows 2, 3 still loading)
     Geo geo0 = geo_of(0);
@@ -187,9 +231,10 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
     {
         const char *sa, *sb;
         slices_of(c0, sa, sb);
+        if constexpr (CV) cv_offsets(c0.cb, c0.xd, geo0);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            load_row(r0a, r0b, sa, sb, h, geo0.xo);
+            ld(r0a, r0b, sa, sb, c0, h, geo0);
             bfly_row(tn[h], r0a, r0b, -1.f);
         }
 #pragma unroll
@@ -197,8 +242,9 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
             v[0][w] = tn[0][w] - tn[2][w]; v[1][w] = tn[1][w] + tn[2][w]; v[2][w] = tn[2][w] - tn[1][w]; v[3][w] = tn[1][w] - tn[3][w];
         }
         slices_of(c1, sa, sb);
-        load_row(r0a, r0b, sa, sb, 0, geo1.xo);
-        load_row(r1a, r1b, sa, sb, 1, geo1.xo);
+        if constexpr (CV) cv_offsets(c1.cb, c1.xd, geo1);
+        ld(r0a, r0b, sa, sb, c1, 0, geo1);
+        ld(r1a, r1b, sa, sb, c1, 1, geo1);
     }
 
     int slab = 0;
@@ -220,7 +266,7 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
 
         boundary(slab_a);
         load_w(wfA, slab_a, 0);
-        load_row(r2a, r2b, sa1, sb1, 2, geo1.xo);
+        ld(r2a, r2b, sa1, sb1, c1, 2, geo1);
         load_w(wfB, slab_a, 1);
         // h butterfly, rows 1..3 of this step's B fragments (row 0 was finished at the end of the previous step): in the shadow
         // of row 0's MFMAs, before tn[1..3] are overwritten by the next step's rows
@@ -232,18 +278,19 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
         bfly_row(tn[0], r0a, r0b, sgn);
         WN_MFMA_ROW(0, wfA)
         __builtin_amdgcn_sched_barrier(0);
-        load_row(r3a, r3b, sa1, sb1, 3, geo1.xo);
+        ld(r3a, r3b, sa1, sb1, c1, 3, geo1);
         bfly_row(tn[1], r1a, r1b, sgn);
         WN_MFMA_ROW(1, wfB)
         __builtin_amdgcn_sched_barrier(0);
         boundary(slab_b);
         load_w(wfA, slab_b, 2);
-        load_row(r0a, r0b, sa2, sb2, 0, geo2.xo);
+        if constexpr (CV) cv_offsets(c2.cb, c2.xd, geo2);
+        ld(r0a, r0b, sa2, sb2, c2, 0, geo2);
         load_w(wfB, slab_b, 3);
         bfly_row(tn[2], r2a, r2b, sgn);
         WN_MFMA_ROW(2, wfA)
         __builtin_amdgcn_sched_barrier(0);
-        load_row(r1a, r1b, sa2, sb2, 1, geo2.xo);
+        ld(r1a, r1b, sa2, sb2, c2, 1, geo2);
         bfly_row(tn[3], r3a, r3b, sgn);
         WN_MFMA_ROW(3, wfB)
         __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +368,17 @@ __global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv
 }
 
 template <int CT>
-int launch(const drc_tapconv_params& p, hipStream_t stream) {
+__global__ __launch_bounds__(64 * WN_WAVES) void wino3d_kernel(const drc_tapconv_params p) {
+    wino3d_body<CT, false>(p, drc_costvol_src{});
+}
+
+template <int CT>
+__global__ __launch_bounds__(64 * WN_WAVES) void wino3d_cv_kernel(const drc_tapconv_params p, const drc_costvol_src cv) {
+    wino3d_body<CT, true>(p, cv);
+}
+
+template <int CT>
+int launch(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_t stream) {
     const long tiles = (long)p.N * (p.OD / 2) * (p.OH / 2) * (p.OW / 2);
     const long groups = (tiles + 15) / 16;
     const int n_cg = p.cout_pad / 16 / CT;
@@ -331,7 +388,10 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     if (per_cg > need) per_cg = need;
     if (per_cg < 1) per_cg = 1;
     dim3 grid((unsigned)(per_cg * n_cg), 1, 1);
-    hipLaunchKernelGGL((wino3d_kernel<CT>), grid, dim3(64 * WN_WAVES), 0, stream, p);
+    if (cv)
+        hipLaunchKernelGGL((wino3d_cv_kernel<CT>), grid, dim3(64 * WN_WAVES), 0, stream, p, *cv);
+    else
+        hipLaunchKernelGGL((wino3d_kernel<CT>), grid, dim3(64 * WN_WAVES), 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -381,10 +441,10 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* pp, int cout_tiles_per_wave, void* stream) {
+static int wino_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, int cout_tiles_per_wave, void* stream) {
     if (!pp) return -1;
     const drc_tapconv_params& p = *pp;
-    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if ((!cv && !p.x) || !p.w || !p.y || !p.scale || !p.shift) return -1;
     if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
     if (p.N == 0) return 0;
     if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
@@ -392,12 +452,26 @@ extern "C" int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* pp, int cout_til
     if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 || k.sw != 1)
         return -4;
     if ((p.OD | p.OH | p.OW) & 1) return -4;                                   // whole 2x2x2 tiles only
-    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;             // 32-bit lane offsets over the whole batch
+    if (!cv && (int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;      // 32-bit lane offsets over the whole batch
+    if (cv) {
+        if (!cv->left || !cv->right) return -1;
+        if (cv->pad < 1 || cv->cbi <= 0 || p.cb_in != 2 * cv->cbi || cv->Wp != p.OW) return -2;
+        if ((int64_t)p.N * cv->n_stride * 4 >= (1LL << 32)) return -5;
+    }
     if ((int64_t)p.N * p.OD * p.OH * p.OW / 8 >= (1LL << 31) - 16 || (int64_t)64 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
     const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;
     if ((CT != 1 && CT != 2) || ct % CT) return -2;
     hipStream_t s = (hipStream_t)stream;
-    return CT == 2 ? launch<2>(p, s) : launch<1>(p, s);
+    return CT == 2 ? launch<2>(p, cv, s) : launch<1>(p, cv, s);
+}
+
+extern "C" int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* pp, int cout_tiles_per_wave, void* stream) {
+    return wino_fwd(pp, nullptr, cout_tiles_per_wave, stream);
+}
+
+extern "C" int drc_conv3d_k3_wino_costvol_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, int cout_tiles_per_wave, void* stream) {
+    if (!cv) return -1;
+    return wino_fwd(pp, cv, cout_tiles_per_wave, stream);
 }
 
 extern "C" int drc_pack_weights_wino(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream) {

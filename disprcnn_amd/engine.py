@@ -539,8 +539,50 @@ class ConvPlan:
             TIMING.append((self.kname, self.flops, e0, e1))
 
 
+    def run_costvol(self, left, right, lo4, w16, scale, shift, y):
+        """dres0[0] straight from the feature maps (the cost volume is never materialised): `left`, `right` are blocked 2D feature
+        tensors (D = 1, no depth halo, halo >= 1 in y and x) of the same geometry holding this plan's N maps each -- `right` may
+        be a (Blocked, first_unit) pair naming a later range of the same tensor.  Only Winograd plans (plan.wino) have this form.
+        Reference: stackhourglass.py:115-130."""
+        if not (self.wino and not self.c2d):
+            raise ValueError("run_costvol needs a 3D Winograd plan")
+        r_first = 0
+        if isinstance(right, tuple):
+            right, r_first = right
+        p = self.p
+        for f in (left, right):
+            if f.D != 1 or f.pd != 0 or f.ph < 1 or f.ph != f.pw or f.W != p.OW or f.H != p.OH or 2 * f.cb != p.cb_in:
+                raise ValueError("run_costvol: feature maps do not match the plan's volume")
+        if (right.n_stride, right.cb_stride, right.h_stride, right.ph) != (left.n_stride, left.cb_stride, left.h_stride, left.ph):
+            raise ValueError("run_costvol: left and right feature maps differ in geometry")
+        if left.N < p.N or right.N < r_first + p.N:
+            raise ValueError("run_costvol: fewer feature maps than volume units")
+        if w16 is None or w16.shape[0] != 64:
+            raise ValueError("run_costvol: pass w16 = plan.pack16(weight)")
+        cv = _lib.DrcCostvolSrc()
+        cv.left = _base_ptr(left)
+        cv.right = _base_ptr(right) + 4 * r_first * right.n_stride
+        cv.n_stride, cv.cb_stride, cv.h_stride = left.n_stride, left.cb_stride, left.h_stride
+        cv.cbi, cv.pad, cv.lo4, cv.Wp = left.cb, left.ph, int(lo4), left.W
+        p.x = None
+        p.y = _base_ptr(y)
+        p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
+        p.y_off0 = y.interior_off
+        p.w, p.scale, p.shift = w16.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        p.res = None
+        if TIMING is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        st = _lib.lib().drc_conv3d_k3_wino_costvol_fwd(C.byref(p), C.byref(cv), self.slide_ct, _stream_ptr(self.device))
+        _lib.check(st, "drc_conv3d_k3_wino_costvol_fwd")
+        if TIMING is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            TIMING.append((self.kname.replace("wino3d_kernel", "wino3d_cv_kernel"), self.flops, e0, e1))
+
+
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
-WINO = {"enabled": True}      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
+WINO = {"enabled": True,      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
+        "fuse_costvol": True} # eval: dres0[0] reads the feature maps directly, the cost volume is never written (wino3d_cv_kernel)
 WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)

@@ -267,14 +267,23 @@ class PSMNetRuntime:
         ws = dict(t=t, p=p, pool=pool, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
         return self._ws_put(key, ws)
 
-    def _regress(self, ws, W):
-        """dres0..dres4 + classif heads on ws['t']['cost'] -> dense cost3 [N,D',H',W'] (reference :130-144)."""
+    def _fuse_costvol(self, ws, training):
+        """Eval with a Winograd dres0[0]: the cost volume is folded into that layer's input loads (wino3d_cv_kernel)."""
+        return bool(not training and self._tape is None and E.WINO["fuse_costvol"] and ws["p"]["dres0.0"].wino)
+
+    def _regress(self, ws, W, cv=None):
+        """dres0..dres4 + classif heads on ws['t']['cost'] -> dense cost3 [N,D',H',W'] (reference :130-144).
+        cv = (left, right, lo4): dres0[0] reads the blocked feature maps instead of a materialised volume (:115-130)."""
         t, p = ws["t"], ws["p"]
 
         def run(plan, wname, x, y, res=None):
             self._site(ws, W, plan, wname, x, y, res)
 
-        run("dres0.0", "dres0.0", "cost", "d0a")
+        if cv is not None:
+            c, pl = W["dres0.0"], p["dres0.0"]
+            pl.run_costvol(cv[0], cv[1], cv[2], c.w16_for(pl), c.scale, c.shift, t["d0a"])
+        else:
+            run("dres0.0", "dres0.0", "cost", "d0a")
         run("dres0.2", "dres0.2", "d0a", "cost0a")
         run("dres1.0", "dres1.0", "cost0a", "d1a")
         run("dres1.2", "dres1.2", "d1a", "cost0", res="cost0a")           # dres1(cost0)+cost0, no relu
@@ -435,8 +444,14 @@ class PSMNetRuntime:
             return self._heads(self._regress16(ws, Wt), N, H, W, mx, mn, False)
         ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
         self._stamp(ws)
-        E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
-        costs = self._regress(ws, Wt)
+        cv = None
+        if self._fuse_costvol(ws, training):
+            pool = ws["pool"]
+            cv = (pool.blocked("featL", N, 32, 1, Hp, Wp, 0, 1, 1).from_dense(fl),
+                  pool.blocked("featR", N, 32, 1, Hp, Wp, 0, 1, 1).from_dense(fr), mn // 4)
+        else:
+            E.cost_volume_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, 0)
+        costs = self._regress(ws, Wt, cv)
         self._last_train = (ws, Wt, costs, mx, mn, (H, W))
         self._last_gens = self._generations(ws)
         return self._heads(costs, N, H, W, mx, mn, training)
@@ -568,6 +583,7 @@ class PSMNetRuntime:
             E.cost_volume16_blocked(fv, fv[N * feat.n_stride:], ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
             return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
         ws3 = self._ws3d(N, (mx - mn) // 4, H // 4, W // 4)
+        cv = None
         if training:
             # the reference runs feature_extraction(left) and feature_extraction(right) as two calls (stackhourglass.py:112-113):
             # batch statistics and running-stat updates are per call, so the two views must not share a batch here
@@ -582,10 +598,13 @@ class PSMNetRuntime:
             ws2 = self._ws2d(2 * N, H, W)
             self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, torch.cat((left, right), 0))
-            fv = feat.storage
-            right_view = fv[N * feat.n_stride:]
-            E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
-        costs = self._regress(ws3, Wt)
+            if self._fuse_costvol(ws3, training):
+                cv = (feat, (feat, N), mn // 4)
+            else:
+                fv = feat.storage
+                right_view = fv[N * feat.n_stride:]
+                E.cost_volume_blocked(fv, right_view, ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
+        costs = self._regress(ws3, Wt, cv)
         self._last_train = (ws3, Wt, costs, mx, mn, (H, W))
         return self._heads(costs, N, H, W, mx, mn, training)
 

@@ -160,6 +160,26 @@ int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per
  * kernels' by fp32 rounding only (about twice the direct kernel's own error against fp64). */
 int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* Source of a cost volume that is never materialised: the two channel-blocked, zero-haloed 2D feature maps of N ROI pairs /
+ * image pairs.  Voxel (n, cb, y, x) of a side lives at side + n*n_stride + cb*cb_stride + (y+pad)*h_stride + (x+pad)*16 (floats);
+ * the first voxel of every (n, cb) plane must be a (zero) halo voxel, i.e. pad >= 1. */
+typedef struct drc_costvol_src {
+    const float* left;
+    const float* right;
+    int64_t n_stride, cb_stride, h_stride;
+    int32_t cbi;   /* channel blocks per side (C/16) */
+    int32_t pad;
+    int32_t lo4;   /* disparity of volume slice 0 (mindisp/4) */
+    int32_t Wp;    /* feature-map width W' */
+} drc_costvol_src;
+
+/* dres0[0] with the cost volume fused into its input loads (reference stackhourglass.py:115-130 + :63-66): the convolution of
+ * drc_conv3d_k3_wino_fwd applied to cost[n, c, j, y, x] = (c < C ? left[n, c, y, x] : right[n, c-C, y, x-i]) if 0 <= x-i < W'
+ * else 0, i = lo4 + j, without the volume ever reaching HBM.  p->x is ignored, p->cb_in = 2*cbi, p->OD = D' slices, p->OW = Wp;
+ * the same weights, epilogue and limits as drc_conv3d_k3_wino_fwd (N * n_stride * 4 < 2^32).  Results are bit-identical to
+ * drc_cost_volume_blocked_fwd followed by drc_conv3d_k3_wino_fwd. */
+int drc_conv3d_k3_wino_costvol_fwd(const drc_tapconv_params* p, const drc_costvol_src* cv, int cout_tiles_per_wave, void* stream);
+
 /* Conv2d 3x3, stride 1, dilation 1, pad 1 (same parameter block as drc_conv2d_k3_direct_fwd; R, WT ignored) as Winograd
  * F(2x2, 3x3): 16 instead of 36 multiplies per (cin, cout) pair and 2x2 output tile.  Needs even OH, OW and
  * N * x_n_stride * 4 < 2^32; weights from drc_pack_weights_wino2d ([16 = xh*4+xw][ceil(Cin/16)][cout_pad][16]). */

@@ -87,6 +87,23 @@ def test_layout_roundtrip_full_size(dev):
     assert abs(b.storage.double().sum().item() - x.double().sum().item()) < 1e-6 * x.numel()
 
 
+@pytest.mark.parametrize("shape,pads", [((3, 3, 1, 20, 37), (0, 1, 1)), ((2, 24, 3, 9, 30), (1, 1, 1)), ((2, 32, 1, 28, 28), (0, 2, 2)),
+                                        ((1, 40, 2, 5, 5), (1, 1, 1)), ((4, 32, 1, 7, 130), (0, 1, 1))])
+def test_layout_roundtrip_shapes(dev, shape, pads):
+    """Both dense -> blocked kernels (line-per-block with the LDS transpose; thread-per-float4 for narrow rows): identity
+    round trip, zero halo and zero channel padding, against a torch restatement of the layout."""
+    from disprcnn_amd import engine as E
+    x = synth.hash_uniform(f"rt{shape}", shape).to(dev)
+    n, c, d, h, w = shape
+    b = E.Blocked(n, c, d, h, w, *pads, dev).from_dense(x)
+    assert torch.equal(b.to_dense(), x)
+    cb = (c + 15) // 16
+    ref = torch.zeros(n, cb * 16, d + 2 * pads[0], h + 2 * pads[1], w + 2 * pads[2], device=dev)
+    ref[:, :c, pads[0]:pads[0] + d, pads[1]:pads[1] + h, pads[2]:pads[2] + w] = x
+    ref = ref.view(n, cb, 16, *ref.shape[2:]).permute(0, 1, 3, 4, 5, 2).contiguous()
+    assert torch.equal(b.view6(), ref)
+
+
 # ------------------------------------------------------------------------------------------------ a2-a6 layers
 LAYERS = [  # cin, cout, stride, transposed, dims
     (64, 32, 1, False, (4, 12, 28)), (32, 32, 1, False, (3, 28, 28)), (32, 64, 2, False, (12, 28, 28)),
@@ -168,6 +185,48 @@ def test_conv3d_winograd_kernel_vs_oracle(dev, n, cin, cout, dims, with_res):
         E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = saved
     assert plan.wino, "shape was expected to take the Winograd kernel"
     _close(got, ref)
+
+
+@pytest.mark.parametrize("n,C,cout,D,H,W,lo4,pad", [(3, 32, 32, 12, 28, 28, 0, 1), (2, 32, 32, 6, 28, 28, -6, 1), (5, 16, 48, 8, 10, 30, 3, 2),
+                                                     (1, 32, 32, 24, 56, 56, 0, 1), (2, 32, 32, 4, 6, 2, -1, 1), (19, 32, 32, 12, 28, 28, 0, 1)])
+def test_conv3d_winograd_fused_cost_volume(dev, n, C, cout, D, H, W, lo4, pad):
+    """wino3d_cv_kernel (dres0[0] reading the 2D feature maps, cost volume never materialised; stackhourglass.py:115-130):
+    bit-identical to drc_cost_volume_blocked_fwd + drc_conv3d_k3_wino_fwd, and within the layer tolerance of the oracle's
+    volume convolved directly.  Covers negative / positive mindisp, widths below the disparity range, feature halos > 1,
+    a right side named as a later range of the same tensor, and partial tile groups."""
+    from disprcnn_amd import engine as E
+    fl = synth.hash_uniform(f"CV{n}{C}{H}{W}:l", (n, C, H, W))
+    fr = synth.hash_uniform(f"CV{n}{C}{H}{W}:r", (n, C, H, W))
+    w = synth.hash_uniform(f"CV{C}{cout}:w", (cout, 2 * C, 3, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("CV:s", (cout,), 0.5, 1.5).to(dev)
+    shift = synth.hash_uniform("CV:b", (cout,), -0.5, 0.5).to(dev)
+    mn, mx = 4 * lo4, 4 * (lo4 + D)
+    cost = O.cost_volume(fl, fr, mx, mn)
+    ref = F.relu(F.conv3d(cost, w, None, 1, 1) * scale.cpu().view(1, -1, 1, 1, 1) + shift.cpu().view(1, -1, 1, 1, 1))
+    saved = (E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"])
+    E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = True, 2, 1, True
+    try:
+        xb = E.Blocked(n, 2 * C, D, H, W, 1, 1, 1, dev)
+        y0, y1 = E.Blocked(n, cout, D, H, W, 1, 1, 1, dev), E.Blocked(n, cout, D, H, W, 1, 1, 1, dev)
+        plan = E.plan_conv3d(xb, y0, 1, cout, True)
+    finally:
+        E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = saved
+    assert plan.wino
+    w16 = plan.pack16(w.to(dev))
+    both = E.Blocked(2 * n, C, 1, H, W, 0, pad, pad, dev).from_dense(torch.cat((fl, fr), 0).to(dev))      # left maps, then right maps
+    E.cost_volume_blocked(fl.to(dev), fr.to(dev), xb, lo4, lo4 + D, 0)
+    plan.run(xb, w16, scale, shift, y0, w16=w16)
+    plan.run_costvol(both, (both, n), lo4, w16, scale, shift, y1)
+    torch.cuda.synchronize()
+    a, b = y0.to_dense(), y1.to_dense()
+    assert torch.equal(a, b), f"fused differs from materialised: max {(a - b).abs().max().item():.3e}"
+    _close(b, ref)
+    # separate left / right tensors
+    fL = E.Blocked(n, C, 1, H, W, 0, pad, pad, dev).from_dense(fl.to(dev))
+    fR = E.Blocked(n, C, 1, H, W, 0, pad, pad, dev).from_dense(fr.to(dev))
+    y2 = E.Blocked(n, cout, D, H, W, 1, 1, 1, dev)
+    plan.run_costvol(fL, fR, lo4, w16, scale, shift, y2)
+    assert torch.equal(y2.to_dense(), a)
 
 
 @pytest.mark.parametrize("n,cin,cout,hw,with_res", [(4, 32, 32, (112, 112), True), (3, 64, 64, (56, 56), False), (2, 128, 128, (28, 28), True),
