@@ -123,6 +123,12 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
     }
 
     // ---- flush: D[i = a channel][j = b channel]: lane holds rows 4g..4g+3 of column j
+    if (p.scratch) {                               // partial sums [job][worker][t][lane] for wgrad_reduce_kernel
+        float* dst = p.scratch + (((int64_t)blockIdx.y * workers + blockIdx.x * WG_WAVES + wave) * NT) * 256 + lane * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4*)(dst + t * 256) = acc[t];
+        return;
+    }
     const int ntaps = p.nd * p.nh * p.nw;
     const int cbt = p.cb_b * 16;
 #pragma unroll
@@ -136,8 +142,58 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
     }
 }
 
+// gw[...] += sum over the workers' partials, in worker order.  Block = (job, tap): 64 lanes x 4 worker segments.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, int workers, int NT, int cb_a, int cb_b, int ntaps,
+                                                           float* __restrict__ gw) {
+    const int job = blockIdx.x / NT, t = blockIdx.x - job * NT;
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int per = (workers + 3) >> 2;
+    const int w0 = seg * per, w1 = w0 + per < workers ? w0 + per : workers;
+    const int64_t stride = (int64_t)NT * 256;
+    const float* src = scratch + (((int64_t)job * workers + w0) * NT + t) * 256 + lane * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *(const f32x4*)(src + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];
+        src += 8 * stride;
+    }
+    for (; w < w1; ++w, src += stride) sum += *(const f32x4*)src;
+    __shared__ f32x4 red[4][64];
+    red[seg][lane] = sum;
+    __syncthreads();
+    if (seg) return;
+    sum = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int cbb = job % cb_b, ca = (job / cb_b) % cb_a, di = job / (cb_b * cb_a);
+    const int j = lane & 15, g = lane >> 4;
+    const int cbt = cb_b * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ia = ca * 16 + g * 4 + r, ib = cbb * 16 + j;
+        gw[((int64_t)ia * cbt + ib) * ntaps + di * NT + t] += sum[r];
+    }
+}
+
+}  // namespace
+
+// shared with wgrad_slide.hip: true if the partial-sum path can be used for `waves` waves of NT accumulators each
+bool drc_wgrad_scratch_fits(const drc_wgrad_params& p, long waves, int NT) {
+    return p.scratch && p.scratch_floats >= waves * (long)NT * 256;
+}
+int drc_wgrad_reduce(const drc_wgrad_params& p, int workers, long jobs, int NT, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(jobs * NT)), dim3(256), 0, s, p.scratch, workers, NT, p.cb_a, p.cb_b,
+                       p.nd * p.nh * p.nw, p.gw);
+    return (int)hipGetLastError();
+}
+
+namespace {
+
 template <int NT>
-int launch(const drc_wgrad_params& p, hipStream_t s) {
+int launch(const drc_wgrad_params& p0, hipStream_t s) {
+    drc_wgrad_params p = p0;
     const long groups = (long)p.N * p.OD * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
     const long jobs = (long)p.nd * p.cb_a * p.cb_b;
     // one wave per SIMD across all jobs: every extra wave adds a full set of atomicAdd flushes onto the same few addresses
@@ -152,8 +208,12 @@ int launch(const drc_wgrad_params& p, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid((unsigned)((workers + WG_WAVES - 1) / WG_WAVES), (unsigned)jobs, 1);
+    const bool partial = drc_wgrad_scratch_fits(p, (long)grid.x * WG_WAVES * jobs, NT);
+    if (!partial) p.scratch = nullptr;
     hipLaunchKernelGGL((wgrad_kernel<NT>), grid, dim3(64 * WG_WAVES), lds, s, p);
-    return (int)hipGetLastError();
+    const int st = (int)hipGetLastError();
+    if (st || !partial) return st;
+    return drc_wgrad_reduce(p, (int)grid.x * WG_WAVES, jobs, NT, s);
 }
 
 }  // namespace

@@ -168,6 +168,12 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
     }
 
     // ---- flush: D[i = a channel][j = b channel]: lane holds rows 4g..4g+3 of column j
+    if (p.scratch) {                               // partial sums [job][worker][t][lane] for wgrad.hip's wgrad_reduce_kernel
+        float* dst = p.scratch + (((int64_t)blockIdx.y * workers + blockIdx.x * WS_WAVES + wave) * 27) * 256 + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *(f32x4*)(dst + t * 256) = acc[t];
+        return;
+    }
     const int cbt = p.cb_b * 16;
 #pragma unroll
     for (int t = 0; t < 27; ++t)
@@ -180,9 +186,12 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
 
 }  // namespace
 
+bool drc_wgrad_scratch_fits(const drc_wgrad_params& p, long waves, int NT);                    // wgrad.hip
+int drc_wgrad_reduce(const drc_wgrad_params& p, int workers, long jobs, int NT, hipStream_t s);
+
 // returns 1 if the shape is not handled here (caller uses the generic kernel), 0 on launch, or a hipError_t
 extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* stream) {
-    const drc_wgrad_params& p = *pp;
+    drc_wgrad_params p = *pp;
     if (p.in_mul != 1 || p.nd != 3 || p.nh != 3 || p.nw != 3 || p.sd != 1 || p.sh != 1 || p.sw != 1 || p.OD < 2) return 1;
     // tile: rows as wide as the map up to 32 columns, R*WT <= 64 voxels (16 k-steps)
     const int parts = (p.OW + 31) / 32;
@@ -206,7 +215,10 @@ extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* str
     if (workers > cols) workers = cols;
     if (workers < 1) workers = 1;
     dim3 grid((unsigned)((workers + WS_WAVES - 1) / WS_WAVES), (unsigned)jobs, 1);
+    const bool partial = drc_wgrad_scratch_fits(p, (long)grid.x * WS_WAVES * jobs, 27);
+    if (!partial) p.scratch = nullptr;
     hipLaunchKernelGGL(wgrad_slide_kernel, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT);
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    if (e != hipSuccess || !partial) return e == hipSuccess ? 0 : (int)e;
+    return drc_wgrad_reduce(p, (int)grid.x * WS_WAVES, jobs, 27, (hipStream_t)stream);
 }

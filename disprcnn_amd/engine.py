@@ -812,7 +812,19 @@ def bn_scratch(dev, cb):
     key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, cb)   # ticket offset depends on cb
     buf = _BN_SCRATCH.get(key)
     if buf is None:
-        buf = _BN_SCRATCH[key] = torch.zeros(BN_MAX_CHUNKS * cb * 32 + cb, dtype=torch.float32, device=dev)
+        buf = _BN_SCRATCH[key] = torch.zeros(BN_MAX_CHUNKS * cb * 32 + cb * 32 * 33, dtype=torch.float32, device=dev)   # DRC_BN_SCRATCH_FLOATS
+    return buf
+
+
+_WGRAD_SCRATCH = {}
+
+
+def wgrad_scratch(dev):
+    """Per-(device, stream) workspace of the weight-gradient kernels' partial sums (DRC_WGRAD_SCRATCH_FLOATS, 61 MB)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    buf = _WGRAD_SCRATCH.get(key)
+    if buf is None:
+        buf = _WGRAD_SCRATCH[key] = torch.empty(_lib.WGRAD_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
     return buf
 
 

@@ -41,6 +41,9 @@ class Grads:
         return b
 
 
+WGRAD_PARTIALS = {"enabled": True}     # partial sums + fixed-order reduce instead of the atomicAdd flush (tests flip it)
+
+
 def wgrad(a, b, cls, in_mul, R=None, WT=None):
     """gw[cbA*16][cbB*16][T] for one tap class (see include/disprcnn_hip.h: drc_tapconv_wgrad)."""
     dev = a.device
@@ -73,6 +76,9 @@ def wgrad(a, b, cls, in_mul, R=None, WT=None):
     p.nd, p.nh, p.nw = nd, nh, nw
     p.dd0, p.dh0, p.dw0 = cls["first"]
     p.sd, p.sh, p.sw = cls["step"]
+    if WGRAD_PARTIALS["enabled"]:
+        scratch = E.wgrad_scratch(dev)
+        p.scratch, p.scratch_floats = scratch.data_ptr(), scratch.numel()
     st = _lib.lib().drc_tapconv_wgrad(C.byref(p), E._stream_ptr(dev))
     _lib.check(st, "drc_tapconv_wgrad")
     return gw

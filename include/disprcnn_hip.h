@@ -338,11 +338,11 @@ int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mas
  *                          in ONE pass: per-thread sums around the thread's first value, merged pairwise (Chan) in a fixed
  *                          order lane -> wave -> block -> launch, so the variance is cancellation-free and the statistics (and
  *                          with them every ReLU mask downstream) are bit-reproducible run to run.  `scratch`:
- *                          DRC_BN_SCRATCH_FLOATS(CB) floats whose last CB words (tickets) are zero on entry; they are zero
- *                          again on exit.  One scratch per stream.
+ *                          DRC_BN_SCRATCH_FLOATS(CB) floats whose last CB*32*33 words (arrival counters, one per 128-byte
+ *                          line) are zero on entry; they are zero again on exit.  One scratch per stream.
  *   drc_bn_apply_blocked : y = act((x - mean) * invstd * gamma + beta (+ res)), interior only */
 #define DRC_BN_MAX_CHUNKS 512
-#define DRC_BN_SCRATCH_FLOATS(CB) ((size_t)DRC_BN_MAX_CHUNKS * (CB) * 32 + (CB))
+#define DRC_BN_SCRATCH_FLOATS(CB) ((size_t)DRC_BN_MAX_CHUNKS * (CB) * 32 + (size_t)(CB) * 32 * 33)
 int drc_bn_stats_blocked(const float* x, const int* geom8, float* stats, float* scratch, void* stream);
 /* invstd[c] = rsqrt(stats[1][c]/count + eps) for all C16 (padded) channels, and, if running_mean != NULL, the nn.BatchNorm
  * running-statistics update of the first C channels (momentum, unbiased batch variance); *num_batches_tracked += 1 if non-NULL */
@@ -376,8 +376,12 @@ int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const 
  *   gw[ca][cb][t] += sum_{n,o} a[n, ca, in_mul*o + tap_t] * b[n, cb, o],   t = (td*nh + th)*nw + tw
  * a: blocked tensor the taps slide over (a_* strides in floats, tap offsets dd0/dh0/dw0 + k*sd/sh/sw in padded coordinates);
  * b: blocked tensor read at the plain positions o (b_off0 = float offset of logical voxel (0,0,0));
- * gw: dense fp32 [cb_a*16][cb_b*16][nd*nh*nw], zero-filled by the caller (atomicAdd accumulation).
- * Conv: a = layer input, b = grad of the conv output.  ConvTranspose k3 s2: a = grad of the output (in_mul = 2), b = input. */
+ * gw: dense fp32 [cb_a*16][cb_b*16][nd*nh*nw]; the launch ADDS into it (zero-fill it for a plain gradient).
+ * Conv: a = layer input, b = grad of the conv output.  ConvTranspose k3 s2: a = grad of the output (in_mul = 2), b = input.
+ * scratch (optional): DRC_WGRAD_SCRATCH_FLOATS floats of per-stream workspace.  With it every wave stores its partial sums
+ * with plain coalesced stores and a second kernel adds them in wave order (bit-reproducible run to run); without it (NULL or
+ * scratch_floats too small) the waves flush with atomicAdd -- measured 5.1 ms of the 27.9 ms 64-ROI Config-A train step. */
+#define DRC_WGRAD_SCRATCH_FLOATS ((size_t)(1024 + 3 * 64) * 49 * 256)
 typedef struct drc_wgrad_params {
     const float* a;
     const float* b;
@@ -388,6 +392,9 @@ typedef struct drc_wgrad_params {
     int32_t in_mul, cb_a, cb_b;
     int32_t nd, nh, nw, dd0, dh0, dw0, sd, sh, sw;
     int32_t R, WT, lds_bytes_per_wave;   /* >= ((rows_in*seg_vox) + R*WT) * 64 */
+    int32_t reserved;
+    float* scratch;
+    int64_t scratch_floats;
 } drc_wgrad_params;
 int drc_tapconv_wgrad(const drc_wgrad_params* p, void* stream);
 

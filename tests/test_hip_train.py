@@ -201,6 +201,35 @@ def test_full_psmnet_backward_vs_reference_gradients(dev):
     assert errs[len(errs) // 2] <= 2e-2, errs[len(errs) // 2]
 
 
+@pytest.mark.parametrize("n,cin,cout,dims,stride", [(5, 32, 32, (6, 28, 28), 1), (3, 32, 64, (12, 28, 28), 2), (2, 64, 64, (3, 7, 7), 1),
+                                                    (4, 16, 48, (4, 9, 30), 1), (2, 32, 32, (1, 40, 56), 1)])
+def test_wgrad_partial_sums_vs_atomic_flush_and_oracle(dev, n, cin, cout, dims, stride):
+    """Weight gradient with the waves' partial sums reduced in wave order (DRC_WGRAD_SCRATCH_FLOATS workspace; wgrad_slide and
+    wgrad_kernel<9>) against F.conv3d's autograd (fp64), against the atomicAdd flush, and bit-identical across two runs."""
+    from disprcnn_amd import engine as E
+    from disprcnn_amd.modeling.psmnet import train as T
+    od = tuple(-(-d // stride) for d in dims)
+    x = synth.hash_uniform(f"wg{n}{cin}{dims}:x", (n, cin) + dims)
+    dy = synth.hash_uniform(f"wg{n}{cout}{dims}:dy", (n, cout) + od, -1.0, 1.0)
+    w = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), w, None, stride, 1).backward(dy.double())
+    ref = w.grad.permute(1, 0, 2, 3, 4).reshape(cin, cout, 27)                      # [ci][co][t]
+    xb = E.Blocked(n, cin, *dims, 1, 1, 1, dev).from_dense(x.to(dev))
+    db = E.Blocked(n, cout, *od, 1, 1, 1, dev).from_dense(dy.to(dev))
+    cls = dict(n=(3, 3, 3), first=(0, 0, 0), step=(1, 1, 1))
+    outs = []
+    for partial in (True, True, False):
+        T.WGRAD_PARTIALS["enabled"] = partial
+        try:
+            outs.append(T.wgrad(xb, db, cls, stride)[:cin, :cout].cpu())
+        finally:
+            T.WGRAD_PARTIALS["enabled"] = True
+    assert torch.equal(outs[0], outs[1]), "partial-sum reduction is not run-to-run reproducible"
+    tol = 2e-5 * ref.abs().max().item() + 1e-5
+    for got in (outs[0], outs[2]):
+        assert (got.double() - ref).abs().max().item() <= 5 * tol
+
+
 def test_spp_adjoints(dev):
     """drc_bilinear_up_blocked_bwd / drc_avgpool2d_blocked_bwd are the exact adjoints of the forward SPP kernels
     (reference: autograd of F.interpolate(bilinear, align_corners=True) and AvgPool2d, submodule.py:76-96,128-137):

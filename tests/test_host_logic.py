@@ -27,16 +27,17 @@ def test_params_struct_matches_header_size():
     """sizeof(drc_tapconv_params) computed by gcc must equal the ctypes mirror."""
     import subprocess, tempfile
     from disprcnn_amd import _lib
-    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(int32_t), sizeof(drc_costvol_src));return 0;}'
+    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(int32_t), sizeof(drc_costvol_src), sizeof(drc_wgrad_params));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        a, b, t, cvs = map(int, subprocess.check_output([exe]).split())
+        a, b, t, cvs, wg = map(int, subprocess.check_output([exe]).split())
     assert a == ctypes.sizeof(_lib.DrcTapconvParams)
     assert b == ctypes.sizeof(_lib.DrcTapClass) and t == 4
     assert cvs == ctypes.sizeof(_lib.DrcCostvolSrc)
+    assert wg == ctypes.sizeof(_lib.DrcWgradParams)
 
 
 def test_state_dict_layout():

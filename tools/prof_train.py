@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from disprcnn_amd import _lib
+if os.environ.get("DRC_LIB"):          # development: a variant library from tools/build_variant2.sh
+    _lib.LIB_PATH = os.environ["DRC_LIB"]
 from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
 from disprcnn_amd.utils import synth
 from disprcnn_amd.utils.loss_utils import PSMLoss
