@@ -15,28 +15,31 @@
 
 namespace drc_det {
 
-// Called by all threads of the block after its partials were stored.  True (block-uniformly) in the one block per channel block
-// that arrived last; that block then sees every other block's partials with plain loads (agent-scope release/acquire fences).
+// Called by all threads of the block after its partials were stored BY WAVE 0 (threads < 64).  True (block-uniformly) in the one
+// block per channel block that arrived last; that block then sees every other block's partials with plain loads.
+// Only wave 0 executes the agent-scope release: the fence is an L2 write-back request per WAVE, and with every wave of every
+// block issuing one (4,096 per full-resolution launch) the requests queued at the eight L2s were most of the kernel's time.
 __device__ __forceinline__ bool arrive_last(int cb, int CB, float* scratch) {
     __shared__ unsigned s_last_arrival;
     unsigned* t1 = (unsigned*)(scratch + (size_t)DRC_BN_MAX_CHUNKS * CB * 32);
     unsigned* t2 = t1 + (size_t)CB * 32 * 32;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned grp = blockIdx.x >> 4, ngrp = (gridDim.x + 15u) >> 4;
-        const unsigned rest = gridDim.x - grp * 16u;
-        const unsigned in_grp = rest < 16u ? rest : 16u;
-        unsigned last = 0u;
-        if (atomicAdd(t1 + ((size_t)cb * 32 + grp) * 32, 1u) == in_grp - 1u) {
-            __threadfence();
-            last = atomicAdd(t2 + (size_t)cb * 32, 1u) == ngrp - 1u ? 1u : 0u;
+    if (threadIdx.x < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0) {
+            const unsigned grp = blockIdx.x >> 4, ngrp = (gridDim.x + 15u) >> 4;
+            const unsigned rest = gridDim.x - grp * 16u;
+            const unsigned in_grp = rest < 16u ? rest : 16u;
+            unsigned last = 0u;
+            if (atomicAdd(t1 + ((size_t)cb * 32 + grp) * 32, 1u) == in_grp - 1u) {
+                __threadfence();
+                last = atomicAdd(t2 + (size_t)cb * 32, 1u) == ngrp - 1u ? 1u : 0u;
+            }
+            s_last_arrival = last;
         }
-        s_last_arrival = last;
     }
     __syncthreads();
     if (!s_last_arrival) return false;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return true;
 }
 // the last block re-arms the counters of its channel block (any thread count >= 32)
