@@ -337,6 +337,24 @@ def train_step_extra(dev, model_a, world):
         tr[tag] = {"ms_per_step": round(tt * 1e3, 2), "roi_pairs_per_s_per_gpu": round(nroi / tt, 1),
                    "regressor_tflops_fwd_bwd": round(3 * fl3 / tt / 1e12, 2),
                    "grad_allreduce_ms": round(ar, 3) if world > 1 else 0.0}
+        if world == 1:
+            # the same step replayed from a HIP graph (utils/graph.py): the eager step is bounded by ~2,800 host-side launches
+            from disprcnn_amd.utils.graph import GraphedStep
+
+            def graph_step():
+                opt.zero_grad(set_to_none=True)
+                loss = crit(fwd(), {"disparity": tgt, "mask": msk})
+                loss.backward()
+                opt.step()
+                return loss
+            try:
+                gs = GraphedStep(graph_step, warmup=2)
+                tg = _time(gs, 2, 5)
+                tr[tag]["hip_graph_ms_per_step"] = round(tg * 1e3, 2)
+                tr[tag]["hip_graph_roi_pairs_per_s_per_gpu"] = round(nroi / tg, 1)
+                del gs
+            except Exception as e:                                   # noqa: BLE001 -- report, never hide the eager number
+                tr[tag]["hip_graph_error"] = repr(e)[:200]
         mdl.eval()
     tr["workload"] = ("forward (batch-stat BN) + PSMLoss + backward + gradient sync (one flat fp32 all-reduce of 5.2 M parameters, "
                       f"world {world}) + SGD step; per-GPU batch; regressor FLOPs counted as 3x forward")

@@ -54,7 +54,7 @@ class DrcWgradParams(C.Structure):
                 ("in_mul", C.c_int32), ("cb_a", C.c_int32), ("cb_b", C.c_int32),
                 ("nd", C.c_int32), ("nh", C.c_int32), ("nw", C.c_int32), ("dd0", C.c_int32), ("dh0", C.c_int32), ("dw0", C.c_int32),
                 ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
-                ("R", C.c_int32), ("WT", C.c_int32), ("lds_bytes_per_wave", C.c_int32), ("reserved", C.c_int32),
+                ("R", C.c_int32), ("WT", C.c_int32), ("lds_bytes_per_wave", C.c_int32), ("overwrite", C.c_int32),
                 ("scratch", C.c_void_p), ("scratch_floats", C.c_int64)]
 
 

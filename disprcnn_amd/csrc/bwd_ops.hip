@@ -297,6 +297,53 @@ __global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const float* 
     }
 }
 
+// The same adjoint as a gather: one block per coarse cell (n, cb, cy, cx) sums the fine pixels whose bilinear support contains
+// the cell -- the SPP maps are tiny (1x1 .. 7x7 coarse cells under 56x56 fine pixels), so the scatter form piles thousands of
+// atomicAdds onto each address (958 us per call in the Config-B train step).  64 pixel slots x 4 channel quads per block; fixed
+// summation order (bit-reproducible).  gx[cell] += sum.
+__global__ __launch_bounds__(256) void bilinear_up_bwd_gather_kernel(const float* __restrict__ gy, BlkGeom gg, float* __restrict__ gx, BlkGeom gxg) {
+    const int IH = gxg.H, IW = gxg.W, OH = gg.H, OW = gg.W;
+    int b = blockIdx.x;
+    const int cx = b % IW; b /= IW;
+    const int cy = b % IH; b /= IH;
+    const int cb = b % gg.CB;
+    const int n = b / gg.CB;
+    const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+    const float sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    // conservative bounds of the fine rows / columns with y0 == cy or y1 == cy (fy in (cy-1, cy+1)); the exact test is in the loop
+    int oy_lo = 0, oy_hi = OH - 1, ox_lo = 0, ox_hi = OW - 1;
+    if (sy > 0.f) { oy_lo = max(0, (int)floorf((cy - 1) / sy) - 1); oy_hi = min(OH - 1, (int)ceilf((cy + 1) / sy) + 1); }
+    if (sx > 0.f) { ox_lo = max(0, (int)floorf((cx - 1) / sx) - 1); ox_hi = min(OW - 1, (int)ceilf((cx + 1) / sx) + 1); }
+    const int ncol = ox_hi - ox_lo + 1, total = (oy_hi - oy_lo + 1) * ncol;
+    const int q = threadIdx.x & 3, slot = threadIdx.x >> 2;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = slot; i < total; i += 64) {
+        const int r = i / ncol;
+        const int oy = oy_lo + r, ox = ox_lo + (i - r * ncol);
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < IH - 1), x1 = x0 + (x0 < IW - 1);
+        const float ty = fy - y0, tx = fx - x0;
+        const float wy = (y0 == cy ? 1.f - ty : 0.f) + (y1 == cy ? ty : 0.f);
+        const float wx = (x0 == cx ? 1.f - tx : 0.f) + (x1 == cx ? tx : 0.f);
+        const float w = wy * wx;
+        if (w != 0.f) acc += w * *(const f32x4*)(gy + blk_off(gg, n, cb, 0, oy, ox) + q * 4);
+    }
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m); acc.y += __shfl_xor(acc.y, m); acc.z += __shfl_xor(acc.z, m); acc.w += __shfl_xor(acc.w, m);
+    }
+    __shared__ f32x4 red[4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 4) red[wv][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const f32x4 v = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+        float* dst = gx + blk_off(gxg, n, cb, 0, cy, cx) + q * 4;
+        *(f32x4*)dst = *(const f32x4*)dst + v;
+    }
+}
+
 // adjoint of AvgPool2d(k,k): gx[y,x] += gy[y/k, x/k] / k^2 inside the pooled region
 __global__ __launch_bounds__(kThreads) void avgpool2d_bwd_kernel(const float* __restrict__ gy, BlkGeom gg, float* __restrict__ gx, BlkGeom gxg, int k) {
     const long total = (long)gxg.N * gxg.CB * gxg.H * gxg.W * 4;
@@ -397,9 +444,13 @@ int drc_bilinear_up_blocked_bwd(const float* grad_y, const int* geom_y, float* g
     if (!geom_ok(geom_y) || !geom_ok(geom_x) || geom_y[0] != geom_x[0] || geom_y[1] != geom_x[1]) return -2;
     if (geom_y[0] == 0) return 0;
     if (!grad_y || !grad_x) return -1;                  // grad_x must be zero-filled (or hold earlier contributions)
-    const BlkGeom g = to_geom(geom_y);
-    hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3(grid_for((long)g.N * g.CB * g.H * g.W * 4)), dim3(kThreads), 0, (hipStream_t)stream, grad_y, g,
-                       grad_x, to_geom(geom_x));
+    const BlkGeom g = to_geom(geom_y), gxg = to_geom(geom_x);
+    const long cells = (long)gxg.N * gxg.CB * gxg.H * gxg.W;
+    if ((long)g.H * g.W >= 4L * gxg.H * gxg.W && cells < (1L << 31))          // upsampling: gather per coarse cell, no atomics
+        hipLaunchKernelGGL(bilinear_up_bwd_gather_kernel, dim3((unsigned)cells), dim3(256), 0, (hipStream_t)stream, grad_y, g, grad_x, gxg);
+    else
+        hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3(grid_for((long)g.N * g.CB * g.H * g.W * 4)), dim3(kThreads), 0, (hipStream_t)stream, grad_y, g,
+                           grad_x, gxg);
     return (int)hipGetLastError();
 }
 

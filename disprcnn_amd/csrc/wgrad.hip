@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
 
 // gw[...] += sum over the workers' partials, in worker order.  Block = (job, tap): 64 lanes x 4 worker segments.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ scratch, int workers, int NT, int cb_a, int cb_b, int ntaps,
-                                                           float* __restrict__ gw) {
+                                                           int overwrite, float* __restrict__ gw) {
     const int job = blockIdx.x / NT, t = blockIdx.x - job * NT;
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int per = (workers + 3) >> 2;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ia = ca * 16 + g * 4 + r, ib = cbb * 16 + j;
-        gw[((int64_t)ia * cbt + ib) * ntaps + di * NT + t] += sum[r];
+        float* dst = gw + ((int64_t)ia * cbt + ib) * ntaps + di * NT + t;
+        *dst = overwrite ? sum[r] : *dst + sum[r];
     }
 }
 
@@ -183,9 +184,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 bool drc_wgrad_scratch_fits(const drc_wgrad_params& p, long waves, int NT) {
     return p.scratch && p.scratch_floats >= waves * (long)NT * 256;
 }
+// the atomicAdd flush adds: an `overwrite` launch that cannot use the partial sums clears gw first
+int drc_wgrad_clear_for_atomics(const drc_wgrad_params& p, hipStream_t s) {
+    if (!p.overwrite) return 0;
+    return (int)hipMemsetAsync(p.gw, 0, (size_t)p.cb_a * 16 * p.cb_b * 16 * p.nd * p.nh * p.nw * sizeof(float), s);
+}
 int drc_wgrad_reduce(const drc_wgrad_params& p, int workers, long jobs, int NT, hipStream_t s) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(jobs * NT)), dim3(256), 0, s, p.scratch, workers, NT, p.cb_a, p.cb_b,
-                       p.nd * p.nh * p.nw, p.gw);
+                       p.nd * p.nh * p.nw, p.overwrite, p.gw);
     return (int)hipGetLastError();
 }
 
@@ -209,7 +215,10 @@ int launch(const drc_wgrad_params& p0, hipStream_t s) {
     }
     dim3 grid((unsigned)((workers + WG_WAVES - 1) / WG_WAVES), (unsigned)jobs, 1);
     const bool partial = drc_wgrad_scratch_fits(p, (long)grid.x * WG_WAVES * jobs, NT);
-    if (!partial) p.scratch = nullptr;
+    if (!partial) {
+        p.scratch = nullptr;
+        if (const int st = drc_wgrad_clear_for_atomics(p, s)) return st;
+    }
     hipLaunchKernelGGL((wgrad_kernel<NT>), grid, dim3(64 * WG_WAVES), lds, s, p);
     const int st = (int)hipGetLastError();
     if (st || !partial) return st;

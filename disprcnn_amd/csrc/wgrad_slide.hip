@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
 
 bool drc_wgrad_scratch_fits(const drc_wgrad_params& p, long waves, int NT);                    // wgrad.hip
 int drc_wgrad_reduce(const drc_wgrad_params& p, int workers, long jobs, int NT, hipStream_t s);
+int drc_wgrad_clear_for_atomics(const drc_wgrad_params& p, hipStream_t s);
 
 // returns 1 if the shape is not handled here (caller uses the generic kernel), 0 on launch, or a hipError_t
 extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* stream) {
@@ -216,7 +217,10 @@ extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* str
     if (workers < 1) workers = 1;
     dim3 grid((unsigned)((workers + WS_WAVES - 1) / WS_WAVES), (unsigned)jobs, 1);
     const bool partial = drc_wgrad_scratch_fits(p, (long)grid.x * WS_WAVES * jobs, 27);
-    if (!partial) p.scratch = nullptr;
+    if (!partial) {
+        p.scratch = nullptr;
+        if (const int st = drc_wgrad_clear_for_atomics(p, (hipStream_t)stream)) return st;
+    }
     hipLaunchKernelGGL(wgrad_slide_kernel, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess || !partial) return e == hipSuccess ? 0 : (int)e;

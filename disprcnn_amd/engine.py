@@ -274,13 +274,16 @@ def _deconv_tap_order():
 
 
 _DECONV_TAP_ORDER = _deconv_tap_order()
+_DECONV_TAP_ORDER_DEV = {}     # per device: a host->device copy is not allowed while a HIP graph is being captured
 
 
 def pack_weight_deconv_direct(w, transposed=True, flip=False):
     """ConvTranspose3d weight [Cin,Cout,3,3,3] (or, for the data gradient of a stride-2 Conv3d, its weight read as one) ->
     [cb_in][27][cout_pad][16]: the t16 packing re-ordered channel-block-major with the taps in deconvdirect.hip's use order."""
     t16 = pack_layouts(w, transposed, flip, want_tap=False)[1]               # [27][cb][cout_pad][16]
-    order = torch.tensor(_DECONV_TAP_ORDER, device=t16.device)
+    order = _DECONV_TAP_ORDER_DEV.get(t16.device)
+    if order is None:
+        order = _DECONV_TAP_ORDER_DEV[t16.device] = torch.tensor(_DECONV_TAP_ORDER, device=t16.device)
     return t16.index_select(0, order).permute(1, 0, 2, 3).contiguous()
 
 

@@ -49,8 +49,9 @@ def wgrad(a, b, cls, in_mul, R=None, WT=None):
     dev = a.device
     nd, nh, nw = cls["n"]
     T = nd * nh * nw
-    gw = torch.zeros(a.cb * 16, b.cb * 16, T, dtype=torch.float32, device=dev)
+    gw = torch.empty(a.cb * 16, b.cb * 16, T, dtype=torch.float32, device=dev)
     p = DrcWgradParams()
+    p.overwrite = 1                       # no zero-fill launch: the kernels store (or clear gw themselves on the atomicAdd path)
     span_h, span_w = (nh - 1) * cls["step"][1], (nw - 1) * cls["step"][2]
     # tile: R rows x WT cols of b with (rows_in*seg + R*WT)*64 B <= 38 KiB per wave
     best = None
@@ -138,7 +139,10 @@ class RegressorBackward:
         else:                           # stride 1: in/out swap + flipped taps
             wp, w16 = E.pack_layouts(wt, True, True, want_t16=need16)
         cp = ent["plan"].p.cout_pad
-        return ent["plan"], wp, torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev), w16
+        unit = self.ws.setdefault("unit_affine", {})
+        if cp not in unit:
+            unit[cp] = (torch.ones(cp, device=self.dev), torch.zeros(cp, device=self.dev))
+        return ent["plan"], wp, unit[cp][0], unit[cp][1], w16
 
     _x_of = {}
 
@@ -174,8 +178,8 @@ class RegressorBackward:
                                       E._geom8(draw), E._ptr(dres.storage) if dres is not None else None,
                                       E._geom8(dres) if dres is not None else None, acc, sp)
             _lib.check(st, "drc_bn_bwd_apply")
-            self._padd(c.bn.weight, sums[1, : c.cout].clone())
-            self._padd(c.bn.bias, sums[0, : c.cout].clone())
+            self._padd(c.bn.weight, sums[1, : c.cout])           # `sums` is this site's own tensor: views are safe to keep
+            self._padd(c.bn.bias, sums[0, : c.cout])
         else:                       # plain conv (no BN, no activation, no residual): the output gradient is the conv gradient
             assert not relu and res is None
             draw = dy

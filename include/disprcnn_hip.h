@@ -392,7 +392,7 @@ typedef struct drc_wgrad_params {
     int32_t in_mul, cb_a, cb_b;
     int32_t nd, nh, nw, dd0, dh0, dw0, sd, sh, sw;
     int32_t R, WT, lds_bytes_per_wave;   /* >= ((rows_in*seg_vox) + R*WT) * 64 */
-    int32_t reserved;
+    int32_t overwrite;          /* 1: gw holds garbage -- the launch stores the sums instead of adding them */
     float* scratch;
     int64_t scratch_floats;
 } drc_wgrad_params;

@@ -258,6 +258,12 @@ def test_spp_adjoints(dev):
         lhs = (y.double() * gd[:, 32:64].double()).sum().item()
         rhs = (xd.double() * gx.to_dense().double()).sum().item()
         assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (k, lhs, rhs)
+        xr = xd.squeeze(2).cpu().double().requires_grad_()
+        F.interpolate(xr, (H4, W4), mode="bilinear", align_corners=True).backward(gd[:, 32:64].squeeze(2).cpu().double())
+        assert (gx.to_dense().squeeze(2).cpu().double() - xr.grad).abs().max().item() <= 2e-5 * xr.grad.abs().max().item()
+        # accumulates into grad_x: a second call doubles it
+        _lib.check(lib.drc_bilinear_up_blocked_bwd(E._ptr(gsl.storage), E._geom8(gsl), E._ptr(gx.storage), E._geom8(gx), sp), "up_bwd")
+        assert (gx.to_dense().squeeze(2).cpu().double() - 2 * xr.grad).abs().max().item() <= 4e-5 * xr.grad.abs().max().item()
         # average pool of a 128-channel slice (blocks 1..8 of a 10-block tensor), adjoint accumulates into the slice
         src = E.Blocked(n, 160, 1, H4, W4, 0, 2, 2, dev)
         sdn = synth.hash_uniform(f"spp{k}:s", (n, 160, 1, H4, W4)).to(dev)

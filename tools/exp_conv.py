@@ -63,6 +63,11 @@ if __name__ == "__main__":
         E.DIRECT["down"] = os.environ["DIRECT_DOWN"] != "0"
     if os.environ.get("SLIDE_MIN_OD"):
         E.SLIDE["min_od"] = int(os.environ["SLIDE_MIN_OD"]); E.SLIDE["min_share"] = 1
+    if os.environ.get("SLIDE_MIN_UNITS"):
+        E.SLIDE["min_units"] = int(os.environ["SLIDE_MIN_UNITS"])
+    if os.environ.get("QUARTER"):
+        run(N, 64, 64, (3, 7, 7))
+        sys.exit(0)
     if os.environ.get("SLIDE_CT"):
         E.SLIDE["ct"] = int(os.environ["SLIDE_CT"])
     run(N, 32, 32, (12, 28, 28))
