@@ -20,5 +20,6 @@ run() {   # name, description, command...
 run configB "WHAT=psm python tools/prof_pair.py  (Config B: full PSMNet on 16 ROI crops 224x224, D=96; 2 warm-up + 5 timed passes)" env WHAT=psm python tools/prof_pair.py
 run pair_backbone "WHAT=bb python tools/prof_pair.py  (R-50-FPN trunk on one stereo pair 2x3x375x1242 = 250.3 GFLOP; 2 warm-up + 5 timed passes)" env WHAT=bb python tools/prof_pair.py
 run train "N=64 python tools/prof_train.py  (Config A train step from the feature boundary, 64 ROI pairs: fwd + PSMLoss + bwd; 2 + 3 steps, then 3 forward-only passes)" env N=64 python tools/prof_train.py
+run trainB "N=8 CFG_B=1 python tools/prof_train.py  (Config B train step, full PSMNet on 8 crops 224x224, D=96: fwd + PSMLoss + bwd; 2 + 3 steps)" env N=8 CFG_B=1 python tools/prof_train.py
 run stress16 "WHAT=psm16 python tools/prof_pair.py  (configs[3]: 64 ROI crops 224x224, D=96, fp16-storage regressor)" env WHAT=psm16 python tools/prof_pair.py
 ls profiles/ | grep "$TAG"
