@@ -123,3 +123,41 @@ def synth_backbone_state(template):
         else:                                   # fpn conv bias
             out[k] = hash_uniform("bb:" + k, shape, -0.05, 0.05)
     return out
+
+
+# per-key multipliers on the fan-in bound: spread the objectness / class scores and keep the box deltas moderate, so that the
+# synthetic heads produce proposals and detections with real NMS chains (used by tests/golden/make_golden_det.py and the tests)
+DET_GAIN = {"head.cls_logits.weight": 0.5, "head.bbox_pred.weight": 0.6, "box.predictor.cls_score.weight": 3.0,
+            "box.predictor.bbox_pred.weight": 2.0, "mask.predictor.mask_fcn_logits.weight": 4.0}
+
+
+def synth_det_state(template, gain=None):
+    """Closed-form weights for the 2D-stage heads (Stereo RPN, stereo box head, mask head): uniform with a fan-in bound so that
+    activations stay O(1) through the heads; buffers (cell anchors) are kept.  `gain` overrides the per-key multiplier."""
+    gain = gain or {}
+    out = {}
+    for k, v in template.items():
+        shp = tuple(v.shape)
+        if "cell_anchors" in k:
+            out[k] = v.clone()
+        elif k.endswith("bias"):
+            out[k] = hash_uniform("det:" + k, shp, -0.1, 0.1)
+        else:
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+            if k.endswith("conv5_mask.weight"):                # ConvTranspose2d [Cin, Cout, 2, 2]: one tap per output pixel
+                fan_in = shp[0]
+            a = gain.get(k, 1.0) * math.sqrt(3.0 / fan_in)
+            out[k] = hash_uniform("det:" + k, shp, -a, a)
+    return out
+
+
+def synth_pyramid(n, h, w, c=256, tag="pyr"):
+    """Left/right FPN-like feature pyramids for an h x w image: 5 levels at strides 4..64 (ceil division like the backbone)."""
+    left, right = [], []
+    hh, ww = -(-h // 4), -(-w // 4)
+    for lvl in range(5):
+        a = math.sqrt(3.0)
+        left.append(hash_uniform(f"{tag}:L{lvl}", (n, c, hh, ww), -a, a))
+        right.append(torch.roll(left[-1], shifts=-max(1, 8 >> lvl), dims=3) * 0.8 + 0.2 * hash_uniform(f"{tag}:R{lvl}", (n, c, hh, ww), -a, a))
+        hh, ww = -(-hh // 2), -(-ww // 2)
+    return left, right
