@@ -1,0 +1,57 @@
+"""Pooler -- drop-in for ``disprcnn.modeling.poolers.Pooler`` (poolers.py:10-149): multi-level ROIAlign over the FPN.
+
+Fork behaviour kept: the level of a box is round(4 + ln(sqrt(area) / 224)) (natural log, no epsilon), clamped to the configured
+levels; the extra top level (P6) is never pooled from; the ROIAlign scale of a level is feature height / image height, not the
+configured constant.  ROIAlign itself is the bit-exact HIP kernel behind layers.ROIAlign (drc_roi_align_fwd)."""
+import math
+
+import torch
+from torch import nn
+
+from ..layers.roi_align import ROIAlign
+
+
+class LevelMapper:
+    def __init__(self, k_min, k_max, canonical_scale=224, canonical_level=4, eps=1e-6):
+        self.k_min, self.k_max, self.s0, self.lvl0, self.eps = k_min, k_max, canonical_scale, canonical_level, eps
+
+    def __call__(self, boxlists):
+        s = torch.sqrt(torch.cat([b.area() for b in boxlists]))
+        lv = torch.round(self.lvl0 + torch.log(s / self.s0))
+        return torch.clamp(lv, min=self.k_min, max=self.k_max).to(torch.int64) - int(self.k_min)
+
+
+class Pooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio):
+        super().__init__()
+        self.poolers = nn.ModuleList([ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio) for s in scales])
+        self.output_size = tuple(output_size)
+        self.map_levels = LevelMapper(-math.log2(scales[0]), -math.log2(scales[-1]))
+
+    @staticmethod
+    def convert_to_roi_format(boxes):
+        dev = boxes[0].bbox.device
+        ids = torch.cat([torch.full((len(b), 1), float(i), dtype=torch.float32, device=dev) for i, b in enumerate(boxes)], 0)
+        return torch.cat([ids, torch.cat([b.bbox for b in boxes], 0)], 1)
+
+    def forward(self, x, boxes):
+        """x: per-level [N,C,H,W] maps (a trailing extra level is ignored); boxes: list[BoxList] -> [R,C,oh,ow] in box order."""
+        rois = self.convert_to_roi_format(boxes)
+        c = x[0].shape[1]
+        out = torch.zeros(len(rois), c, *self.output_size, dtype=torch.float32, device=x[0].device)
+        if len(self.poolers) == 1:
+            return self.poolers[0](x[0], rois)
+        if len(rois) == 0:
+            return out
+        levels = self.map_levels(boxes)
+        for level, (feat, pooler) in enumerate(zip(x[: len(self.poolers)], self.poolers)):
+            idx = torch.nonzero(levels == level).reshape(-1)
+            if idx.numel() == 0:
+                continue
+            out.index_copy_(0, idx, pooler(feat, rois.index_select(0, idx), feat.shape[2] / boxes[0].height))
+        return out
+
+
+def make_pooler(cfg, head_name):
+    h = getattr(cfg.MODEL, head_name)
+    return Pooler((h.POOLER_RESOLUTION, h.POOLER_RESOLUTION), h.POOLER_SCALES, h.POOLER_SAMPLING_RATIO)

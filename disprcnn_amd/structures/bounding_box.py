@@ -1,6 +1,6 @@
-"""Minimal BoxList: the three behaviours the disparity stage touches (bbox / get_field / add_field,
-plus indexing and len).  Reference: disprcnn/structures/bounding_box.py:10-455 (the rest of that class is 2D-detection
-plumbing and out of scope)."""
+"""BoxList: boxes of one image + per-box fields + image-level maps.  Reference: disprcnn/structures/bounding_box.py:10-455 --
+bbox / get_field / add_field / indexing / len (the disparity stage), area, clip_to_image, copy_with_fields and the xyxy<->xywh
+view (the 2D stage's heads); transpose / crop / resize of annotations belong to the data pipeline and are not built."""
 import torch
 
 
@@ -59,6 +59,35 @@ class BoxList:
 
     def __len__(self):
         return self.bbox.shape[0]
+
+    def area(self):
+        """(x2 - x1 + 1) * (y2 - y1 + 1): the legacy +1 pixel convention (reference :373-382)."""
+        b = self.bbox
+        return (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+
+    def xywh(self):
+        """[R,4] (x, y, w, h) with w = x2 - x1 + 1 (reference convert('xywh'), :96-128)."""
+        b = self.bbox
+        return torch.stack((b[:, 0], b[:, 1], b[:, 2] - b[:, 0] + 1, b[:, 3] - b[:, 1] + 1), dim=1)
+
+    def clip_to_image(self, remove_empty=True):
+        """In place, like the reference (:317-330)."""
+        w, h = self.size
+        self.bbox[:, 0].clamp_(min=0, max=w - 1); self.bbox[:, 1].clamp_(min=0, max=h - 1)
+        self.bbox[:, 2].clamp_(min=0, max=w - 1); self.bbox[:, 3].clamp_(min=0, max=h - 1)
+        if remove_empty:
+            b = self.bbox
+            return self[(b[:, 3] > b[:, 1]) & (b[:, 2] > b[:, 0])]
+        return self
+
+    def copy_with_fields(self, fields, skip_missing=False):
+        out = BoxList(self.bbox, self.size, self.mode)
+        for f in ([fields] if isinstance(fields, str) else fields):
+            if self.has_field(f):
+                out.add_field(f, self.get_field(f))
+            elif not skip_missing:
+                raise KeyError(f"Field '{f}' not found in {self}")
+        return out
 
     def __repr__(self):
         return f"BoxList(num_boxes={len(self)}, image_width={self.size[0]}, image_height={self.size[1]}, mode={self.mode})"

@@ -290,6 +290,22 @@ int drc_cost_volume16_blocked_fwd(const float* left, const float* right, void* c
  * n <= 32768.  The greedy walk runs on the device (the reference copies the mask to the host). */
 int drc_nms_sorted_fwd(const float* boxes_sorted, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream);
 
+/* f4. Box arithmetic of the 2D detection stage (det_ops.hip).
+ * drc_box_decode_fwd -- BoxCoder.decode (reference modeling/box_coder.py:161-244): codes [rows][groups][per_group], per_group = 4
+ *   (dx,dy,dw,dh) or 6 (+ dx', dw' of the right view, decoded against the SAME reference box: decode_..._fromboxes4), boxes
+ *   [rows][4] xyxy with the legacy +1 widths; weights4 = (wx, wy, ww, wh); dw/dh clamped to xform_clip (log(1000/16)); with
+ *   img_w > 0 the result is clipped to [0, img_w-1] x [0, img_h-1] (BoxList.clip_to_image, structures/bounding_box.py:317-325).
+ * drc_srpn_proposals_fwd -- one FPN level of the Stereo RPN from the head's dense maps to per-anchor proposals (reference
+ *   modeling/rpn/stereo_rpn/srpn.py:41-50 pairwise softmax; stereo_rpn/inference.py:121-150 flattening, decode, left = codes
+ *   0..3, right = (4,1,5,3), clip_boxes :287-299): logits [N][2A][H][W] (RAW cls_logits output), regression [N][6A][H][W],
+ *   anchors [H*W*A][4] (position-major), image_wh [N][2]; writes scores / left / right at [n][level_offset + (y*W+x)*A + a] of
+ *   [N][total_anchors] / [N][total_anchors][4] buffers, so the five levels land concatenated like the reference's torch.cat. */
+int drc_box_decode_fwd(const float* codes, const float* boxes, float* out, int64_t rows, int groups, int per_group, const float* weights4,
+                       float xform_clip, float img_w, float img_h, void* stream);
+int drc_srpn_proposals_fwd(const float* logits, const float* regression, const float* anchors, const float* image_wh, int N, int A, int H,
+                           int W, int64_t total_anchors, int64_t level_offset, float xform_clip, float* scores, float* left, float* right,
+                           void* stream);
+
 /* Training targets of the disparity stage -- replaces the per-ROI host loop of DispRCNN3D.prepare_psmnet_input_and_target
  * (reference modeling/detector/disprcnn3d.py:52-112) incl. Masker(thresh, padding) (roi_heads/mask_head/inference.py:90-190) and
  * DisparityMap.crop / .resize (structures/disparity.py:38-77).

@@ -1,0 +1,174 @@
+"""GPU parity tests of the 2D stage's heads through the C ABI: box decode, Stereo RPN, stereo box head, mask head and
+the DispRCNN driver, against the CPU oracle and the fixtures recorded from the imported reference (tests/golden/det_golden.npz).
+Tolerances: decode 1e-3 px (expf), objectness 1e-5, conv maps 2e-4 (Winograd fp32 + summation order), FC outputs 2e-3, boxes 5e-3 px,
+mask probabilities 5e-4; kept sets identical to the reference's."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import det_oracle as D
+from disprcnn_amd.utils import synth
+from tests.helpers import check_samples, golden_npz
+from tests.test_oracle_det import CASES, POST_NMS, RATIOS, SIZES, STRIDES, det_states
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def z():
+    return golden_npz("det_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from disprcnn_amd.modeling.detector import default_cfg_2d
+    from disprcnn_amd.modeling.roi_heads import build_roi_heads
+    from disprcnn_amd.modeling.rpn import build_stereorpn
+    cfg = default_cfg_2d("R-50-FPN", post_nms_top_n_test=POST_NMS)
+    rpn, heads = build_stereorpn(cfg, 256), build_roi_heads(cfg, 256)
+    w_rpn, w_heads = det_states()
+    rpn.load_state_dict(w_rpn, strict=True)
+    heads.load_state_dict(w_heads, strict=True)
+    return rpn.to(dev).eval(), heads.to(dev).eval()
+
+
+@pytest.mark.parametrize("rows,groups,per,clip", [(1000, 1, 6, None), (777, 2, 4, (320, 160)), (64, 3, 6, (1242, 375)), (0, 2, 4, None), (5, 1, 4, (50, 40))])
+def test_box_decode_vs_oracle(dev, rows, groups, per, clip):
+    from disprcnn_amd.modeling.box_coder import BoxCoder
+    w = (10.0, 10.0, 5.0, 5.0) if per == 4 else (1.0, 1.0, 1.0, 1.0)
+    codes = synth.hash_uniform(f"dec{rows}", (rows, groups * per), -3.0, 3.0) * (4.0 if per == 4 else 1.0)
+    if rows:
+        codes[0, 2] = 50.0                                # exceeds the log(1000/16) clamp
+    b = synth.hash_uniform(f"decb{rows}", (rows, 4), 0.0, 1.0)
+    boxes = torch.stack([b[:, 0] * 300, b[:, 1] * 150, b[:, 0] * 300 + b[:, 2] * 200, b[:, 1] * 150 + b[:, 3] * 100], 1)
+    got = BoxCoder(w).decode(codes.to(dev), boxes.to(dev), clip_to=clip, per=per).cpu()
+    assert got.shape == codes.shape
+    if rows == 0:
+        return
+    ref = torch.cat([D.decode(codes[:, g * per:(g + 1) * per], boxes, w) for g in range(groups)], 1)
+    if clip is not None:
+        ref = ref.reshape(-1, per)
+        ref[:, [0, 2] + ([4, 5] if per == 6 else [])] = ref[:, [0, 2] + ([4, 5] if per == 6 else [])].clamp(0, clip[0] - 1)
+        ref[:, [1, 3]] = ref[:, [1, 3]].clamp(0, clip[1] - 1)
+        ref = ref.reshape(rows, -1)
+    scale = ref.abs().clamp(min=1.0)
+    assert ((got - ref).abs() / scale).max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("tag,n,h,w", CASES)
+def test_stereo_rpn_vs_oracle_and_reference(dev, z, model, tag, n, h, w):
+    from disprcnn_amd.structures.image_list import ImageList
+    rpn, _ = model
+    fl, fr = synth.synth_pyramid(n, h, w, tag="det" + tag)
+    gl, gr = [f.to(dev) for f in fl], [f.to(dev) for f in fr]
+    images = ImageList(torch.zeros(n, 3, h, w), [(h, w)] * n)
+    # raw head maps vs the reference's (objectness is recorded after its pairwise softmax)
+    logits, regs = rpn._head(gl, gr)
+    for lvl in range(5):
+        s = logits[lvl]
+        check_samples(z, tag, f"obj{lvl}", s.view(s.shape[0], 2, -1, s.shape[3]).softmax(1).view(*s.shape), 3e-5)
+        check_samples(z, tag, f"reg{lvl}", regs[lvl], 3e-4)
+    # every anchor's (score, left, right) vs the oracle
+    w_rpn, _ = det_states()
+    obj, reg = D.srpn_head(fl, fr, w_rpn)
+    anchors = D.pyramid_anchors(SIZES, RATIOS, [tuple(f.shape[-2:]) for f in fl], STRIDES)
+    sc, left, right = rpn.proposals_dense(images, gl, gr)
+    osc = torch.cat([o.permute(0, 2, 3, 1).reshape(n, -1, 2) for o in obj], 1)[:, :, 1]
+    org = torch.cat([r.permute(0, 2, 3, 1).reshape(n, -1, 6) for r in reg], 1)
+    anc = torch.cat([torch.as_tensor(a, dtype=torch.float32) for a in anchors], 0)
+    assert (sc.cpu() - osc).abs().max().item() <= 3e-5
+    for i in range(n):
+        p = D.decode(org[i], anc, (1.0, 1.0, 1.0, 1.0))
+        assert (left[i].cpu() - D.clip(p[:, 0:4], w, h)).abs().max().item() <= 5e-3
+        assert (right[i].cpu() - D.clip(p[:, [4, 1, 5, 3]], w, h)).abs().max().item() <= 5e-3
+    # final proposals vs the reference
+    lp, rp, _ = rpn(images, images, gl, gr)
+    for i in range(n):
+        assert len(lp[i]) == z[f"{tag}_prop_left{i}"].shape[0] == POST_NMS and lp[i].size == (w, h)
+        np.testing.assert_allclose(lp[i].get_field("objectness").cpu().numpy(), z[f"{tag}_prop_score{i}"], rtol=0, atol=3e-5)
+        np.testing.assert_allclose(lp[i].bbox.cpu().numpy(), z[f"{tag}_prop_left{i}"], rtol=0, atol=5e-3)
+        np.testing.assert_allclose(rp[i].bbox.cpu().numpy(), z[f"{tag}_prop_right{i}"], rtol=0, atol=5e-3)
+
+
+@pytest.mark.parametrize("tag,n,h,w", CASES)
+def test_roi_heads_vs_reference(dev, z, model, tag, n, h, w):
+    from disprcnn_amd.structures.bounding_box import BoxList
+    _, heads = model
+    fl, fr = synth.synth_pyramid(n, h, w, tag="det" + tag)
+    gl, gr = [f.to(dev) for f in fl], [f.to(dev) for f in fr]
+
+    def props(side):
+        out = []
+        for i in range(n):
+            b = BoxList(torch.from_numpy(z[f"{tag}_prop_{side}{i}"]).to(dev), (w, h))
+            b.add_field("objectness", torch.from_numpy(z[f"{tag}_prop_score{i}"]).to(dev))
+            out.append(b)
+        return out
+    lp, rp = props("left"), props("right")                  # the REFERENCE's proposals: one flipped tie upstream cannot cascade
+    x = heads.box.feature_extractor({"left": gl, "right": gr}, {"left": lp, "right": rp})
+    logits, deltas = heads.box.predictor(x)
+    check_samples(z, tag, "box_x", x, 2e-3)
+    np.testing.assert_allclose(logits.cpu().numpy(), z[f"{tag}_box_logits"], rtol=0, atol=3e-3)
+    np.testing.assert_allclose(deltas.cpu().numpy(), z[f"{tag}_box_deltas"], rtol=0, atol=3e-3)
+    _, ld, rd, _ = heads(gl, gr, lp, rp)
+    for i in range(n):
+        assert ld[i].bbox.shape == z[f"{tag}_det_left{i}"].shape, "kept set differs from the reference's"
+        np.testing.assert_array_equal(ld[i].get_field("labels").cpu().numpy(), z[f"{tag}_det_label{i}"])
+        np.testing.assert_allclose(ld[i].get_field("scores").cpu().numpy(), z[f"{tag}_det_score{i}"], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(ld[i].bbox.cpu().numpy(), z[f"{tag}_det_left{i}"], rtol=0, atol=5e-2)
+        np.testing.assert_allclose(rd[i].bbox.cpu().numpy(), z[f"{tag}_det_right{i}"], rtol=0, atol=5e-2)
+        m = ld[i].get_field("mask")
+        assert tuple(m.shape) == tuple(z[f"{tag}_det_mask_shape{i}"])
+    # mask head alone on the reference's detections (tight)
+    dets = []
+    for i in range(n):
+        b = BoxList(torch.from_numpy(z[f"{tag}_det_left{i}"]).to(dev), (w, h))
+        b.add_field("labels", torch.from_numpy(z[f"{tag}_det_label{i}"]).to(dev))
+        dets.append(b)
+    _, md, _ = heads.mask(gl, dets)
+    for i in range(n):
+        check_samples(z, tag, f"det_mask{i}", md[i].get_field("mask"), 5e-4)
+
+
+def test_disprcnn_end_to_end_vs_oracle(dev):
+    """The whole 2D stage (R-50-FPN trunk + Stereo RPN + heads) on a small stereo pair: the heads' outputs are checked against the
+    oracle fed with the product's own pyramid (the trunk has its own golden tests, tests/test_backbone.py)."""
+    from disprcnn_amd.modeling.detector import DispRCNN, default_cfg_2d
+    n, h, w = 2, 160, 256
+    m = DispRCNN(default_cfg_2d("R-50-FPN", post_nms_top_n_test=40))
+    sd = m.state_dict()
+    t_rpn = {k[4:]: v for k, v in sd.items() if k.startswith("rpn.")}
+    t_heads = {k[10:]: v for k, v in sd.items() if k.startswith("roi_heads.")}
+    w_rpn, w_heads = synth.synth_det_state(t_rpn, gain=synth.DET_GAIN), synth.synth_det_state(t_heads, gain=synth.DET_GAIN)
+    bb = synth.synth_backbone_state({k[9:]: v for k, v in sd.items() if k.startswith("backbone.")})
+    m.load_state_dict({**{"backbone." + k: v for k, v in bb.items()}, **{"rpn." + k: v for k, v in w_rpn.items()},
+                       **{"roi_heads." + k: v for k, v in w_heads.items()}}, strict=True)
+    m = m.to(dev).eval()
+    left, right = synth.synth_images(n, h, w, tag="e2e2d")
+    with torch.no_grad():
+        out = m({"left": left.to(dev), "right": right.to(dev)})
+        feats = m.backbone(torch.cat((left, right), 0).to(dev))
+    assert set(out) == {"left", "right"} and len(out["left"]) == n
+    fl, fr = [f[:n].cpu() for f in feats], [f[n:].cpu() for f in feats]
+    obj, reg = D.srpn_head(fl, fr, w_rpn)
+    anchors = D.pyramid_anchors(SIZES, RATIOS, [tuple(f.shape[-2:]) for f in fl], STRIDES)
+    props = D.srpn_select(anchors, obj, reg, [(w, h)] * n, 6000, 40, 0.7, 0)
+    pl, pr = [p[0] for p in props], [p[1] for p in props]
+    _, logits, deltas = D.box_head(fl, fr, pl, pr, h, w_heads)
+    dets = D.box_post(logits, deltas, pl, pr, [(w, h)] * n)
+    for i in range(n):
+        ld, rd = out["left"][i], out["right"][i]
+        assert ld.size == (w, h) and set(ld.fields()) >= {"scores", "labels", "mask"}
+        assert len(ld) == len(dets[i]["scores"]) == len(rd), (len(ld), len(dets[i]["scores"]))
+        # same detections up to order (ties in NMS bookkeeping aside): compare sorted by score
+        o1, o2 = torch.argsort(ld.get_field("scores").cpu(), descending=True), torch.argsort(dets[i]["scores"], descending=True)
+        assert (ld.get_field("scores").cpu()[o1] - dets[i]["scores"][o2]).abs().max().item() <= 2e-3
+        assert (ld.bbox.cpu()[o1] - dets[i]["left"][o2]).abs().max().item() <= 0.1
+        assert (rd.bbox.cpu()[o1] - dets[i]["right"][o2]).abs().max().item() <= 0.1
+        assert tuple(ld.get_field("mask").shape) == (len(ld), 1, 28, 28)
