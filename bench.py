@@ -441,6 +441,26 @@ def rank0_extras(dev, extra):
                               "profiles/r2_pair_*.md")},
         "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
     del bb, det, mB
+    # ---- the 2D stage in front of the path: DispRCNN = R-50-FPN trunk + Stereo RPN + stereo box head + mask head on the pair
+    try:
+        from disprcnn_amd.modeling.detector import DispRCNN, default_cfg_2d
+        d2 = DispRCNN(default_cfg_2d("R-50-FPN"))
+        sd2 = d2.state_dict()
+        heads2 = synth.synth_det_state({k: v for k, v in sd2.items() if not k.startswith("backbone.")}, gain={
+            "rpn." + k if k.startswith("head.") else "roi_heads." + k: v for k, v in synth.DET_GAIN.items()})
+        d2.load_state_dict({**{"backbone." + k: v for k, v in bsd.items()}, **heads2}, strict=True)
+        d2 = d2.to(dev).eval()
+        with torch.no_grad():
+            out2 = d2({"left": pair[:1], "right": pair[1:]})
+            t2d = _time(lambda: d2({"left": pair[:1], "right": pair[1:]}), 1, 5)
+        extra["stereo_2d_stage_r50fpn_pair"] = {
+            "ms_per_pair": round(t2d * 1e3, 2), "pairs_per_s": round(1.0 / t2d, 2), "heads_ms": round((t2d - tbb) * 1e3, 2),
+            "detections": int(len(out2["left"][0])),
+            "workload": ("DispRCNN on 2x3x375x1242 with synthetic weights: R-50-FPN trunk, Stereo RPN over 5 levels (PRE_NMS 6000, POST_NMS 300), "
+                         "stereo box head (2 x 7x7 ROIAlign, FC 25088-2048-2048), NMS, mask head (14x14 ROIAlign, 4 x conv3x3, deconv, logits)")}
+        del d2, out2
+    except Exception as ex:                                   # noqa: BLE001 -- reported, never hides the other extras
+        extra["stereo_2d_stage_error"] = repr(ex)[:300]
     # ---- post-processing: 16 images 375x1242, 16 ROI maps 224x224 each -> full-image disparity maps
     from disprcnn_amd import ops as _ops
     gpp = torch.Generator().manual_seed(0)
