@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wgrad_params p, int R, int WT) {
+__global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wgrad_params p, int R, int WT, int nseg, int seglen) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -61,7 +61,11 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
     for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     unsigned poff_a[WS_PA], poff_b[WS_PB];
-    for (int col = blockIdx.x * WS_WAVES + wave; col < cols; col += workers) {
+    // work unit = (column, depth segment): a column's D output slices are cut into nseg runs of seglen so that the units divide
+    // evenly among the waves (32->32 at 64 ROIs: 896 columns over 256 waves = 3.5 per wave -> 1,792 half columns = 7 per wave)
+    for (int unit = blockIdx.x * WS_WAVES + wave; unit < cols * nseg; unit += workers) {
+        const int col = unit / nseg, sgi = unit - col * nseg;
+        const int od_lo = sgi * seglen, od_hi = od_lo + seglen < D ? od_lo + seglen : D;
         int q = col;
         const int wt = q % n_wt; q /= n_wt;
         const int rt = q % n_rt;
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
         };
 
         // all LDS reads of the previous column are consumed (in-order wave) before its tiles are overwritten
-        stage_a(0); stage_a(1); stage_a(2); stage_b(0);
-        for (int od = 0; od < D; ++od) {
+        stage_a(od_lo); stage_a(od_lo + 1); stage_a(od_lo + 2); stage_b(od_lo);
+        for (int od = od_lo; od < od_hi; ++od) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a[od+2] and b[od] (issued one slice ago) have landed
             const float* bt = lds_b + (od & 1) * b_floats;
             // Software pipeline over the (depth tap, k-step) stages of the slice: the ten operand reads of the NEXT stage are issued
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
                         if (last_m && kd < 2 && cur == 0) fetch(0, kd + 1, 0, a_off[0]);
                     }
                 }
-                if (kd == 0 && od + 1 < D) {   // slot od % 3 is free now: stage the slice after next into it, and the next b tile
+                if (kd == 0 && od + 1 < od_hi) {   // slot od % 3 is free now: stage the slice after next into it, and the next b tile
                     __builtin_amdgcn_sched_barrier(0);
                     stage_a(od + 3);
                     stage_b(od + 1);
@@ -213,7 +217,7 @@ extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* str
     const long cols = (long)p.N * ((p.OH + R - 1) / R) * ((p.OW + WT - 1) / WT);
     const long jobs = (long)p.cb_a * p.cb_b;
     long workers = 1024 / (jobs > 0 ? jobs : 1);            // one wave per SIMD across all jobs (atomicAdd flushes per wave)
-    if (workers > cols) workers = cols;
+    if (workers > cols * 4) workers = cols * 4;              // up to four depth segments per column (below)
     if (workers < 1) workers = 1;
     dim3 grid((unsigned)((workers + WS_WAVES - 1) / WS_WAVES), (unsigned)jobs, 1);
     const bool partial = drc_wgrad_scratch_fits(p, (long)grid.x * WS_WAVES * jobs, 27);
@@ -221,7 +225,18 @@ extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* str
         p.scratch = nullptr;
         if (const int st = drc_wgrad_clear_for_atomics(p, (hipStream_t)stream)) return st;
     }
-    hipLaunchKernelGGL(wgrad_slide_kernel, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT);
+    // depth segments: the split (<= 4 runs of >= 3 slices) with the shortest critical path, rounds x (slices per unit + staging prologue)
+    const long nworkers = (long)grid.x * WS_WAVES;
+    int nseg = 1, seglen = p.OD;
+    double best = 1e30;
+    for (int s = 1; s <= 4; ++s) {
+        const int len = (p.OD + s - 1) / s;
+        if (s > 1 && len < 3) break;
+        const int ns = (p.OD + len - 1) / len;
+        const double cost = (double)((cols * ns + nworkers - 1) / nworkers) * (len + 0.75);
+        if (cost < best - 1e-9) { best = cost; nseg = ns; seglen = len; }
+    }
+    hipLaunchKernelGGL(wgrad_slide_kernel, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT, nseg, seglen);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess || !partial) return e == hipSuccess ? 0 : (int)e;
     return drc_wgrad_reduce(p, (int)grid.x * WS_WAVES, jobs, 27, (hipStream_t)stream);
