@@ -63,7 +63,7 @@ class MaskRCNNC4Predictor(nn.Module):
         t = torch.relu_(t).permute(0, 1, 4, 2, 5, 3).reshape(-1, cout)                          # rows = output pixels (y, dy, x, dx)
         wl = self.mask_fcn_logits.weight.detach().to(device=x.device, dtype=torch.float32).view(-1, cout)
         lg = torch.addmm(self.mask_fcn_logits.bias.detach().to(x.device).float(), t, wl.t())
-        return lg.view(r, 2 * h, 2 * w, -1).permute(0, 3, 1, 2).contiguous()
+        return lg.view(r, 2 * h, 2 * w, wl.shape[0]).permute(0, 3, 1, 2).contiguous()
 
 
 class MaskPostProcessor(nn.Module):

@@ -136,6 +136,29 @@ def test_roi_heads_vs_reference(dev, z, model, tag, n, h, w):
         check_samples(z, tag, f"det_mask{i}", md[i].get_field("mask"), 5e-4)
 
 
+def test_roi_heads_without_detections(dev, z, model):
+    """No proposal passes the score threshold: empty BoxLists with an empty [0,1,28,28] mask field, no launch on empty batches."""
+    from disprcnn_amd.structures.bounding_box import BoxList
+    _, heads = model
+    tag, n, h, w = CASES[1]
+    fl, fr = synth.synth_pyramid(n, h, w, tag="det" + tag)
+    gl, gr = [f.to(dev) for f in fl], [f.to(dev) for f in fr]
+    lp = [BoxList(torch.from_numpy(z[f"{tag}_prop_left{i}"]).to(dev), (w, h)) for i in range(n)]
+    rp = [BoxList(torch.from_numpy(z[f"{tag}_prop_right{i}"]).to(dev), (w, h)) for i in range(n)]
+    saved = heads.box.post_processor.score_thresh
+    heads.box.post_processor.score_thresh = 2.0
+    try:
+        _, ld, rd, _ = heads(gl, gr, lp, rp)
+    finally:
+        heads.box.post_processor.score_thresh = saved
+    for i in range(n):
+        assert len(ld[i]) == 0 and len(rd[i]) == 0
+        assert tuple(ld[i].get_field("mask").shape) == (0, 1, 28, 28) and ld[i].get_field("labels").dtype == torch.int64
+    # and an image without proposals at all
+    x = heads.box.feature_extractor({"left": gl, "right": gr}, {"left": [lp[0][:0]], "right": [rp[0][:0]]})
+    assert tuple(x.shape) == (0, 2048)
+
+
 def test_disprcnn_end_to_end_vs_oracle(dev):
     """The whole 2D stage (R-50-FPN trunk + Stereo RPN + heads) on a small stereo pair: the heads' outputs are checked against the
     oracle fed with the product's own pyramid (the trunk has its own golden tests, tests/test_backbone.py)."""
