@@ -61,15 +61,20 @@ __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(con
         const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
         const float ty = fy - y0, tx = fx - x0;
         const float* c = cost + (long)n * Dp * Hp * Wp;
-        float m = -INFINITY;
         for (int k = 0; k < Dp; ++k) {
             const float* s = c + (long)k * Hp * Wp;
             const float a = s[y0 * Wp + x0] * (1.f - tx) + s[y0 * Wp + x1] * tx;
             const float b = s[y1 * Wp + x0] * (1.f - tx) + s[y1 * Wp + x1] * tx;
-            const float v = a * (1.f - ty) + b * ty;
-            cz[k * kSAThreads + threadIdx.x] = v;
+            cz[k * kSAThreads + threadIdx.x] = a * (1.f - ty) + b * ty;
             gz[k * kSAThreads + threadIdx.x] = 0.f;
-            m = fmaxf(m, v);
+        }
+        float m = -INFINITY;                            // maximum over the FINE samples (see upsample_softargmin_kernel)
+        for (int d = 0; d < D; ++d) {
+            const float fd = sd * d;
+            const int k0 = (int)fd;
+            const int k1 = k0 + (k0 < Dp - 1);
+            const float td = fd - k0;
+            m = fmaxf(m, cz[k0 * kSAThreads + threadIdx.x] * (1.f - td) + cz[k1 * kSAThreads + threadIdx.x] * td);
         }
         float se = 0.f, sde = 0.f;
         for (int d = 0; d < D; ++d) {

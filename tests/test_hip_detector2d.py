@@ -195,3 +195,55 @@ def test_disprcnn_end_to_end_vs_oracle(dev):
         assert (ld.bbox.cpu()[o1] - dets[i]["left"][o2]).abs().max().item() <= 0.1
         assert (rd.bbox.cpu()[o1] - dets[i]["right"][o2]).abs().max().item() <= 0.1
         assert tuple(ld.get_field("mask").shape) == (len(ld), 1, 28, 28)
+
+
+def test_full_pipeline_images_to_disparity_maps(dev):
+    """test_net.py's data flow on the HIP path: stereo pair -> DispRCNN (2D stage) -> DispRCNN3D (instance disparity on the detections)
+    -> DisparityMapProcessor (full-image maps).  The 2D stage's output IS the disparity stage's lr_result; each stage has its own parity
+    tests, here the hand-over is checked: fields, pairing, shapes, and the disparity stage against its oracle on the same detections."""
+    from oracle import psmnet_oracle as O, roi_oracle as R
+    from disprcnn_amd.modeling.detector import DispRCNN, DispRCNN3D, default_cfg_2d
+    from disprcnn_amd.modeling.detector.disprcnn3d import default_cfg
+    from disprcnn_amd.modeling.psmnet.inference import DisparityMapProcessor
+    from disprcnn_amd.structures import ImageList
+    from tests.helpers import state_for
+    n, h, w = 1, 192, 384
+    m2 = DispRCNN(default_cfg_2d("R-50-FPN", post_nms_top_n_test=30))
+    sd = m2.state_dict()
+    heads = synth.synth_det_state({k: v for k, v in sd.items() if not k.startswith("backbone.")},
+                                  gain={("rpn." if k.startswith("head.") else "roi_heads.") + k: v for k, v in synth.DET_GAIN.items()})
+    bb = synth.synth_backbone_state({k[9:]: v for k, v in sd.items() if k.startswith("backbone.")})
+    m2.load_state_dict({**{"backbone." + k: v for k, v in bb.items()}, **heads}, strict=True)
+    m2 = m2.to(dev).eval()
+    m3 = DispRCNN3D(default_cfg(48, -48, 224))
+    m3.dispnet.load_state_dict(state_for("B"), strict=True)
+    m3 = m3.to(dev).eval()
+    # raw [0,1) images: DispRCNN3D normalises its crops itself (disprcnn3d.py:44-50), so PSMNet sees inputs in its calibrated range
+    left = synth.hash_uniform("pipe:L", (n, 3, h, w), 0.0, 1.0)
+    right = torch.roll(left, shifts=-5, dims=3) * 0.9 + 0.1 * synth.hash_uniform("pipe:R", (n, 3, h, w), 0.0, 1.0)
+    left, right = left.to(dev), right.to(dev)
+    with torch.no_grad():
+        det = m2({"left": left, "right": right})
+        for side in ("left", "right"):                       # keep the six best detections: the CPU oracle below runs PSMNet per ROI
+            det[side] = [b[torch.argsort(det["left"][i].get_field("scores"), descending=True)[:6]] for i, b in enumerate(det[side])]
+        out = m3({"left": ImageList(left, [(h, w)] * n), "right": ImageList(right, [(h, w)] * n)}, det)
+        maps = DisparityMapProcessor()(out["left"], out["right"])
+    maps = maps if isinstance(maps, list) else [maps]
+    for i in range(n):
+        ld, rd = out["left"][i], out["right"][i]
+        assert len(ld) == len(rd) > 0 and set(ld.fields()) >= {"scores", "labels", "mask", "disparity"}
+        assert tuple(ld.get_field("disparity").shape) == (len(ld), 224, 224) and torch.isfinite(ld.get_field("disparity")).all()
+        assert tuple(maps[i].data.shape) == (h, w) and torch.isfinite(maps[i].data).all()
+    # the disparity stage vs its oracle on the detections the 2D stage produced (image 0)
+    ld, rd = out["left"][0], out["right"][0]
+    img_l, img_r = left[0].cpu().numpy(), right[0].cpu().numpy()
+    rois_l, rois_r = [], []
+    for lb, rb in zip(ld.bbox.cpu().tolist(), rd.bbox.cpu().tolist()):
+        x1, y1, x1p, y2, mw = R.align_roi_pair(lb, rb, w, h)
+        rois_l.append([0, x1, y1, x1 + mw, y2]); rois_r.append([0, x1p, y1, x1p + mw, y2])
+    import numpy as np
+    cl = torch.from_numpy(R.crop_and_normalise(img_l[None], np.asarray(rois_l, dtype=np.float32), 224))
+    cr = torch.from_numpy(R.crop_and_normalise(img_r[None], np.asarray(rois_r, dtype=np.float32), 224))
+    ref = O.psmnet_forward(state_for("B"), cl, cr, 48, -48)
+    err = (ld.get_field("disparity").cpu() - ref).abs()
+    assert err.mean().item() <= 2e-3 and err.max().item() <= 1e-1, (err.mean().item(), err.max().item())     # crops of ~8 px wide boxes

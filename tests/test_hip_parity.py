@@ -394,6 +394,31 @@ def test_upsample_softargmin_vs_oracle(dev):
         assert err.mean().item() < 1e-4 and err.max().item() < 2e-3, (err.mean().item(), err.max().item())
 
 
+def test_upsample_softargmin_sharp_costs(dev):
+    """Cost columns with |c| ~ 2000 and neighbours of opposite sign (an untrained regressor on out-of-range crops produces them):
+    every exp underflows unless the softmax shift is the maximum of the UPSAMPLED column -- the kernel used the maximum of the coarse
+    slices and returned 0/0 there.  Forward vs the oracle, backward finite and equal to the oracle's autograd."""
+    from disprcnn_amd import ops
+    dp, hp, wp, mx, mn = 24, 14, 14, 48, -48
+    cost = synth.hash_uniform("sharp", (2, 1, dp, hp, wp), -2000.0, 2000.0)
+    ref = O.upsample_softargmin(cost, mx, mn, 4 * hp, 4 * wp)
+    got = ops.upsample_softargmin(cost.to(dev), mx, mn, 4 * hp, 4 * wp).cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert err.mean().item() < 1e-3 and err.max().item() < 5e-2, (err.mean().item(), err.max().item())
+    from disprcnn_amd import _lib, engine as E
+    c = cost[:, 0].contiguous().to(dev)
+    gd = synth.hash_uniform("sharp:g", (2, 4 * hp, 4 * wp), -1.0, 1.0).to(dev)
+    g = torch.zeros_like(c)
+    st = _lib.lib().drc_upsample_softargmin_bwd(E._ptr(c), E._ptr(gd), E._ptr(g), 2, dp, hp, wp, mx - mn, 4 * hp, 4 * wp, mn, E._stream_ptr(dev))
+    _lib.check(st, "drc_upsample_softargmin_bwd")
+    assert torch.isfinite(g).all()
+    cr = cost.double().requires_grad_()
+    O.upsample_softargmin(cr, mx, mn, 4 * hp, 4 * wp).backward(gd.cpu().double())
+    gref = cr.grad[:, 0]
+    assert (g.cpu().double() - gref).abs().max().item() <= 1e-3 * max(gref.abs().max().item(), 1e-3) + 1e-6
+
+
 # ------------------------------------------------------------------------------------------------ whole path
 def _model(dev, case, mx, mn):
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
