@@ -56,6 +56,8 @@ constexpr ComboTable make_table() {
 }
 constexpr ComboTable kTab = make_table();
 
+// (Measured and rejected: one cout tile per wave, 292 registers: 83-91 TFLOP/s against 91-102 for two; the same forced to two
+// waves per SIMD with amdgpu_waves_per_eu(2,2), 29 spills: 79-84.  Occupancy is not what this kernel lacks.)
 template <int VT, int CT>
 __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_tapconv_params p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

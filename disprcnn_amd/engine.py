@@ -647,7 +647,8 @@ def plan_conv3d(x, y, stride, cout, relu):
 
 
 FUSED_DECONV = {"enabled": True}
-DECONV_DIRECT = {"enabled": True}     # LDS-free fused transposed conv (deconvdirect.hip) instead of the LDS-staged tapdeconv.hip
+DECONV_DIRECT = {"enabled": True,     # LDS-free fused transposed conv (deconvdirect.hip) instead of the LDS-staged tapdeconv.hip
+                 "ct": 2}             # cout tiles per wave when they pair up (development knob: tools/exp_conv.py DC_CT)
 
 
 DECONV_TILE = None    # development override (tools/exp_conv.py)
@@ -684,7 +685,7 @@ def plan_deconv3d(x, y, cout, relu):
             # LDS-free kernel: 32 consecutive voxels of the flattened (n,d,h,w) index per wave (no tile shape), two cout tiles per wave
             # when the cout tiles pair up (every layer of the regressor)
             ct = pl.p.cout_pad // 16
-            CT = 2 if ct % 2 == 0 else 1
+            CT = 2 if ct % 2 == 0 and DECONV_DIRECT["ct"] == 2 else 1
             pl.deconv_direct, pl.direct, pl.deconv_ct = True, True, CT
             pl.p.R, pl.p.WT = 1, min(x.W, 32)
             pl.kname = "deconvdirect_kernel<2,%d>" % CT

@@ -48,8 +48,10 @@ if __name__ == "__main__":
         E.MAX_SLOTS = int(os.environ["MAX_SLOTS"])
     if os.environ.get("DECONV_DIRECT"):
         E.DECONV_DIRECT["enabled"] = os.environ["DECONV_DIRECT"] != "0"
+    if os.environ.get("DC_CT"):
+        E.DECONV_DIRECT["ct"] = int(os.environ["DC_CT"])
     if os.environ.get("DC_B"):
-        for n_ in (16, 64):
+        for n_ in ((int(os.environ["DC_N"]),) if os.environ.get("DC_N") else (16, 64)):
             run(n_, 64, 64, (6, 14, 14), deconv=True)
             run(n_, 64, 32, (12, 28, 28), deconv=True)
         sys.exit(0)
