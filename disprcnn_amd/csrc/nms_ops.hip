@@ -49,31 +49,66 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     mask[(int64_t)row * col_blocks + cb] = t;
 }
 
-// one wavefront: lane j holds the removed-bits of column blocks j, j+64, ...
+// one wavefront: lane j holds the removed-bits of column blocks j, j+64, ...  The walk goes 64 rows (one column block) at a time:
+// (1) lane r fetches the DIAGONAL word of row 64c+r (one parallel load, issued a chunk ahead); (2) the 64 rows of the chunk are
+// resolved against each other in registers -- the only truly sequential part, ~20 cycles per row, no memory access; (3) the kept rows'
+// mask rows are ORed into the removed-words of the later blocks with independent loads, four rows in flight.  (Round 2, first form:
+// one dependent global load per kept row -- 1.27 ms for the Stereo RPN's 6,000 boxes, 27 % of the 2D stage.)
 __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks, uint8_t* __restrict__ keep) {
     constexpr int kMaxWords = 8;                           // up to 64*64*8 = 32768 boxes
     uint64_t remv[kMaxWords];
 #pragma unroll
     for (int w = 0; w < kMaxWords; ++w) remv[w] = 0;
     const int lane = threadIdx.x;
-    for (int i = 0; i < n; ++i) {
-        const int nb = i >> 6, ib = i & 63;
-        // the word of block nb lives in lane nb & 63, register nb >> 6
+    auto diag_of = [&](int c) {
+        const int row = c * 64 + lane;
+        return (c < col_blocks && row < n) ? mask[(int64_t)row * col_blocks + c] : 0ULL;
+    };
+    uint64_t dnext = diag_of(0);
+    for (int c = 0; c < col_blocks; ++c) {
+        const uint64_t diag = dnext;
+        dnext = diag_of(c + 1);
+        const int nr = n - c * 64 < 64 ? n - c * 64 : 64;
+        // removed-bits of block c: they live in lane c & 63, register c >> 6
         uint64_t word = 0;
 #pragma unroll
         for (int w = 0; w < kMaxWords; ++w)
-            if (w == (nb >> 6)) word = remv[w];
-        const unsigned lo = __builtin_amdgcn_readlane((unsigned)word, nb & 63), hi = __builtin_amdgcn_readlane((unsigned)(word >> 32), nb & 63);
-        const uint64_t cur = ((uint64_t)hi << 32) | lo;
-        const bool kept = !((cur >> ib) & 1ULL);           // wave-uniform
-        if (lane == 0) keep[i] = kept ? 1 : 0;
-        if (kept) {
-            const uint64_t* p = mask + (int64_t)i * col_blocks;
+            if (w == (c >> 6)) word = remv[w];
+        // (the builtin returns a signed int: widen through unsigned, or bit 31 of the low half smears over the high half)
+        uint64_t cur = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((unsigned)(word >> 32), c & 63) << 32) |
+                       (uint64_t)(unsigned)__builtin_amdgcn_readlane((unsigned)word, c & 63);
+        uint64_t kept = 0;                                 // wave-uniform
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        for (int r = 0; r < nr; ++r) {                     // branch-free: the cross-lane reads stay in uniform control flow
+            const uint64_t dr = ((uint64_t)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readlane(dlo, r);
+            const uint64_t k = ((cur >> r) & 1ULL) ^ 1ULL;
+            kept |= k << r;
+            cur |= dr & (0ULL - k);
+        }
+        if (lane < nr) keep[c * 64 + lane] = (uint8_t)((kept >> lane) & 1ULL);
+        // OR the kept rows into the later blocks' removed-words
+        uint64_t km = kept;
+        while (km) {
+            int rows[4];
 #pragma unroll
-            for (int w = 0; w < kMaxWords; ++w) {
-                const int j = w * 64 + lane;
-                if (j >= nb && j < col_blocks) remv[w] |= p[j];
+            for (int q = 0; q < 4; ++q) {
+                rows[q] = km ? __builtin_ctzll(km) : -1;
+                km &= km - 1;                              // (0 & anything stays 0)
             }
+            uint64_t v[4][kMaxWords];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t* p = mask + (int64_t)(c * 64 + (rows[q] < 0 ? 0 : rows[q])) * col_blocks;
+#pragma unroll
+                for (int w = 0; w < kMaxWords; ++w) {
+                    const int j = w * 64 + lane;
+                    v[q][w] = (rows[q] >= 0 && j > c && j < col_blocks) ? p[j] : 0ULL;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < kMaxWords; ++w) remv[w] |= v[q][w];
         }
     }
 }
