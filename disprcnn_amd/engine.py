@@ -16,7 +16,7 @@ SLACK_FLOATS = 1 << 16          # over-read room behind every blocked tensor (ra
 LDS_PER_WAVE_MAX = 38 * 1024    # 4 waves/block -> 152 KiB of the 160 KiB LDS
 MAX_SLOTS = 112                 # 7 voxel tiles of 16
 TIMING = None                   # bench.py sets this to a list to collect (kernel name, flops, start_evt, end_evt)
-SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1, "min_units": 700}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
+SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1, "min_units": 700, "min_units_ct1": 150}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
 
 
 def _stream_ptr(device):
@@ -452,6 +452,9 @@ class ConvPlan:
             # (measured cross-over, tools/exp_conv.py)
             self.slide_ct = SLIDE["ct"] if ct % SLIDE["ct"] == 0 else 1
             cols = x.N * (-(-OH // R)) * (-(-OW // WT))
+            # small batches: with ONE cout tile per wave the LDS-free direct kernel still beats the generic kernel down to ~150 units
+            # (3x7x7 maps, 64->64: 47 vs 87 us at 64 ROIs, 45 vs 84 us at 16; at 128 ROIs two tiles per wave win, 75 vs 93 us)
+            self.slide_small_ok = OD >= SLIDE["min_od"] and cols * ct * OD >= SLIDE["min_units_ct1"]
             if OD < SLIDE["min_od"] or cols * (ct // self.slide_ct) * OD // SLIDE["min_share"] < SLIDE["min_units"]:
                 self.slide = False
             else:
@@ -626,6 +629,11 @@ def plan_conv3d(x, y, stride, cout, relu):
         if WINO["enabled"] and not (y.D | y.H | y.W) & 1 and x.N * x.n_stride * 4 < 2 ** 32:
             pl.wino = True
             pl.kname = "wino3d_kernel<%d>" % pl.slide_ct
+    elif (not pl.slide and stride == 1 and SLIDE["enabled"] and DIRECT["enabled"] and getattr(pl, "slide_small_ok", False)
+          and (y.D | y.H | y.W) & 1):
+        # odd maps (no Winograd) at small batch: the direct kernel with one cout tile per wave
+        pl.slide, pl.direct, pl.slide_ct = True, True, 1
+        pl.kname = "tapdirect_kernel<%d,1>" % (-(-(pl.p.R * pl.p.WT) // 16))
     elif pl.slide and (pl.p.R + 2) * (-(-(2 * (pl.p.WT + 2)) // 64)) > 18:
         pl.slide = False                     # the LDS-staged kernel stages at most two pieces per tap step: tall narrow tiles go generic
         pl.kname = pl.kname.replace("tapslide", "tapconv")

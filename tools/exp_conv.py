@@ -67,11 +67,11 @@ if __name__ == "__main__":
         E.SLIDE["min_od"] = int(os.environ["SLIDE_MIN_OD"]); E.SLIDE["min_share"] = 1
     if os.environ.get("SLIDE_MIN_UNITS"):
         E.SLIDE["min_units"] = int(os.environ["SLIDE_MIN_UNITS"])
+    if os.environ.get("SLIDE_CT"):
+        E.SLIDE["ct"] = int(os.environ["SLIDE_CT"])
     if os.environ.get("QUARTER"):
         run(N, 64, 64, (3, 7, 7))
         sys.exit(0)
-    if os.environ.get("SLIDE_CT"):
-        E.SLIDE["ct"] = int(os.environ["SLIDE_CT"])
     run(N, 32, 32, (12, 28, 28))
     if os.environ.get("ALL"):
         run(N, 64, 32, (12, 28, 28))
