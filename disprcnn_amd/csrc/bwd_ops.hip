@@ -31,35 +31,40 @@ inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[
 // ------------------------------------------------------------------------------------------------ a7 backward
 // disp = sum_d p_d * dval_d, p = softmax_d(c_up), c_up = trilinear(cost).  d disp / d c_up[d] = p_d (dval_d - disp).
 // One thread per output pixel, one block per 8 x 16 pixel tile of an image: recompute the LDS column of bilinear-resampled
-// coarse slices, fold the D fine gradients back onto the coarse slices (lerp weights), add the D' values onto the tile's coarse
-// footprint (a few cells x D', LDS atomics), then flush the footprint with one global atomicAdd per cell -- 20x fewer global
-// atomics than scattering from every pixel.
+// coarse slices, fold the D fine gradients back onto the coarse slices (lerp weights) -> gz[D'][pixel].  The pixels' D' values are
+// then gathered onto the tile's coarse footprint (a few cells x D') SEPARABLY and without atomics -- along x into tmp[D'][8 rows][CW],
+// along y into the footprint; bilinear weights come from per-row / per-column tables -- and the footprint is flushed with one global
+// atomicAdd per cell (neighbouring tiles share their border cells).  (Round 2, first form: 48 LDS atomicAdds per pixel onto ~24
+// cells per slice, ~20-way contended: 303 us per call at 64 ROIs.)
 constexpr int kSAThreads = 128, kSATX = 16, kSATY = 8;
 __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ gdisp,
                                                                              float* __restrict__ gcost, int N, int Dp, int Hp, int Wp,
                                                                              int D, int H, int W, int mindisp, int CH, int CW) {
-    extern __shared__ float sm[];                      // cz [Dp][T], gz [Dp][T], footprint [Dp][CH][CW]
+    extern __shared__ float sm[];                      // cz [Dp][T], gz [Dp][T], tmp [Dp][kSATY][CW]
     float* cz = sm;
     float* gz = sm + Dp * kSAThreads;
-    float* fp = gz + Dp * kSAThreads;
+    float* tmp = gz + Dp * kSAThreads;
+    __shared__ int row_l[kSATY][2], col_l[kSATX][2];
+    __shared__ float row_t[kSATY], col_t[kSATX];
     const int tiles_x = (W + kSATX - 1) / kSATX, tiles_y = (H + kSATY - 1) / kSATY;
     int bt = blockIdx.x;
     const int bx = bt % tiles_x; bt /= tiles_x;
     const int by = bt % tiles_y;
     const int n = bt / tiles_y;
-    const int x = bx * kSATX + (threadIdx.x % kSATX), y = by * kSATY + (threadIdx.x / kSATX);
+    const int txi = threadIdx.x % kSATX, tyi = threadIdx.x / kSATX;
+    const int x = bx * kSATX + txi, y = by * kSATY + tyi;
     const bool live = x < W && y < H;
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
     const float sd = D > 1 ? (float)(Dp - 1) / (float)(D - 1) : 0.f;
     const int cy0 = (int)(sy * (by * kSATY)), cx0 = (int)(sx * (bx * kSATX));     // footprint origin (coarse)
-    for (int i = threadIdx.x; i < Dp * CH * CW; i += kSAThreads) fp[i] = 0.f;
-    __syncthreads();
+    const float fy = sy * y, fx = sx * x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
+    const float ty = fy - y0, tx = fx - x0;
+    if (txi == 0) { row_l[tyi][0] = y < H ? y0 - cy0 : -1000; row_l[tyi][1] = y < H ? y1 - cy0 : -1000; row_t[tyi] = ty; }
+    if (tyi == 0) { col_l[txi][0] = x < W ? x0 - cx0 : -1000; col_l[txi][1] = x < W ? x1 - cx0 : -1000; col_t[txi] = tx; }
     if (live) {
-        const float fy = sy * y, fx = sx * x;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
-        const float ty = fy - y0, tx = fx - x0;
         const float* c = cost + (long)n * Dp * Hp * Wp;
         for (int k = 0; k < Dp; ++k) {
             const float* s = c + (long)k * Hp * Wp;
@@ -96,23 +101,35 @@ __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(con
             gz[k0 * kSAThreads + threadIdx.x] += gv * (1.f - td);
             gz[k1 * kSAThreads + threadIdx.x] += gv * td;
         }
-        const int ly0 = y0 - cy0, ly1 = y1 - cy0, lx0 = x0 - cx0, lx1 = x1 - cx0;   // inside [0,CH) x [0,CW) by construction
-        for (int k = 0; k < Dp; ++k) {
-            const float v = gz[k * kSAThreads + threadIdx.x];
-            float* f = fp + k * CH * CW;
-            atomicAdd(f + ly0 * CW + lx0, v * (1.f - ty) * (1.f - tx));
-            atomicAdd(f + ly0 * CW + lx1, v * (1.f - ty) * tx);
-            atomicAdd(f + ly1 * CW + lx0, v * ty * (1.f - tx));
-            atomicAdd(f + ly1 * CW + lx1, v * ty * tx);
-        }
+    } else {
+        for (int k = 0; k < Dp; ++k) gz[k * kSAThreads + threadIdx.x] = 0.f;
     }
     __syncthreads();
+    // along x: tmp[k][row][cx] = sum over the row's 16 pixels of gz * wx(pixel, cx)
+    for (int o = threadIdx.x; o < Dp * kSATY * CW; o += kSAThreads) {
+        const int cxl = o % CW, r = (o / CW) % kSATY, k = o / (CW * kSATY);
+        const float* gr = gz + k * kSAThreads + r * kSATX;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < kSATX; ++c) {
+            const float w = (col_l[c][0] == cxl ? 1.f - col_t[c] : 0.f) + (col_l[c][1] == cxl ? col_t[c] : 0.f);
+            acc += gr[c] * w;
+        }
+        tmp[o] = acc;
+    }
+    __syncthreads();
+    // along y, and flush: one global atomicAdd per footprint cell
     float* gc = gcost + (long)n * Dp * Hp * Wp;
-    for (int i = threadIdx.x; i < Dp * CH * CW; i += kSAThreads) {
-        const int k = i / (CH * CW), r = i - k * CH * CW;
-        const int yy = cy0 + r / CW, xx = cx0 + r % CW;
-        const float v = fp[i];
-        if (v != 0.f && yy < Hp && xx < Wp) atomicAdd(gc + ((long)k * Hp + yy) * Wp + xx, v);
+    for (int o = threadIdx.x; o < Dp * CH * CW; o += kSAThreads) {
+        const int cxl = o % CW, cyl = (o / CW) % CH, k = o / (CW * CH);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < kSATY; ++r) {
+            const float w = (row_l[r][0] == cyl ? 1.f - row_t[r] : 0.f) + (row_l[r][1] == cyl ? row_t[r] : 0.f);
+            acc += tmp[(k * kSATY + r) * CW + cxl] * w;
+        }
+        const int yy = cy0 + cyl, xx = cx0 + cxl;
+        if (acc != 0.f && yy < Hp && xx < Wp) atomicAdd(gc + ((long)k * Hp + yy) * Wp + xx, acc);
     }
 }
 
@@ -380,7 +397,7 @@ int drc_upsample_softargmin_bwd(const float* cost, const float* grad_disp, float
     if (!cost || !grad_disp || !grad_cost) return -1;           // grad_cost is zero-filled by the caller
     const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
     const int CH = (int)(sy * (kSATY - 1)) + 3, CW = (int)(sx * (kSATX - 1)) + 3;    // coarse cells an 8 x 16 tile can touch (+ rounding slack)
-    const size_t lds = ((size_t)2 * Dp * kSAThreads + (size_t)Dp * CH * CW) * 4;
+    const size_t lds = ((size_t)2 * Dp * kSAThreads + (size_t)Dp * kSATY * CW) * 4;
     if (lds > 64 * 1024) return -2;
     const long blocks = (long)N * ((H + kSATY - 1) / kSATY) * ((W + kSATX - 1) / kSATX);
     hipLaunchKernelGGL(upsample_softargmin_bwd_kernel, dim3((unsigned)blocks), dim3(kSAThreads), lds, (hipStream_t)stream,
