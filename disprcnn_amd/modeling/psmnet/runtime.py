@@ -15,6 +15,18 @@ from .submodule import SPP_BRANCHES, TRUNK_STAGES
 WS_MAX_PLANS = 48        # launch-plan sets kept per runtime (one per exact unit count; they hold views, not memory)
 
 
+_UNIT_AFFINE = {}
+
+
+def _unit_affine(n, device):
+    """(ones[n], zeros[n]) on `device`, shared by every site that needs them (read-only)."""
+    key = (n, device)
+    v = _UNIT_AFFINE.get(key)
+    if v is None:
+        v = _UNIT_AFFINE[key] = (torch.ones(n, dtype=torch.float32, device=device), torch.zeros(n, dtype=torch.float32, device=device))
+    return v
+
+
 class _Conv:
     """Packed weights + folded BN of one conv(+bn) site."""
 
@@ -36,17 +48,23 @@ class _Conv:
         cout_pad = E.cout_pad_of(self.cout)
         self.cout_pad, self.device = cout_pad, device
         self.bn = bn
-        self.unit_scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
-        self.zero_shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+        # constant vectors are shared per (length, device); the BatchNorm affine is read straight from the module's parameters when no
+        # channel padding is needed (every layer of PSMNet): a train step re-builds these objects after each optimizer step, and six
+        # tiny fill / copy launches per conv were ~700 launches (3 ms of GPU time, 10 ms of host time) per Config-B step
+        self.unit_scale, self.zero_shift = _unit_affine(cout_pad, device)
         if bn is not None:
-            self.gamma = torch.zeros(cout_pad, dtype=torch.float32, device=device)
-            self.beta = torch.zeros(cout_pad, dtype=torch.float32, device=device)
-            self.gamma[: self.cout] = bn.weight.detach().to(device).float()
-            self.beta[: self.cout] = bn.bias.detach().to(device).float()
+            direct = (cout_pad == self.cout and bn.weight.device == device and bn.weight.dtype == torch.float32 and bn.weight.is_contiguous()
+                      and bn.bias.device == device and bn.bias.dtype == torch.float32 and bn.bias.is_contiguous())
+            if direct:
+                self.gamma, self.beta = bn.weight.detach(), bn.bias.detach()
+            else:
+                self.gamma = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+                self.beta = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+                self.gamma[: self.cout] = bn.weight.detach().to(device).float()
+                self.beta[: self.cout] = bn.bias.detach().to(device).float()
             self.scale = self.shift = None          # eval-mode fold: computed on demand (refold), it depends on the running statistics
         else:
-            self.scale = torch.ones(cout_pad, dtype=torch.float32, device=device)
-            self.shift = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+            self.scale, self.shift = self.unit_scale, self.zero_shift
 
     def w16_for(self, plan):
         """The LDS-free packing `plan` reads: t16, or the Winograd-transformed weights (built on first use)."""
