@@ -100,8 +100,8 @@ def headline(total_rois, elapsed, args, world, N, roofline, cpu, extra):
         "metric": "ROI cost-volumes/sec (112x112x48)", "value": round(total_rois / elapsed, 1), "unit": "ROI cost-volumes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Config A: per ROI pair, features [32,28,28]x2 -> concat cost volume [64,12,28,28] -> "
-                               "3D stacked-hourglass regressor -> trilinear x4 + softmax + soft-argmin -> disparity [112,112]",
+        "config": {"workload": "Config A: per ROI pair, features [32,28,28]x2 -> concat cost volume [64,12,28,28] (folded into the first "
+                               "3D layer's loads, never written) -> 3D stacked-hourglass regressor -> trilinear x4 + softmax + soft-argmin -> disparity [112,112]",
                    "rois_per_step_per_gpu": N, "maxdisp": 48, "mindisp": 0, "parallelism": f"roi-shard x{world} (no collective)",
                    "weights": "closed-form synthetic (disprcnn_amd.utils.synth), BN stats calibrated fixture"},
         "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
