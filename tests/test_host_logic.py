@@ -213,3 +213,14 @@ def test_reference_init_statistics():
             assert torch.equal(mod.weight, torch.ones_like(mod.weight)) and torch.equal(mod.bias, torch.zeros_like(mod.bias)), name
             checked["bn"] += 1
     assert checked["deconv"] == 6 and checked["conv"] > 60 and checked["bn"] > 60, checked
+
+
+def test_graphed_step_needs_the_gpu():
+    """utils/graph.GraphedStep replays HIP graphs: without a GPU it raises instead of silently running the step eagerly."""
+    import pytest
+    import torch
+    from disprcnn_amd.utils.graph import GraphedStep
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        GraphedStep(lambda: torch.zeros(1))
