@@ -27,6 +27,8 @@ __device__ __forceinline__ float iou_plus1(const float* a, const float* b) {
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thresh, int strict, uint64_t* __restrict__ mask) {
     const int rb = blockIdx.y, cb = blockIdx.x;
     const int col_blocks = gridDim.x;
+    boxes += (int64_t)blockIdx.z * n * 4;                  // batched launch: box set blockIdx.z
+    mask += (int64_t)blockIdx.z * n * col_blocks;
     __shared__ float cbox[64 * 4];
     const int cn = min(n - cb * 64, 64), rn = min(n - rb * 64, 64);
     if ((int)threadIdx.x < cn) {
@@ -56,6 +58,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 // one dependent global load per kept row -- 1.27 ms for the Stereo RPN's 6,000 boxes, 27 % of the 2D stage.)
 __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks, uint8_t* __restrict__ keep) {
     constexpr int kMaxWords = 8;                           // up to 64*64*8 = 32768 boxes
+    mask += (int64_t)blockIdx.x * n * col_blocks;          // batched launch: one wavefront per box set
+    keep += (int64_t)blockIdx.x * n;
     uint64_t remv[kMaxWords];
 #pragma unroll
     for (int w = 0; w < kMaxWords; ++w) remv[w] = 0;
@@ -115,14 +119,19 @@ __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict
 
 }  // namespace
 
-extern "C" int drc_nms_sorted_fwd(const float* boxes_sorted, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream) {
-    if (n < 0) return -2;
-    if (n == 0) return 0;
+extern "C" int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep,
+                                        void* stream) {
+    if (n < 0 || sets < 0 || sets > 65535) return -2;
+    if (n == 0 || sets == 0) return 0;
     if (!boxes_sorted || !mask_ws || !keep) return -1;
     const int col_blocks = (n + 63) / 64;
     if (col_blocks > 64 * 8) return -5;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, s, boxes_sorted, n, thresh, strict, mask_ws);
-    hipLaunchKernelGGL(nms_walk_kernel, dim3(1), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, sets), dim3(64), 0, s, boxes_sorted, n, thresh, strict, mask_ws);
+    hipLaunchKernelGGL(nms_walk_kernel, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
     return (int)hipGetLastError();
+}
+
+extern "C" int drc_nms_sorted_fwd(const float* boxes_sorted, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream) {
+    return drc_nms_sorted_batch_fwd(boxes_sorted, 1, n, thresh, strict, mask_ws, keep, stream);
 }

@@ -3,7 +3,7 @@ double_view_boxlist_nms (left and right views suppressed separately, the kept se
 NMS itself runs in libdisprcnn_hip.so (layers/nms.py); index bookkeeping is torch plumbing."""
 import torch
 
-from ..layers import nms as _box_nms
+from ..layers import nms as _box_nms, nms_pair as _box_nms_pair
 from .bounding_box import BoxList
 
 
@@ -27,12 +27,13 @@ def double_view_boxlist_nms(left_boxlist, right_boxlist, nms_thresh, max_proposa
         raise ValueError(use_keep)
     if nms_thresh <= 0:
         return left_boxlist, right_boxlist
-    keep = None
-    if use_keep in ("joint", "left"):
+    if use_keep == "joint":       # both views share their scores, hence their order: one sort and one launch pair for the two
+        kl, kr = _box_nms_pair(left_boxlist.bbox, right_boxlist.bbox, left_boxlist.get_field(score_field), nms_thresh)
+        keep = intersect_sorted(kl, kr)
+    elif use_keep == "left":
         keep = _box_nms(left_boxlist.bbox, left_boxlist.get_field(score_field), nms_thresh)
-    if use_keep in ("joint", "right"):
-        kr = _box_nms(right_boxlist.bbox, right_boxlist.get_field(score_field), nms_thresh)
-        keep = kr if keep is None else intersect_sorted(keep, kr)
+    else:
+        keep = _box_nms(right_boxlist.bbox, right_boxlist.get_field(score_field), nms_thresh)
     if max_proposals > 0:
         keep = keep[:max_proposals]
     return left_boxlist[keep], right_boxlist[keep]

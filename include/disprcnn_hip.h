@@ -289,6 +289,9 @@ int drc_cost_volume16_blocked_fwd(const float* left, const float* right, void* c
  * op's test) or >= thresh (strict = 0, the CPU op's).  mask_ws: n * ceil(n/64) uint64 of scratch; keep [n] u8 out (1 = kept).
  * n <= 32768.  The greedy walk runs on the device (the reference copies the mask to the host). */
 int drc_nms_sorted_fwd(const float* boxes_sorted, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream);
+/* The same for `sets` box sets of n boxes each in one launch pair (boxes_sorted [sets][n][4], mask_ws [sets][n*ceil(n/64)], keep [sets][n]):
+ * the two views of double_view_boxlist_nms (reference structures/boxlist_ops.py:49-79) share their scores, hence their order. */
+int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream);
 
 /* f4. Box arithmetic of the 2D detection stage (det_ops.hip).
  * drc_box_decode_fwd -- BoxCoder.decode (reference modeling/box_coder.py:161-244): codes [rows][groups][per_group], per_group = 4

@@ -44,3 +44,17 @@ def test_nms_edge_cases(dev):
     assert np.array_equal(nms(dets.to(dev), scores.to(dev), 0.4).cpu().numpy(), ref) and 0 < len(ref) < n
     with pytest.raises(RuntimeError):
         nms(torch.zeros(3, 4), torch.zeros(3), 0.5)                                   # CPU tensors: no fallback
+
+
+def test_nms_pair_equals_two_calls():
+    """nms_pair (one sort + one launch pair for the two views of a stereo list) == two nms calls on the same scores."""
+    from disprcnn_amd.layers import nms, nms_pair
+    from tests.golden.make_golden_nms import proposals
+    dev = torch.device("cuda:0")
+    for tag, n in (("pa", 700), ("pb", 65), ("pc", 1), ("pd", 0)):
+        a, s = proposals(tag, n) if n else (torch.zeros(0, 4), torch.zeros(0))
+        b = a.clone()
+        if n:
+            b[:, [0, 2]] -= 17.0 + 40.0 * s[:, None]
+        ka, kb = nms_pair(a.to(dev), b.to(dev), s.to(dev), 0.7)
+        assert torch.equal(ka, nms(a.to(dev), s.to(dev), 0.7)) and torch.equal(kb, nms(b.to(dev), s.to(dev), 0.7))
