@@ -6,7 +6,9 @@
 set -u
 TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ONLY=${2:-}      # optional: collect just this workload
 run() {   # name, description, command...
+  if [ -n "$ONLY" ] && [ "$ONLY" != "$1" ]; then return; fi
   local name=$1 desc=$2; shift 2
   local OUT=gpurun_out/prof_${TAG}_$name
   mkdir -p "$OUT"
@@ -21,5 +23,6 @@ run configB "WHAT=psm python tools/prof_pair.py  (Config B: full PSMNet on 16 RO
 run pair_backbone "WHAT=bb python tools/prof_pair.py  (R-50-FPN trunk on one stereo pair 2x3x375x1242 = 250.3 GFLOP; 2 warm-up + 5 timed passes)" env WHAT=bb python tools/prof_pair.py
 run train "N=64 python tools/prof_train.py  (Config A train step from the feature boundary, 64 ROI pairs: fwd + PSMLoss + bwd; 2 + 3 steps, then 3 forward-only passes)" env N=64 python tools/prof_train.py
 run trainB "N=8 CFG_B=1 python tools/prof_train.py  (Config B train step, full PSMNet on 8 crops 224x224, D=96: fwd + PSMLoss + bwd; 2 + 3 steps)" env N=8 CFG_B=1 python tools/prof_train.py
+run stage2d "python tools/prof_2d.py  (2D stage: DispRCNN = R-50-FPN trunk + Stereo RPN + stereo box head + mask head on one 2x3x375x1242 pair, synthetic weights; 2 warm-up + 5 timed passes)" python tools/prof_2d.py
 run stress16 "WHAT=psm16 python tools/prof_pair.py  (configs[3]: 64 ROI crops 224x224, D=96, fp16-storage regressor)" env WHAT=psm16 python tools/prof_pair.py
 ls profiles/ | grep "$TAG"
