@@ -59,6 +59,11 @@ class DrcWgradParams(C.Structure):
 
 
 WGRAD_SCRATCH_FLOATS = (1024 + 3 * 64) * 49 * 256      # DRC_WGRAD_SCRATCH_FLOATS
+LOSS_SCRATCH_FLOATS = 1024 * 8                          # DRC_LOSS_SCRATCH_FLOATS
+
+
+def cout1_wgrad_scratch_floats(cb_in):                  # DRC_COUT1_WGRAD_SCRATCH_FLOATS
+    return 1024 * cb_in * 27 * 16
 
 
 _P = C.c_void_p
@@ -112,12 +117,13 @@ _SIGS = {
     "drc_tapconv_wgrad": (_I, [C.POINTER(DrcWgradParams), _P]),
     "drc_bilinear_up_blocked_bwd": (_I, [_P, _P, _P, _P, _P]),
     "drc_avgpool2d_blocked_bwd": (_I, [_P, _P, _P, _P, _I, _P]),
-    "drc_upsample_softargmin_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_upsample_softargmin_bwd_scratch_floats": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
+    "drc_upsample_softargmin_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, C.c_int64, _P]),
     "drc_conv3d_cout1_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "drc_conv3d_cout1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "drc_conv3d_cout1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "drc_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "drc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P, _I, _P]),
-    "drc_psm_loss_sums": (_I, [_P, _P, _P, _P, _P, C.c_int64, _P, _P]),
+    "drc_psm_loss_sums": (_I, [_P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "drc_psm_loss_grad": (_I, [_P, _P, _P, C.c_int64, _P, C.c_float, _P, _P, _P]),
 }
 

@@ -34,15 +34,21 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    objs = []
+    objs, jobs = [], []
     for src in _sources():
         obj = src[:-4] + ".o"
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in [src] + _headers()):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        objs.append(obj)
+    if jobs:                                    # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            list(ex.map(run, jobs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

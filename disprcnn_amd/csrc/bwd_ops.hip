@@ -33,12 +33,14 @@ inline BlkGeom to_geom(const int* g) { return BlkGeom{g[0], g[1], g[2], g[3], g[
 // One thread per output pixel, one block per 8 x 16 pixel tile of an image: recompute the LDS column of bilinear-resampled
 // coarse slices, fold the D fine gradients back onto the coarse slices (lerp weights) -> gz[D'][pixel].  The pixels' D' values are
 // then gathered onto the tile's coarse footprint (a few cells x D') SEPARABLY and without atomics -- along x into tmp[D'][8 rows][CW],
-// along y into the footprint; bilinear weights come from per-row / per-column tables -- and the footprint is flushed with one global
-// atomicAdd per cell (neighbouring tiles share their border cells).  (Round 2, first form: 48 LDS atomicAdds per pixel onto ~24
-// cells per slice, ~20-way contended: 303 us per call at 64 ROIs.)
+// along y into the footprint; bilinear weights come from per-row / per-column tables.  Neighbouring tiles share their border cells,
+// so (round 3) the tile STORES its footprint [Dp][CH][CW] to scratch and softargmin_bwd_gather_kernel adds, per coarse cell, the
+// footprints of the tiles that contain it in tile order: no atomicAdd anywhere, the gradient is bit-reproducible run to run (it feeds
+// every upstream gradient, and through the BatchNorm statistics the ReLU masks).  (Round 2: one global atomicAdd per footprint cell;
+// before that 48 LDS atomicAdds per pixel onto ~24 cells per slice, ~20-way contended: 303 us per call at 64 ROIs.)
 constexpr int kSAThreads = 128, kSATX = 16, kSATY = 8;
 __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ gdisp,
-                                                                             float* __restrict__ gcost, int N, int Dp, int Hp, int Wp,
+                                                                             float* __restrict__ foot, int N, int Dp, int Hp, int Wp,
                                                                              int D, int H, int W, int mindisp, int CH, int CW) {
     extern __shared__ float sm[];                      // cz [Dp][T], gz [Dp][T], tmp [Dp][kSATY][CW]
     float* cz = sm;
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(con
         tmp[o] = acc;
     }
     __syncthreads();
-    // along y, and flush: one global atomicAdd per footprint cell
-    float* gc = gcost + (long)n * Dp * Hp * Wp;
+    // along y, and store the footprint (every cell, zeros included: the gather reads all of it)
+    float* fo = foot + (long)blockIdx.x * Dp * CH * CW;
     for (int o = threadIdx.x; o < Dp * CH * CW; o += kSAThreads) {
         const int cxl = o % CW, cyl = (o / CW) % CH, k = o / (CW * CH);
         float acc = 0.f;
@@ -128,8 +130,45 @@ __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_bwd_kernel(con
             const float w = (row_l[r][0] == cyl ? 1.f - row_t[r] : 0.f) + (row_l[r][1] == cyl ? row_t[r] : 0.f);
             acc += tmp[(k * kSATY + r) * CW + cxl] * w;
         }
-        const int yy = cy0 + cyl, xx = cx0 + cxl;
-        if (acc != 0.f && yy < Hp && xx < Wp) atomicAdd(gc + ((long)k * Hp + yy) * Wp + xx, acc);
+        fo[o] = acc;
+    }
+}
+
+// gcost[n][k][yy][xx] = sum over the tiles (by, bx) whose footprint [cy0, cy0+CH) x [cx0, cx0+CW) contains (yy, xx), by ascending then bx
+// ascending; cy0 / cx0 are recomputed with the tile kernel's own float expression.  thread = one coarse cell (all of it: overwrite).
+__global__ __launch_bounds__(kThreads) void softargmin_bwd_gather_kernel(const float* __restrict__ foot, float* __restrict__ gcost, int N, int Dp,
+                                                                         int Hp, int Wp, int H, int W, int CH, int CW) {
+    const int tiles_x = (W + kSATX - 1) / kSATX, tiles_y = (H + kSATY - 1) / kSATY;
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const long total = (long)N * Dp * Hp * Wp;
+    for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
+        long t = idx;
+        const int xx = (int)(t % Wp); t /= Wp;
+        const int yy = (int)(t % Hp); t /= Hp;
+        const int k = (int)(t % Dp);
+        const int n = (int)(t / Dp);
+        // candidate tile rows / columns: cy0(by) = (int)(sy * 8 by) is non-decreasing in by, so the tiles containing yy are a range
+        int by0 = 0, by1 = tiles_y - 1, bx0 = 0, bx1 = tiles_x - 1;
+        if (sy > 0.f) {
+            by0 = (int)((float)(yy - CH) / (sy * kSATY)) - 1; by1 = (int)((float)(yy + 1) / (sy * kSATY)) + 1;
+            by0 = by0 < 0 ? 0 : by0; by1 = by1 > tiles_y - 1 ? tiles_y - 1 : by1;
+        }
+        if (sx > 0.f) {
+            bx0 = (int)((float)(xx - CW) / (sx * kSATX)) - 1; bx1 = (int)((float)(xx + 1) / (sx * kSATX)) + 1;
+            bx0 = bx0 < 0 ? 0 : bx0; bx1 = bx1 > tiles_x - 1 ? tiles_x - 1 : bx1;
+        }
+        float acc = 0.f;
+        for (int by = by0; by <= by1; ++by) {
+            const int cyl = yy - (int)(sy * (by * kSATY));
+            if (cyl < 0 || cyl >= CH) continue;
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const int cxl = xx - (int)(sx * (bx * kSATX));
+                if (cxl < 0 || cxl >= CW) continue;
+                acc += foot[((((long)n * tiles_y + by) * tiles_x + bx) * Dp + k) * CH * CW + cyl * CW + cxl];
+            }
+        }
+        gcost[idx] = acc;
     }
 }
 
@@ -173,9 +212,10 @@ __global__ __launch_bounds__(kThreads) void cout1_bwd_data_kernel(const float* _
     }
 }
 
-// weight: gw[t][c] += sum_{n,v} x[n,c,v+t] * gy[n,v];  thread = (voxel, quad) strided, 27 float4 partials, block reduce
+// weight: gw[t][c] = sum_{n,v} x[n,c,v+t] * gy[n,v];  thread = (voxel, quad) strided, 27 float4 partials, block reduce; the block's
+// 27 x 16 sums go to part[block][cb][27][16] and cout1_bwd_weight_finish_kernel adds the blocks in order (no atomicAdd)
 __global__ __launch_bounds__(kThreads) void cout1_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                    float* __restrict__ gw, int N, int cb_in, int D, int H, int W) {
+                                                                    float* __restrict__ part, int N, int cb_in, int D, int H, int W) {
     const int cb = blockIdx.y;
     const int q = threadIdx.x & 3;
     const BlkGeom g{N, cb_in, D, H, W, 1, 1, 1, cb_in, 0};
@@ -217,10 +257,23 @@ __global__ __launch_bounds__(kThreads) void cout1_bwd_weight_kernel(const float*
             const int qq = threadIdx.x >> 2, k = threadIdx.x & 3;
             float v = 0.f;
             for (int i = 0; i < kThreads / 64; ++i) v += red[i][qq][k];
-            atomicAdd(gw + (t * cb_in + cb) * 16 + qq * 4 + k, v);
+            part[(((long)blockIdx.x * cb_in + cb) * 27 + t) * 16 + qq * 4 + k] = v;
         }
         __syncthreads();
     }
+}
+
+// gw[t][cb*16 + c] = sum_blocks part[block][cb][t][c]: one 64-lane wave per output, lane l takes blocks l, l+64, ... in order, fixed xor-tree
+__global__ __launch_bounds__(kThreads) void cout1_bwd_weight_finish_kernel(const float* __restrict__ part, int nblocks, int cb_in,
+                                                                           float* __restrict__ gw) {
+    const int o = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= 27 * cb_in * 16) return;
+    const int c = o & 15, cb = (o >> 4) % cb_in, t = (o >> 4) / cb_in;
+    float v = 0.f;
+    for (int i = lane; i < nblocks; i += 64) v += part[(((long)i * cb_in + cb) * 27 + t) * 16 + c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (lane == 0) gw[(t * cb_in + cb) * 16 + c] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm backward
@@ -389,19 +442,34 @@ __global__ __launch_bounds__(kThreads) void avgpool2d_bwd_kernel(const float* __
 
 extern "C" {
 
+static void softargmin_bwd_footprint(int Hp, int Wp, int H, int W, int* CH, int* CW) {
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    *CH = (int)(sy * (kSATY - 1)) + 3; *CW = (int)(sx * (kSATX - 1)) + 3;    // coarse cells an 8 x 16 tile can touch (+ rounding slack)
+}
+
+int64_t drc_upsample_softargmin_bwd_scratch_floats(int N, int Dp, int Hp, int Wp, int H, int W) {
+    if (N < 0 || Dp <= 0 || Hp <= 0 || Wp <= 0 || H <= 0 || W <= 0) return -2;
+    int CH, CW;
+    softargmin_bwd_footprint(Hp, Wp, H, W, &CH, &CW);
+    return (int64_t)N * ((H + kSATY - 1) / kSATY) * ((W + kSATX - 1) / kSATX) * Dp * CH * CW;
+}
+
 int drc_upsample_softargmin_bwd(const float* cost, const float* grad_disp, float* grad_cost, int N, int Dp, int Hp, int Wp, int D, int H,
-                                int W, int mindisp, void* stream) {
+                                int W, int mindisp, float* scratch, int64_t scratch_floats, void* stream) {
     if (N < 0 || Dp <= 0 || Hp <= 0 || Wp <= 0 || D <= 0 || H <= 0 || W <= 0 || Dp > 96) return -2;
     const long total = (long)N * H * W;
     if (total == 0) return 0;
-    if (!cost || !grad_disp || !grad_cost) return -1;           // grad_cost is zero-filled by the caller
-    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
-    const int CH = (int)(sy * (kSATY - 1)) + 3, CW = (int)(sx * (kSATX - 1)) + 3;    // coarse cells an 8 x 16 tile can touch (+ rounding slack)
+    if (!cost || !grad_disp || !grad_cost || !scratch) return -1;
+    int CH, CW;
+    softargmin_bwd_footprint(Hp, Wp, H, W, &CH, &CW);
     const size_t lds = ((size_t)2 * Dp * kSAThreads + (size_t)Dp * kSATY * CW) * 4;
     if (lds > 64 * 1024) return -2;
     const long blocks = (long)N * ((H + kSATY - 1) / kSATY) * ((W + kSATX - 1) / kSATX);
+    if (blocks >= (1L << 31) || scratch_floats < blocks * Dp * CH * CW) return -2;
     hipLaunchKernelGGL(upsample_softargmin_bwd_kernel, dim3((unsigned)blocks), dim3(kSAThreads), lds, (hipStream_t)stream,
-                       cost, grad_disp, grad_cost, N, Dp, Hp, Wp, D, H, W, mindisp, CH, CW);
+                       cost, grad_disp, scratch, N, Dp, Hp, Wp, D, H, W, mindisp, CH, CW);
+    hipLaunchKernelGGL(softargmin_bwd_gather_kernel, dim3(grid_for((long)N * Dp * Hp * Wp, 8192)), dim3(kThreads), 0, (hipStream_t)stream,
+                       scratch, grad_cost, N, Dp, Hp, Wp, H, W, CH, CW);
     return (int)hipGetLastError();
 }
 
@@ -417,15 +485,19 @@ int drc_conv3d_cout1_bwd_data(const float* grad_out, const float* w, float* grad
 }
 
 int drc_conv3d_cout1_bwd_weight(const float* x_blk, const float* grad_out, float* grad_w, int N, int cb_in, int D, int H, int W,
-                                void* stream) {
+                                float* scratch, void* stream) {
     if (N < 0 || cb_in <= 0 || D <= 0 || H <= 0 || W <= 0) return -2;
     const long nvox = (long)N * D * H * W;
-    if (nvox == 0) return 0;
-    if (!x_blk || !grad_out || !grad_w) return -1;              // grad_w [27][cb_in*16] is zero-filled by the caller
+    if (!grad_w) return -1;
+    if (nvox == 0) return (int)hipMemsetAsync(grad_w, 0, (size_t)27 * cb_in * 16 * sizeof(float), (hipStream_t)stream);
+    if (!x_blk || !grad_out || !scratch) return -1;
     long chunks = (nvox + 64 * 16 - 1) / (64 * 16);
-    if (chunks > 1024) chunks = 1024;
+    if (chunks > 1024) chunks = 1024;                           // DRC_COUT1_WGRAD_SCRATCH_FLOATS holds 1024 blocks of partials
     hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((unsigned)chunks, (unsigned)cb_in), dim3(kThreads), 0, (hipStream_t)stream, x_blk, grad_out,
-                       grad_w, N, cb_in, D, H, W);
+                       scratch, N, cb_in, D, H, W);
+    const int outs = 27 * cb_in * 16;
+    hipLaunchKernelGGL(cout1_bwd_weight_finish_kernel, dim3((unsigned)((outs + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0,
+                       (hipStream_t)stream, scratch, (int)chunks, cb_in, grad_w);
     return (int)hipGetLastError();
 }
 

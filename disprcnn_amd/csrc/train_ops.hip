@@ -1,7 +1,8 @@
 // train_ops.hip -- loss kernels of the disparity stage (gfx950).
 //   PSMLoss / EndPointErrorLoss: masked smooth-L1 (train, 3 heads, weights 0.5/0.7/1.0) and masked mean |err| (eval).
 //   Reference: utils/loss_utils.py:9-32 == utils/stereo_utils.py:185-208.
-// One pass over the heads: per-block shuffle/LDS reduction, one atomicAdd per block and quantity.
+// One pass over the heads: per-block shuffle/LDS reduction; every block stores its five partials and a one-block finishing
+// launch adds them in block order (no atomicAdd: the loss and everything downstream of it are bit-reproducible run to run).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,7 +25,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // sums[0..2] = sum_k mask*smooth_l1(pred_k - tgt), sums[3] = sum mask, sums[4] = sum mask*|pred_0 - tgt|
 __global__ __launch_bounds__(kThreads) void psm_loss_sums_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
                                                                  const float* __restrict__ p2, const float* __restrict__ tgt,
-                                                                 const uint8_t* __restrict__ mask, long n, float* __restrict__ sums) {
+                                                                 const uint8_t* __restrict__ mask, long n, float* __restrict__ part) {
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
         const float m = mask[i] ? 1.f : 0.f;
@@ -51,8 +52,20 @@ __global__ __launch_bounds__(kThreads) void psm_loss_sums_kernel(const float* __
     if (threadIdx.x < 5) {
         float v = 0.f;
         for (int i = 0; i < kThreads / 64; ++i) v += red[threadIdx.x][i];
-        atomicAdd(sums + threadIdx.x, v);
+        part[(long)blockIdx.x * 8 + threadIdx.x] = v;
     }
+}
+
+// sums[k] = sum over blocks (block order) of part[block][k]: 5 groups of 32 threads take blocks i = lane, lane + 32, ...
+// in order, then a fixed xor-tree over the 32 lanes of the group
+__global__ __launch_bounds__(kThreads) void psm_loss_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ sums) {
+    const int k = threadIdx.x >> 5, l = threadIdx.x & 31;
+    float v = 0.f;
+    if (k < 5)
+        for (int i = l; i < nblocks; i += 32) v += part[(long)i * 8 + k];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (k < 5 && l == 0) sums[k] = v;
 }
 
 // d loss / d pred_k = gscale * w_k * mask * clamp(pred_k - tgt, -1, 1) / msum   (msum==0 -> no division, as the reference)
@@ -79,13 +92,15 @@ inline unsigned grid_for(long work) {
 extern "C" {
 
 int drc_psm_loss_sums(const float* pred1, const float* pred2, const float* pred3, const float* target, const uint8_t* mask,
-                      int64_t numel, float* sums5, void* stream) {
+                      int64_t numel, float* sums5, float* scratch, void* stream) {
     if (numel < 0) return -2;
     if (!sums5) return -1;
-    if (numel == 0) return 0;           // sums5 must be zeroed by the caller; an empty batch leaves it at zero
-    if (!pred1 || !target || !mask) return -1;
-    hipLaunchKernelGGL(psm_loss_sums_kernel, dim3(grid_for(numel)), dim3(kThreads), 0, (hipStream_t)stream, pred1, pred2, pred3, target,
-                       mask, (long)numel, sums5);
+    if (numel == 0) return (int)hipMemsetAsync(sums5, 0, 5 * sizeof(float), (hipStream_t)stream);   // an empty batch: all sums are zero
+    if (!pred1 || !target || !mask || !scratch) return -1;
+    const unsigned blocks = grid_for(numel);            // <= 1024 = DRC_LOSS_SCRATCH_FLOATS / 8
+    hipLaunchKernelGGL(psm_loss_sums_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, pred1, pred2, pred3, target,
+                       mask, (long)numel, scratch);
+    hipLaunchKernelGGL(psm_loss_finish_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, scratch, (int)blocks, sums5);
     return (int)hipGetLastError();
 }
 

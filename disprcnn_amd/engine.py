@@ -840,6 +840,19 @@ def wgrad_scratch(dev):
     return buf
 
 
+_SCRATCH = {}
+
+
+def scratch(dev, tag, floats):
+    """Per-(device, stream, tag) float workspace for the fixed-order two-launch reductions (loss sums, classifier weight gradient,
+    soft-argmin adjoint footprints): grows to the largest request and is then reused, so a captured step keeps its pointers."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0, tag)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = _SCRATCH[key] = torch.empty(int(floats), dtype=torch.float32, device=dev)
+    return buf
+
+
 def bn_batch_stats(raw):
     """Per-channel batch mean and biased variance of a Blocked tensor's interior (one pass, Chan-combined, fixed order)."""
     dev = raw.device

@@ -213,12 +213,16 @@ class RegressorBackward:
         H, W_ = out_hw
         # heads: d loss / d cost_k (dense), cumulative: cost2 = classif2 + cost1, cost3 = classif3 + cost2
         gc = []
+        nfoot = lib.drc_upsample_softargmin_bwd_scratch_floats(N, Dp, Hp, Wp, H, W_)
         for k in range(3):
-            g = torch.zeros_like(costs[k])
             if gpreds[k] is not None:
+                g = torch.empty_like(costs[k])           # overwritten: tile footprints gathered in a fixed order (no atomics)
+                foot = E.scratch(dev, "softargmin_bwd", nfoot)
                 st = lib.drc_upsample_softargmin_bwd(E._ptr(costs[k]), E._ptr(gpreds[k].contiguous().float()), E._ptr(g), N, Dp, Hp, Wp,
-                                                     mx - mn, H, W_, mn, sp)
+                                                     mx - mn, H, W_, mn, E._ptr(foot), foot.numel(), sp)
                 _lib.check(st, "drc_upsample_softargmin_bwd")
+            else:
+                g = torch.zeros_like(costs[k])
             gc.append(g)
         gc[1] = gc[1] + gc[2]
         gc[0] = gc[0] + gc[1]
@@ -229,8 +233,9 @@ class RegressorBackward:
             st = lib.drc_conv3d_cout1_bwd_data(E._ptr(gc[k - 1]), E._ptr(w27), E._ptr(gx.storage), N, gx.cb, Dp, Hp, Wp, 0, sp)
             _lib.check(st, "drc_conv3d_cout1_bwd_data")
             G.have.add(name)
-            gw = torch.zeros_like(w27)
-            st = lib.drc_conv3d_cout1_bwd_weight(E._ptr(t[name].storage), E._ptr(gc[k - 1]), E._ptr(gw), N, gx.cb, Dp, Hp, Wp, sp)
+            gw = torch.empty_like(w27)                   # overwritten: per-block partials added in block order (no atomics)
+            st = lib.drc_conv3d_cout1_bwd_weight(E._ptr(t[name].storage), E._ptr(gc[k - 1]), E._ptr(gw), N, gx.cb, Dp, Hp, Wp,
+                                                 E._ptr(E.scratch(dev, "cout1_wgrad", _lib.cout1_wgrad_scratch_floats(gx.cb))), sp)
             _lib.check(st, "drc_conv3d_cout1_bwd_weight")
             conv = getattr(self.rt.model, f"classif{k}")[2]
             self._padd(conv.weight, gw[:, :32].t().reshape(conv.weight.shape))

@@ -15,14 +15,14 @@ _WEIGHTS = (0.5, 0.7, 1.0)
 def _sums(preds, target, mask):
     E.require_gpu(target, "PSMLoss target")
     dev = target.device
-    sums = torch.zeros(5, dtype=torch.float32, device=dev)
+    sums = torch.empty(5, dtype=torch.float32, device=dev)           # overwritten: per-block partials added in block order (no atomics)
     ps = [p.contiguous() for p in preds] + [None] * (3 - len(preds))
     for p in preds:
         E.require_gpu(p, "PSMLoss prediction")
         if p.shape != target.shape:
             raise ValueError(f"prediction {tuple(p.shape)} vs target {tuple(target.shape)}")
     st = _lib.lib().drc_psm_loss_sums(E._ptr(ps[0]), E._ptr(ps[1]), E._ptr(ps[2]), E._ptr(target), E._ptr(mask), target.numel(), E._ptr(sums),
-                                      E._stream_ptr(dev))
+                                      E._ptr(E.scratch(dev, "loss", _lib.LOSS_SCRATCH_FLOATS)), E._stream_ptr(dev))
     _lib.check(st, "drc_psm_loss_sums")
     return sums
 

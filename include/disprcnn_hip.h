@@ -339,12 +339,14 @@ int drc_roi_depth_maps_fwd(const float* disp, int S, const int32_t* boxes, const
 
 /* ---------------------------------------------------------------------------------------
  * a10. PSMLoss / EndPointErrorLoss (utils/loss_utils.py:9-32, utils/stereo_utils.py:185-208).
- *   sums5 (caller-zeroed) += { sum m*smoothl1(p1-t), sum m*smoothl1(p2-t), sum m*smoothl1(p3-t), sum m, sum m*|p1-t| }
- *   (pred2/pred3 may be NULL for the eval form).  The scalar loss is assembled by the caller:
+ *   sums5 = { sum m*smoothl1(p1-t), sum m*smoothl1(p2-t), sum m*smoothl1(p3-t), sum m, sum m*|p1-t| }   (overwritten)
+ *   (pred2/pred3 may be NULL for the eval form).  scratch: DRC_LOSS_SCRATCH_FLOATS floats of per-block partials, added in
+ *   block order by a finishing launch -- no atomics, bit-reproducible.  The scalar loss is assembled by the caller:
  *   train: 0.5*s0/s3 + 0.7*s1/s3 + s2/s3 (division skipped when s3 == 0); eval: s4/s3 (0 when s3 == 0).
  *   grad:  grad_pred = grad_scale[0] * weight * m * clamp(pred - t, -1, 1) / s3 */
+#define DRC_LOSS_SCRATCH_FLOATS ((size_t)1024 * 8)
 int drc_psm_loss_sums(const float* pred1, const float* pred2, const float* pred3, const float* target, const uint8_t* mask,
-                      int64_t numel, float* sums5, void* stream);
+                      int64_t numel, float* sums5, float* scratch, void* stream);
 int drc_psm_loss_grad(const float* pred, const float* target, const uint8_t* mask, int64_t numel, const float* sums5, float weight,
                       const float* grad_scale, float* grad_pred, void* stream);
 
@@ -374,17 +376,22 @@ int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int*
  * Backward kernels (autograd of stackhourglass.py:130-174 in the reference).  Data gradients of the MFMA convolutions
  * reuse drc_tapconv_fwd / drc_tapconv3d_slide_fwd / drc_deconv3d_k3s2_fwd with transformed weights
  * (disprcnn_amd/modeling/psmnet/train.py).
- *   drc_upsample_softargmin_bwd : grad_cost [N,Dp,Hp,Wp] (caller-zeroed) += d disp / d cost * grad_disp [N,H,W]
+ *   drc_upsample_softargmin_bwd : grad_cost [N,Dp,Hp,Wp] = d disp / d cost * grad_disp [N,H,W]  (overwritten).  scratch:
+ *        drc_upsample_softargmin_bwd_scratch_floats(...) floats -- every 8 x 16 pixel tile stores the gradient of its coarse
+ *        footprint there and a second launch gathers, per coarse cell, the tiles that touch it in tile order (no atomics)
  *   drc_conv3d_cout1_bwd_data   : grad of the 32->1 classifier conv w.r.t. its blocked input (assign or accumulate)
- *   drc_conv3d_cout1_bwd_weight : grad_w [27][cb_in*16] (caller-zeroed) += sum x * grad_out
+ *   drc_conv3d_cout1_bwd_weight : grad_w [27][cb_in*16] = sum x * grad_out  (overwritten).  scratch:
+ *        DRC_COUT1_WGRAD_SCRATCH_FLOATS(cb_in) floats of per-block partials, added in block order by a second launch
  *   drc_bn_bwd_reduce / _apply  : training-mode BatchNorm backward with the ReLU mask and the residual fan-out fused:
  *        dz = dy*[y>0];  sums = {sum dz, sum dz*xhat};  draw = gamma*invstd*(dz - sums0/M - xhat*sums1/M);  dres (=|+=) dz */
+int64_t drc_upsample_softargmin_bwd_scratch_floats(int N, int Dp, int Hp, int Wp, int H, int W);
 int drc_upsample_softargmin_bwd(const float* cost, const float* grad_disp, float* grad_cost, int N, int Dp, int Hp, int Wp, int D, int H,
-                                int W, int mindisp, void* stream);
+                                int W, int mindisp, float* scratch, int64_t scratch_floats, void* stream);
 int drc_conv3d_cout1_bwd_data(const float* grad_out, const float* w, float* grad_x_blk, int N, int cb_in, int D, int H, int W,
                               int accumulate, void* stream);
+#define DRC_COUT1_WGRAD_SCRATCH_FLOATS(cb_in) ((size_t)1024 * (cb_in) * 27 * 16)
 int drc_conv3d_cout1_bwd_weight(const float* x_blk, const float* grad_out, float* grad_w, int N, int cb_in, int D, int H, int W,
-                                void* stream);
+                                float* scratch, void* stream);
 int drc_bn_bwd_reduce(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,
                       const float* mean, const float* invstd, int relu, float* sums, float* scratch /* as drc_bn_stats_blocked */, void* stream);
 int drc_bn_bwd_apply(const float* dy, const int* geom_dy, const float* y, const int* geom_y, const float* raw, const int* geom_raw,

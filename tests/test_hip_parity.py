@@ -409,8 +409,10 @@ def test_upsample_softargmin_sharp_costs(dev):
     from disprcnn_amd import _lib, engine as E
     c = cost[:, 0].contiguous().to(dev)
     gd = synth.hash_uniform("sharp:g", (2, 4 * hp, 4 * wp), -1.0, 1.0).to(dev)
-    g = torch.zeros_like(c)
-    st = _lib.lib().drc_upsample_softargmin_bwd(E._ptr(c), E._ptr(gd), E._ptr(g), 2, dp, hp, wp, mx - mn, 4 * hp, 4 * wp, mn, E._stream_ptr(dev))
+    g = torch.full_like(c, float("nan"))                       # overwritten by the gather launch
+    foot = E.scratch(dev, "softargmin_bwd", _lib.lib().drc_upsample_softargmin_bwd_scratch_floats(2, dp, hp, wp, 4 * hp, 4 * wp))
+    st = _lib.lib().drc_upsample_softargmin_bwd(E._ptr(c), E._ptr(gd), E._ptr(g), 2, dp, hp, wp, mx - mn, 4 * hp, 4 * wp, mn, E._ptr(foot),
+                                                foot.numel(), E._stream_ptr(dev))
     _lib.check(st, "drc_upsample_softargmin_bwd")
     assert torch.isfinite(g).all()
     cr = cost.double().requires_grad_()

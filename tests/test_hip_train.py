@@ -392,10 +392,11 @@ def test_upsample_softargmin_backward_vs_oracle_autograd(dev, shape):
     c64 = cost.double().requires_grad_(True)
     pred = O.upsample_softargmin(c64.unsqueeze(1), mn + ndisp, mn, H, W)
     (pred * gd.double()).sum().backward()
-    g = torch.zeros(n, dp, hp, wp, device=dev)
+    g = torch.full((n, dp, hp, wp), float("nan"), device=dev)   # overwritten by the gather launch
     cost_d, gd_d = cost.to(dev), gd.to(dev)                      # keep the device tensors alive across the launch
+    foot = E.scratch(dev, "softargmin_bwd", _lib.lib().drc_upsample_softargmin_bwd_scratch_floats(n, dp, hp, wp, H, W))
     st = _lib.lib().drc_upsample_softargmin_bwd(E._ptr(cost_d), E._ptr(gd_d), E._ptr(g), n, dp, hp, wp, ndisp, H, W, mn,
-                                                E._stream_ptr(dev))
+                                                E._ptr(foot), foot.numel(), E._stream_ptr(dev))
     _lib.check(st, "drc_upsample_softargmin_bwd")
     ref = c64.grad
     assert (g.cpu().double() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-7
