@@ -1,0 +1,526 @@
+// wino3d_rb.hip -- stride-1 3x3x3 convolution (+BN, +residual, +ReLU) as Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores,
+// TWO waves per SIMD, input staged per BLOCK as depth- and w-transformed ROWS ("row brick") in LDS (gfx950 / CDNA4, round 3).
+//
+//   reference: dres0/dres1, classifN[0], hourglass conv2 (stackhourglass.py:63-88, :14-20)
+//
+// wino3d.hip (rounds 1-2) gives every lane its tile's 4x4x4 patch: 32 float4 global loads per step into 128 landing registers,
+// every input voxel fetched ~8x per CU (5-9x from L2), 450 registers -> ONE wave per SIMD, so every barrier, operand read and
+// phase end is exposed (MFMA busy 39 %).  Here
+//   * a block of 8 waves (2 per SIMD, <= 256 registers each) owns 64 consecutive tiles: waves (tg, ct) -- tile group tg of 16
+//     tiles (the N dimension of the 16x16x4 MFMA) x cout tile ct of 16 couts; the two waves of a SIMD share their tile group;
+//   * per step (depth frequency xd, channel block cb) the block stages the input ROWS its tiles touch ONCE: work item
+//     (row slot, tile column wt, channel quad g) loads the row's four columns 2wt..2wt+3 of the two slices of xd (8 float4),
+//     applies the depth butterfly (slice a +/- slice b) and the w butterfly and writes the four w-frequencies to LDS --
+//     rows are shared by the two tile rows that overlap them, so these two butterflies run once per ROW instead of once
+//     per tile (2x and 4x fewer), and each input voxel is loaded ~2.3x per CU instead of 8x;
+//   * a wave reads its tiles' four transformed rows from LDS (12 + 4 ds_read_b128 per step), applies the h butterfly (64 VALU)
+//     and runs 64 MFMAs against the transformed weights, which the block shares through a two-slab LDS ring filled by LDS-DMA
+//     (no registers) half a step ahead;
+//   * the partial depth inverses are two running sums in registers (no LDS parking).
+// The arithmetic and its order are exactly wino3d.hip's: results are BIT-IDENTICAL to drc_conv3d_k3_wino_fwd.
+// LDS: ring 2 x 16 KB + brick 2 x NS slots x (256 * TW) B; NS = 16 for 28x28 maps (144 KB), 28 for 14x14 maps (130 KB).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define RB_WAVES 8
+#define RB_RING_BYTES 32768
+#ifdef RB_ABL_NOBARRIER
+#define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+
+#ifdef RB_TRACE
+// development only: s_memtime stamps of block RB_TRACE_BLOCK, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps
+__device__ unsigned long long rb_trace_buf[2][64][16];
+#define RB_MARK(k)                                                                                              \
+    do {                                                                                                        \
+        if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && stepno >= 8 && stepno < 72)                      \
+            rb_trace_buf[wave >> 2][stepno - 8][k] = __builtin_readcyclecounter();                              \
+    } while (0)
+extern "C" int drc_rb_trace_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_trace_buf), sizeof(rb_trace_buf));
+}
+#else
+#define RB_MARK(k)
+#endif
+
+namespace {
+
+template <int TW>
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_tapconv_params p, int NS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SB = 256 * TW;                   // bytes per row slot: [xw 4][g 4][wt TW] float4
+    constexpr int XWS = 64 * TW;                   // bytes per w-frequency plane of a slot
+    constexpr int GS = 16 * TW;                    // bytes per channel quad
+    char* const ring = smem;                       // [slab 2][unit = i * 2 + ct_local : 16][g 4][j 16] float4
+    char* const brick = smem + RB_RING_BYTES;      // [buffer 2][NS][SB]
+    const unsigned buf_bytes = (unsigned)NS * SB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int g = lane >> 4;
+    const int tg = wave & 3;                       // tile group of the chunk
+    const int ctl = wave >> 2;                     // cout tile within the block's 32 couts (waves w and w+4 share a SIMD)
+
+    const drc_tap_class cls = p.cls[0];
+    const int TD = p.OD >> 1, TH = p.OH >> 1;
+    const int tiles = p.N * TD * TH * TW;
+    const int rows_total = p.N * TD * TH;
+    const int chunks = (tiles + 63) >> 6;
+    const int n_cg = p.cout_pad / 32;
+    int cg, pos;
+    const int nbk = (int)gridDim.x / n_cg;          // blocks per cout group (positions are numbered XCD by XCD, see wino3d.hip)
+    if (gridDim.x % (8 * n_cg) == 0) {
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        cg = l % n_cg;
+        pos = xcd * (nbk / 8) + l / n_cg;
+    } else {
+        cg = blockIdx.x % n_cg;
+        pos = blockIdx.x / n_cg;
+    }
+    const int rounds = (chunks + nbk - 1) / nbk;
+    const int n_ct = p.cout_pad / 16;
+    const int ct0 = cg * 2;
+
+    auto slice_a = [](int xd) { return xd == 0 ? 0 : (xd == 2 ? 2 : 1); };      // depth butterfly of frequency xd: slice a + sgn * slice b
+    auto slice_b = [](int xd) { return xd == 2 ? 1 : (xd == 3 ? 3 : 2); };      // (d0-d2, d1+d2, d2-d1, d1-d3)
+
+    // ---- geometry of a round.  Lane: its tile, the LDS offset of its rows inside a brick buffer.  Thread: its (at most two)
+    // staging items (row slot, tile column, channel quad): global byte offset of the row's first column, LDS byte offset.
+    struct Geo { int n, dt, ht, wt; bool valid; unsigned lds; };
+    auto geo_of = [&](int round) __attribute__((always_inline)) {
+        Geo q;
+        const int chunk = round * nbk + pos;
+        const int t0 = chunk * 64 < tiles ? chunk * 64 : tiles - 1;
+        int tile = chunk * 64 + tg * 16 + j;
+        q.valid = tile < tiles;
+        if (tile >= tiles) tile = tiles - 1;
+        const int R0 = t0 / TW, R = tile / TW;
+        q.wt = tile - R * TW;
+        int t = R;
+        q.ht = t % TH; t /= TH;
+        q.dt = t % TD;
+        q.n = t / TD;
+        int slot = 2 * (R - R0) + 2 * (R / TH - R0 / TH);
+        slot = slot > NS - 4 ? NS - 4 : slot;
+        q.lds = (unsigned)(slot * SB + g * GS + q.wt * 16);
+        return q;
+    };
+    // A staging item = (row slot, tile column wt, channel quad gq), thread t takes items t and t + 512: it loads the row's columns
+    // 2wt..2wt+3 in the two slices of the step (8 float4; lanes of a quad group share a 64-byte line), applies the depth butterfly and the
+    // w butterfly and writes the four w-frequencies of tile column wt to LDS.  (Tried and dropped, s_memtime-traced on the GPU: items of
+    // one column PAIR with the neighbour's pair fetched by ds_bpermute / DPP -- half the loads, the same time; loads issued a half step
+    // ahead or right before the barriers -- the wait is the LDS-DMA ring fill, not the loads; L2-warming touches -- slower: every extra
+    // vector-memory instruction costs its issue slot behind the other seven waves' requests.)
+    struct Item { unsigned goff, loff; bool valid; };
+    auto item_of = [&](int round, int k) __attribute__((always_inline)) {
+        Item it;
+        const int chunk = round * nbk + pos;
+        const int t0 = chunk * 64 < tiles ? chunk * 64 : tiles - 1;
+        const int t1 = chunk * 64 + 63 < tiles ? chunk * 64 + 63 : tiles - 1;
+        const int R0 = t0 / TW, R1 = t1 / TW;
+        int nslots = 2 * (R1 - R0) + 2 * (R1 / TH - R0 / TH) + 4;
+        nslots = nslots > NS ? NS : nslots;
+        const int q = (int)threadIdx.x + 512 * k;
+        it.valid = q < nslots * TW * 4;
+        const int s0 = q / (4 * TW), rem = q - s0 * (4 * TW);
+        const int wt = rem >> 2, gq = rem & 3;
+        // slot -> (tile row relative to R0, patch row h): two slots per tile row plus two per slab touched
+        int s = s0 < nslots ? s0 : nslots - 1;
+        int left = TH - R0 % TH, base = 0, rel = 0, h = 0;
+        for (;;) {
+            const int span = 2 * left + 2;
+            if (s < span) {
+                int rr = s >> 1;
+                rr = rr > left - 1 ? left - 1 : rr;
+                rel = base + rr;
+                h = s - 2 * rr;
+                break;
+            }
+            s -= span; base += left; left = TH;
+        }
+        int R = R0 + rel;
+        R = R > rows_total - 1 ? rows_total - 1 : R;
+        int t = R;
+        const int ht = t % TH; t /= TH;
+        const int dt = t % TD;
+        const int n = t / TD;
+        it.goff = (unsigned)((n * p.x_n_stride + (int64_t)(2 * dt + cls.dd0) * p.x_d_stride + (int64_t)(2 * ht + h + cls.dh0) * p.x_h_stride +
+                              (int64_t)(2 * wt + cls.dw0) * 16 + gq * 4) * 4);
+        it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + wt * 16);
+        return it;
+    };
+    struct Raw { f32x4 a[4], b[4]; };
+    // (all uniform offsets are 32-bit: the launcher checks N * x_n_stride * 4 < 2^32 and the packed weights < 2^31 floats)
+    const unsigned xcb4 = (unsigned)p.x_cb_stride * 4u, xd4 = (unsigned)p.x_d_stride * 4u;
+    auto stage_issue = [&](const Item& it, int xd, int cb, Raw& r) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOSTAGE
+        return;
+#endif
+        if (!it.valid) return;
+        const char* sa = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_a(xd) * xd4);
+        const char* sb = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_b(xd) * xd4);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
+            r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
+        }
+    };
+    // depth butterfly, w butterfly, four w-frequencies into brick buffer `bb`
+    auto stage_finish = [&](const Item& it, int xd, char* bb, const Raw& r) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOSTAGE
+        return;
+#endif
+        if (!it.valid) return;
+        const float sgn = xd == 1 ? 1.f : -1.f;
+        f32x4 d[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            d[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); d[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
+            d[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); d[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
+        }
+        char* dst = bb + it.loff;
+        *(f32x4*)(dst + 0 * XWS) = d[0] - d[2];
+        *(f32x4*)(dst + 1 * XWS) = d[1] + d[2];
+        *(f32x4*)(dst + 2 * XWS) = d[2] - d[1];
+        *(f32x4*)(dst + 3 * XWS) = d[1] - d[3];
+    };
+
+    // ---- weight ring: half step (xd, cb, hf) uses frequency points xd*16 + hf*8 + 0..7 of block cb for the block's two cout
+    // tiles = 16 units of 1 KiB [g][j] float4 in the rb packing (drc_pack_weights_wino_rb); wave w copies units w and w + 8 by
+    // LDS-DMA (lane l -> byte l*16 of the unit)
+    // unit u = wave + 8k: frequency point i = u >> 1 (k = 1: + 4), cout tile u & 1; the per-wave part of the source offset is constant
+    const char* const wlane = (const char*)(p.w + (int64_t)ct0 * 256 + lane * 4) + (unsigned)(((wave >> 1) * p.cb_in * n_ct + (wave & 1)) * 1024);
+    const unsigned wxi4 = (unsigned)(p.cb_in * n_ct) * 1024u;         // bytes per frequency point
+    const unsigned wcb4 = (unsigned)n_ct * 1024u;                     // bytes per channel block
+    auto ring_fill = [&](int slab, int xd, int cb, int hf) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOFILL
+        return;
+#endif
+        const char* src = wlane + ((unsigned)(xd * 16 + hf * 8) * wxi4 + (unsigned)cb * wcb4);
+        char* dst = ring + slab * 16384 + wave * 1024;
+        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src), RB_LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src + 4 * wxi4), RB_LDS_PTR(dst + 8192), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+    f32x4 o0[4], o1[4];                            // running depth sums of the in-plane inverses: [oh * 2 + ow]
+#define RB_MFMA_ROW(XH, WF, V)                                                                        \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
+        _Pragma("unroll") for (int xw = 0; xw < 4; ++xw) {                                            \
+            const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                   \
+            acc[XH][xw] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[xw][s], V[xw][s], FIRST && s == 0 ? z4_ : acc[XH][xw], 0, 0, 0); \
+        }
+    // the MFMAs of one half step: frequency rows xh = 2*HALF, 2*HALF+1; tb = the lane's rows in the step's brick buffer,
+    // rs = the half step's ring slab + the wave's cout tile + lane
+    auto consume = [&](auto first_tag, auto half_tag, const char* tb, const char* rs) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int HALF = decltype(half_tag)::value;
+        f32x4 wf0[4], wf1[4], ta[4], tb_[4], tc[4], v0[4], v1[4];
+#ifdef RB_ABL_NOLDSR
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) {
+            const f32x4 c_ = {(float)lane, (float)(lane + xw), 1.f, 2.f};
+            wf0[xw] = c_; wf1[xw] = c_ * 2.f; ta[xw] = c_ * 3.f; tb_[xw] = c_ * 4.f; tc[xw] = c_ * 5.f;
+            asm volatile("" : "+v"(wf0[xw]), "+v"(wf1[xw]), "+v"(ta[xw]), "+v"(tb_[xw]), "+v"(tc[xw]));
+        }
+        if (false)
+#endif
+        {
+        // first row's operands: weights of frequency row 2*HALF, the two transformed rows its h butterfly combines
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) wf0[xw] = *(const f32x4*)(rs + (0 * 4 + xw) * 2048);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) ta[xw] = *(const f32x4*)(tb + (HALF == 0 ? 0 : 1) * SB + xw * XWS);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb + 2 * SB + xw * XWS);
+        }
+        if constexpr (HALF == 0) {                 // xh 0: t0 - t2      (ta = t0, tb_ = t2)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) v0[xw] = ta[xw] - tb_[xw];
+        } else {                                   // xh 2: t2 - t1      (ta = t1, tb_ = t2)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) v0[xw] = tb_[xw] - ta[xw];
+        }
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) asm volatile("" : "+v"(v0[xw]));
+#ifdef RB_ABL_NOLDSR
+        if (false)
+#endif
+        {
+        // second row's operands, requested before the first row's MFMAs so that they arrive in their shadow
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) tc[xw] = *(const f32x4*)(tb + (HALF == 0 ? 1 : 3) * SB + xw * XWS);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) wf1[xw] = *(const f32x4*)(rs + (1 * 4 + xw) * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef RB_ABL_NOMFMA
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) acc[2 * HALF][xw] += wf0[xw] * v0[xw];
+#else
+        RB_MFMA_ROW(2 * HALF, wf0, v0)
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF == 0) {                 // xh 1: t1 + t2      (tc = t1)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) v1[xw] = tc[xw] + tb_[xw];
+        } else {                                   // xh 3: t1 - t3      (tc = t3)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) v1[xw] = ta[xw] - tc[xw];
+        }
+#ifdef RB_ABL_NOMFMA
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) acc[2 * HALF + 1][xw] += wf1[xw] * v1[xw];
+#else
+        RB_MFMA_ROW(2 * HALF + 1, wf1, v1)
+#endif
+    };
+
+    // end of a depth frequency: in-plane inverse (A^T . A, 4x4 -> 2x2), folded into the running depth sums (A^T columns
+    // [1 1 1 0] for od 0, [0 1 -1 -1] for od 1); the last frequency runs the epilogue
+    auto phase_end = [&](int xd_, const Geo& geo) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOPE
+        if (xd_ < 3) return;
+        if (geo.valid && lane == 0 && acc[0][0].x + acc[1][1].y + acc[2][2].z + acc[3][3].w == 1.2345e-30f) p.y[0] = 1.f;
+        return;
+#endif
+        f32x4 inv[4];
+        {
+            f32x4 hh[2][4];
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) {
+                hh[0][xw] = acc[0][xw] + acc[1][xw] + acc[2][xw];
+                hh[1][xw] = acc[1][xw] - acc[2][xw] - acc[3][xw];
+            }
+            inv[0] = hh[0][0] + hh[0][1] + hh[0][2]; inv[1] = hh[0][1] - hh[0][2] - hh[0][3];
+            inv[2] = hh[1][0] + hh[1][1] + hh[1][2]; inv[3] = hh[1][1] - hh[1][2] - hh[1][3];
+        }
+        if (xd_ == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o0[i] = inv[i];
+            return;
+        }
+        if (xd_ == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o0[i] += inv[i]; o1[i] = inv[i]; }
+            return;
+        }
+        if (xd_ == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o0[i] += inv[i]; o1[i] -= inv[i]; }
+            return;
+        }
+        if (!geo.valid) return;
+        const int ct = ct0 + ctl;
+        const f32x4 bn_sc = *(const f32x4*)(p.scale + ct * 16 + g * 4);
+        const f32x4 bn_sh = *(const f32x4*)(p.shift + ct * 16 + g * 4);
+        const int64_t yo = p.y_off0 + (int64_t)geo.n * p.y_n_stride + (int64_t)(2 * geo.dt) * p.y_d_stride + (int64_t)(2 * geo.ht) * p.y_h_stride +
+                           (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.y_cb_stride;
+        const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)(2 * geo.dt) * p.r_d_stride + (int64_t)(2 * geo.ht) * p.r_h_stride +
+                           (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.r_cb_stride;
+#pragma unroll
+        for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < 2; ++ow) {
+                const int i = oh * 2 + ow;
+#pragma unroll
+                for (int od = 0; od < 2; ++od) {
+                    f32x4 v_ = (od == 0 ? o0[i] : o1[i] - inv[i]) * bn_sc + bn_sh;
+                    if (p.res) v_ += *(const f32x4*)(p.res + ro + od * p.r_d_stride + oh * p.r_h_stride + ow * 16);
+                    if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
+                    *(f32x4*)(p.y + yo + od * p.y_d_stride + oh * p.y_h_stride + ow * 16) = v_;
+                }
+            }
+    };
+
+    struct Cursor { int round, xd, cb; };
+    auto advance = [&](Cursor c) __attribute__((always_inline)) {
+        if (++c.cb == p.cb_in) { c.cb = 0; if (++c.xd == 4) { c.xd = 0; ++c.round; } }
+        return c;
+    };
+
+    // ---- prologue: brick of step 0 into buffer 0, weights of half step 0 into slab 0
+    Cursor c0 = {0, 0, 0};
+    Geo geo = geo_of(0);
+    Item itA = item_of(0, 0), itB = item_of(0, 1);
+    ring_fill(0, 0, 0, 0);
+    {
+        Raw r;
+        stage_issue(itA, 0, 0, r); stage_finish(itA, 0, brick, r);
+        stage_issue(itB, 0, 0, r); stage_finish(itB, 0, brick, r);
+    }
+    RB_BARRIER();
+
+    const char* const rs_lane = ring + ctl * 1024 + lane * 16;
+    int stepno = 0;
+    // Step s = (xd, cb) of c0 runs the MFMAs of its brick (buffer s & 1) while the brick of step s+1 is built in the other buffer:
+    //   half 0: ring slab 1 <- weights of half 1 (LDS-DMA) | loads of item A of step s+1 issued | MFMAs of frequency rows 0, 1 |
+    //           item A transformed and written | barrier
+    //   half 1: ring slab 0 <- weights of step s+1's half 0 | loads of item B issued | MFMAs of rows 2, 3 | item B | phase end after
+    //           the last channel block | barrier
+    // Every wave runs the same straight-line sequence: accumulators merged from two control-flow paths cost a copy each, and waves that
+    // alternate roles (one staging while its SIMD partner multiplies) measured no faster.
+    auto do_step = [&](auto first_tag) __attribute__((always_inline)) {
+        const Cursor c1 = advance(c0);
+        const bool next_round = c1.round != c0.round;
+        if (next_round && c1.round < rounds) { itA = item_of(c1.round, 0); itB = item_of(c1.round, 1); }
+        const char* tb = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds;
+        char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
+        Raw r;
+        RB_MARK(0);
+        ring_fill(1, c0.xd, c0.cb, 1);
+        stage_issue(itA, c1.xd, c1.cb, r);
+        RB_MARK(1);
+        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane);
+        RB_MARK(2);
+        stage_finish(itA, c1.xd, nb, r);
+        RB_MARK(3);
+        RB_BARRIER();
+        RB_MARK(4);
+        ring_fill(0, c1.xd, c1.cb, 0);
+        stage_issue(itB, c1.xd, c1.cb, r);
+        RB_MARK(5);
+        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + 16384);
+        RB_MARK(6);
+        stage_finish(itB, c1.xd, nb, r);
+        RB_MARK(7);
+        if (c0.cb == p.cb_in - 1) {
+            phase_end(c0.xd, geo);
+            if (next_round && c1.round < rounds) geo = geo_of(c1.round);
+        }
+        RB_MARK(8);
+        RB_BARRIER();
+        RB_MARK(9);
+        c0 = c1;
+        ++stepno;
+    };
+#pragma unroll 1
+    for (int ph = 0; ph < rounds * 4; ++ph) {
+        do_step(std::true_type{});
+#pragma unroll 1
+        for (int c = 1; c < p.cb_in; ++c) do_step(std::false_type{});
+    }
+#undef RB_MFMA_ROW
+}
+
+// slots a 64-tile chunk can touch: two per tile row plus two per slab
+inline int rb_slots(int TW, int TH) {
+    const int rows_max = 63 / TW + 2;
+    int slabs_max = (rows_max - 2) / TH + 2;
+    if (slabs_max > rows_max) slabs_max = rows_max;
+    return 2 * rows_max + 2 * slabs_max;
+}
+
+template <int TW>
+int launch_rb(const drc_tapconv_params& p, hipStream_t stream) {
+    const int NS = rb_slots(TW, p.OH / 2);
+    const size_t lds = RB_RING_BYTES + (size_t)2 * NS * 256 * TW;
+    if (lds > 163840 || NS * TW * 4 > 1024) return -4;
+    static bool attr_set = false;                  // idempotent: racing first calls set the same value
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wino3d_rb_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long tiles = (long)p.N * (p.OD / 2) * (p.OH / 2) * TW;
+    const long chunks = (tiles + 63) / 64;
+    const int n_cg = p.cout_pad / 32;
+    long per_cg = 256 / n_cg;                      // one block (8 waves, up to 160 KB of LDS) per CU
+    if (per_cg > chunks) per_cg = chunks;
+    if (per_cg < 1) per_cg = 1;
+    hipLaunchKernelGGL((wino3d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
+    return (int)hipGetLastError();
+}
+
+// U = (G x G x G) g per (cout, cin) pair in the rb packing: [xi = (xd*4 + xh)*4 + xw][cb][cout tile][g = ch / 4][j = cout % 16][ch % 4]
+__global__ __launch_bounds__(256) void wino_weights_rb_kernel(const float* __restrict__ w, int cout, int cin, int transposed, int flip,
+                                                              float* __restrict__ out) {
+    const int cb_n = (cin + 15) / 16, cout_pad = (cout + 31) / 32 * 32;
+    const long pairs = (long)cb_n * cout_pad * 16;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < pairs; idx += (long)gridDim.x * 256) {
+        long t = idx;
+        const int s = (int)(t & 3); t >>= 2;
+        const int jj = (int)(t & 15); t >>= 4;
+        const int gq = (int)(t & 3); t >>= 2;
+        const int ctile = (int)(t % (cout_pad / 16));
+        const int cb = (int)(t / (cout_pad / 16));
+        const int co = ctile * 16 + jj, ci = cb * 16 + gq * 4 + s;
+        float a[3][3][3];
+        const bool live = co < cout && ci < cin;
+        const float* src = w + (transposed ? ((long)ci * cout + co) : ((long)co * cin + ci)) * 27;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) a[k / 9][(k / 3) % 3][k % 3] = live ? src[flip ? 26 - k : k] : 0.f;
+        float b[3][3][4], d[3][4][4];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float g0 = a[kd][kh][0], g1 = a[kd][kh][1], g2 = a[kd][kh][2];
+                b[kd][kh][0] = g0; b[kd][kh][1] = 0.5f * (g0 + g1 + g2); b[kd][kh][2] = 0.5f * (g0 - g1 + g2); b[kd][kh][3] = g2;
+            }
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) {
+                const float g0 = b[kd][0][xw], g1 = b[kd][1][xw], g2 = b[kd][2][xw];
+                d[kd][0][xw] = g0; d[kd][1][xw] = 0.5f * (g0 + g1 + g2); d[kd][2][xw] = 0.5f * (g0 - g1 + g2); d[kd][3][xw] = g2;
+            }
+#pragma unroll
+        for (int xh = 0; xh < 4; ++xh)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) {
+                const float g0 = d[0][xh][xw], g1 = d[1][xh][xw], g2 = d[2][xh][xw];
+                const float u[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
+#pragma unroll
+                for (int xd = 0; xd < 4; ++xd) out[(long)((xd * 4 + xh) * 4 + xw) * pairs + idx] = u[xd];
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int OW) {
+    if (cout_pad <= 0 || (cout_pad & 31) || OD <= 0 || OH <= 0 || OW <= 0 || ((OD | OH | OW) & 1)) return 0;
+    const int TW = OW / 2;
+    if (TW != 14 && TW != 7) return 0;
+    const int NS = rb_slots(TW, OH / 2);
+    return RB_RING_BYTES + (size_t)2 * NS * 256 * TW <= 163840 && NS * TW * 4 <= 1024;
+}
+
+extern "C" int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (p.cout_pad <= 0 || (p.cout_pad & 31) || p.cb_in <= 0) return -2;
+    const drc_tap_class& k = p.cls[0];
+    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 || k.sw != 1)
+        return -4;
+    if (!drc_conv3d_k3_wino_rb_supported(p.cout_pad, p.OD, p.OH, p.OW)) return -4;
+    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;             // 32-bit item offsets over the whole batch
+    if ((int64_t)p.N * p.OD * p.OH * p.OW / 8 >= (1LL << 31) - 64 || (int64_t)64 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
+    hipStream_t s = (hipStream_t)stream;
+    return p.OW == 28 ? launch_rb<14>(p, s) : launch_rb<7>(p, s);
+}
+
+extern "C" int drc_pack_weights_wino_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream) {
+    if (cout <= 0 || cin <= 0) return -2;
+    if (!w || !out) return -1;
+    const long pairs = (long)((cin + 15) / 16) * ((cout + 31) / 32 * 32) * 16;
+    long blocks = (pairs + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wino_weights_rb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transposed, flip, out);
+    return (int)hipGetLastError();
+}

@@ -250,6 +250,21 @@ def pack_weight_wino(w, transposed=False, flip=False):
     return out
 
 
+def pack_weight_wino_rb(w, transposed=False, flip=False):
+    """The same transformed weights in the packing of wino3d_rb.hip: [64][cb_in][cout tile][ch / 4][cout % 16][ch % 4] (cout padded
+    to 32) -- a (frequency point, channel block, cout tile) unit is the 1 KiB an LDS-DMA instruction copies in lane order."""
+    w = w.detach().contiguous().float()
+    require_gpu(w, "pack_weight_wino_rb")
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError("pack_weight_wino_rb expects a 3x3x3 kernel")
+    a, b = w.shape[:2]
+    cout, cin = (b, a) if transposed else (a, b)
+    out = torch.empty(64, (cin + CB - 1) // CB, (cout + 31) // 32 * 32, 16, dtype=torch.float32, device=w.device)
+    st = _lib.lib().drc_pack_weights_wino_rb(_ptr(w), cout, cin, int(transposed), int(flip), _ptr(out), _stream_ptr(w.device))
+    _lib.check(st, "drc_pack_weights_wino_rb")
+    return out
+
+
 def pack_weight_wino2d(w, transposed=False, flip=False):
     """3x3 weights [Cout,Cin,3,3] (or [Cin,Cout,3,3] with transposed; flip reverses the taps) -> Winograd F(2,3)^2 transformed
     [16 frequency points][cb_in][cout_pad][16] (drc_pack_weights_wino2d): the packing of wino2d.hip."""
@@ -410,6 +425,7 @@ class ConvPlan:
         self.tap2d = False
         self.direct = False
         self.wino = False
+        self.rb = False            # wino3d_rb.hip (two waves per SIMD, row brick) instead of wino3d.hip
         self.c2d = False
         self.deconv_direct = False
         OD, OH, OW = grid_dhw
@@ -465,8 +481,19 @@ class ConvPlan:
         """True when this plan's kernel reads the [tap][cb][cout][16] packing (the LDS-free kernels) instead of the tap layout."""
         return bool(self.direct and (self.slide or self.down or self.c2d or self.deconv_direct))
 
-    def pack16(self, w, transposed=False, flip=False):
+    @property
+    def pack_kind(self):
+        """Name of the weight packing pack16 returns (a layer may run under plans of several kinds: one packing is kept per kind)."""
+        if self.wino:
+            return "wino2d" if self.c2d else ("wino_rb" if self.rb else "wino")
+        return "deconv_direct" if self.deconv_direct else ("t16" if self.needs_t16 else "tap")
+
+    def pack16(self, w, transposed=False, flip=False, kind=None):
         """The weight packing this plan's LDS-free kernel reads (None when the plan runs an LDS-staged kernel)."""
+        if kind == "wino":
+            return pack_weight_wino(w, transposed, flip)
+        if self.wino and self.rb and not self.c2d:
+            return pack_weight_wino_rb(w, transposed, flip)
         if self.wino:
             return pack_weight_wino2d(w, transposed, flip) if self.c2d else pack_weight_wino(w, transposed, flip)
         if self.deconv_direct:
@@ -512,6 +539,9 @@ class ConvPlan:
         elif self.direct and self.down:
             st = _lib.lib().drc_conv3d_k3s2_direct_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_direct_fwd")
+        elif self.wino and self.rb:
+            st = _lib.lib().drc_conv3d_k3_wino_rb_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_conv3d_k3_wino_rb_fwd")
         elif self.wino:
             st = _lib.lib().drc_conv3d_k3_wino_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3_wino_fwd")
@@ -564,7 +594,7 @@ class ConvPlan:
         if left.N < p.N or right.N < r_first + p.N:
             raise ValueError("run_costvol: fewer feature maps than volume units")
         if w16 is None or w16.shape[0] != 64:
-            raise ValueError("run_costvol: pass w16 = plan.pack16(weight)")
+            raise ValueError("run_costvol: pass w16 = plan.pack16(weight, kind='wino')")
         cv = _lib.DrcCostvolSrc()
         cv.left = _base_ptr(left)
         cv.right = _base_ptr(right) + 4 * r_first * right.n_stride
@@ -583,12 +613,14 @@ class ConvPlan:
         _lib.check(st, "drc_conv3d_k3_wino_costvol_fwd")
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            TIMING.append((self.kname.replace("wino3d_kernel", "wino3d_cv_kernel"), self.flops, e0, e1))
+            TIMING.append(("wino3d_cv_kernel<%d>" % self.slide_ct, self.flops, e0, e1))
 
 
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
 WINO = {"enabled": True,      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
-        "fuse_costvol": True} # eval: dres0[0] reads the feature maps directly, the cost volume is never written (wino3d_cv_kernel)
+        "fuse_costvol": True, # eval: dres0[0] reads the feature maps directly, the cost volume is never written (wino3d_cv_kernel)
+        "rb": True,           # 28- and 14-wide maps: the two-waves-per-SIMD row-brick kernel (wino3d_rb.hip) ...
+        "rb_min_chunks": 256} # ... when every CU gets at least one (64-tile chunk, 32-cout group) unit
 WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
@@ -629,6 +661,11 @@ def plan_conv3d(x, y, stride, cout, relu):
         if WINO["enabled"] and not (y.D | y.H | y.W) & 1 and x.N * x.n_stride * 4 < 2 ** 32:
             pl.wino = True
             pl.kname = "wino3d_kernel<%d>" % pl.slide_ct
+            chunks = x.N * (y.D // 2) * (y.H // 2) * (y.W // 2) // 64
+            if (WINO.get("rb") and chunks * (pl.p.cout_pad // 32) >= WINO["rb_min_chunks"]
+                    and _lib.lib().drc_conv3d_k3_wino_rb_supported(pl.p.cout_pad, y.D, y.H, y.W)):
+                pl.rb = True
+                pl.kname = "wino3d_rb_kernel<%d>" % (y.W // 2)
     elif (not pl.slide and stride == 1 and SLIDE["enabled"] and DIRECT["enabled"] and getattr(pl, "slide_small_ok", False)
           and (y.D | y.H | y.W) & 1):
         # odd maps (no Winograd) at small batch: the direct kernel with one cout tile per wave

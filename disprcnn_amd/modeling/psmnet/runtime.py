@@ -66,13 +66,18 @@ class _Conv:
         else:
             self.scale, self.shift = self.unit_scale, self.zero_shift
 
-    def w16_for(self, plan):
-        """The LDS-free packing `plan` reads: t16, or the Winograd-transformed weights (built on first use)."""
-        if not (plan.wino or plan.deconv_direct):
+    def w16_for(self, plan, kind=None):
+        """The LDS-free packing `plan` reads: t16, or the Winograd-transformed weights (built on first use, one per packing kind:
+        the same layer runs under different plans at different batch sizes).  kind = "wino": the packing of the fused cost-volume
+        launch (wino3d_cv_kernel), whatever the plan's own kernel."""
+        if kind is None and not (plan.wino or plan.deconv_direct):
             return self.w16
-        if self._ww is None:       # Winograd-transformed / transposed-conv-ordered packings come from the plan that reads them
-            self._ww = plan.pack16(self.conv.weight.detach().to(device=self.device, dtype=torch.float32), self.transposed)
-        return self._ww
+        kind = kind or plan.pack_kind
+        if self._ww is None:
+            self._ww = {}
+        if kind not in self._ww:   # Winograd-transformed / transposed-conv-ordered packings come from the plan that reads them
+            self._ww[kind] = plan.pack16(self.conv.weight.detach().to(device=self.device, dtype=torch.float32), self.transposed, kind=kind)
+        return self._ww[kind]
 
     def refold(self):
         """Eval-mode BatchNorm folded into per-cout scale/shift from the module's current running statistics."""
@@ -299,7 +304,7 @@ class PSMNetRuntime:
 
         if cv is not None:
             c, pl = W["dres0.0"], p["dres0.0"]
-            pl.run_costvol(cv[0], cv[1], cv[2], c.w16_for(pl), c.scale, c.shift, t["d0a"])
+            pl.run_costvol(cv[0], cv[1], cv[2], c.w16_for(pl, kind="wino"), c.scale, c.shift, t["d0a"])
         else:
             run("dres0.0", "dres0.0", "cost", "d0a")
         run("dres0.2", "dres0.2", "d0a", "cost0a")

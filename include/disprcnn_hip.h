@@ -160,6 +160,14 @@ int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per
  * kernels' by fp32 rounding only (about twice the direct kernel's own error against fp64). */
 int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
+/* The same convolution (same parameter block, bit-identical results) with TWO waves per SIMD: a block of 8 waves owns 64 consecutive
+ * 2x2x2 tiles and stages, once per (depth frequency, channel block), the depth- and w-transformed input ROWS those tiles touch in LDS
+ * (wino3d_rb.hip); waves read their tiles' rows from there.  For 28- and 14-wide maps (drc_conv3d_k3_wino_rb_supported), cout_pad a
+ * multiple of 32; weights from drc_pack_weights_wino_rb: [64][ceil(Cin/16)][cout_pad/16][ch/4][cout%16][ch%4], cout padded to 32. */
+int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int OW);
+int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* p, void* stream);
+int drc_pack_weights_wino_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream);
+
 /* Source of a cost volume that is never materialised: the two channel-blocked, zero-haloed 2D feature maps of N ROI pairs /
  * image pairs.  Voxel (n, cb, y, x) of a side lives at side + n*n_stride + cb*cb_stride + (y+pad)*h_stride + (x+pad)*16 (floats);
  * the first voxel of every (n, cb) plane must be a (zero) halo voxel, i.e. pad >= 1. */

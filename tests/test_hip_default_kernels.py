@@ -34,7 +34,7 @@ def _model(dev, case, mx, mn):
 def _assert_bench_kernels(ws):
     p = ws["p"]
     for name in WINO_LAYERS:
-        assert p[name].wino and p[name].kname.startswith("wino3d_kernel"), (name, p[name].kname)
+        assert p[name].wino and p[name].kname.startswith(("wino3d_rb_kernel", "wino3d_kernel")), (name, p[name].kname)
     for k in (1, 2, 3):
         assert p[f"hg{k}.conv4"].direct and p[f"hg{k}.conv4"].slide and not p[f"hg{k}.conv4"].wino      # 3x7x7: odd dims -> tapdirect
         assert p[f"hg{k}.conv1"].kname.startswith("downdirect_kernel") and p[f"hg{k}.conv3"].kname.startswith("downdirect_kernel")
@@ -58,7 +58,7 @@ def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn):
     Dp = (mx - mn) // 4
     ws = m._rt._ws[("3d", N, Dp, 28, 28)]
     names = _assert_bench_kernels(ws)
-    assert names["hg1.conv1"] == "downdirect_kernel<7,4>" and names["dres0.0"] == "wino3d_kernel<2>", names
+    assert names["hg1.conv1"] == "downdirect_kernel<7,4>" and names["dres1.0"] == "wino3d_rb_kernel<14>" and names["hg1.conv2"] == "wino3d_rb_kernel<7>", names
     ref = torch.from_numpy(z[f"{case}_pred"])
     err = (pred.view(N // 2, 2, 112, 112) - ref[None]).abs()
     print(case, f"N={N} mean/max err px", err.mean().item(), err.max().item())

@@ -187,6 +187,56 @@ def test_conv3d_winograd_kernel_vs_oracle(dev, n, cin, cout, dims, with_res):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("n,cin,cout,dims,with_res,expect_rb", [
+    (3, 32, 32, (12, 28, 28), True, True),       # the 32 -> 32 layers of Config A (TW = 14): chunks that straddle tile rows, slabs and ROIs
+    (2, 64, 32, (4, 12, 28), False, True),       # TH = 6 != TW
+    (5, 64, 64, (6, 14, 14), True, True),        # hourglass conv2 at half resolution (TW = 7, two cout groups, four channel blocks)
+    (1, 32, 32, (2, 28, 28), False, True),       # fewer chunks than blocks, a partial last chunk
+    (4, 40, 64, (4, 6, 28), True, True),         # three channel blocks (one partial), TH = 3: a chunk spans three slabs
+    (7, 48, 32, (2, 2, 14), True, False),        # TH = 1: more row slots than the LDS holds -> the engine keeps wino3d.hip
+    (2, 32, 32, (4, 20, 20), True, False)])      # a width the row-brick kernel is not built for
+def test_conv3d_winograd_rowbrick_kernel(dev, n, cin, cout, dims, with_res, expect_rb):
+    """wino3d_rb.hip (round 3: two waves per SIMD, the input staged per block as depth- and w-transformed rows in LDS) against the direct
+    convolution (same tolerance as the other kernels) AND against wino3d.hip, whose arithmetic it repeats operation for operation:
+    bit-identical."""
+    from disprcnn_amd import ops, engine as E
+    x = synth.hash_uniform(f"RB{cin}{cout}{dims}:x", (n, cin) + dims)
+    w = synth.hash_uniform(f"RB{cin}{cout}:w", (cout, cin, 3, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("RB:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("RB:b", (cout,), -0.5, 0.5)
+    res = synth.hash_uniform(f"RB{cout}{dims}:r", (n, cout) + dims) if with_res else None
+    ref = F.conv3d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    ref = F.relu(ref + res) if with_res else ref
+    saved = (E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"], E.WINO["rb"], E.WINO["rb_min_chunks"])
+    E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = True, 2, 1, True
+    got = {}
+    try:
+        for rb in (True, False):
+            E.WINO["rb"], E.WINO["rb_min_chunks"] = rb, 0
+            xb = E.Blocked(n, cin, *dims, 1, 1, 1, dev)
+            plan = E.plan_conv3d(xb, E.Blocked(n, cout, *dims, 1, 1, 1, dev), 1, cout, True)
+            assert plan.wino and plan.rb == (rb and expect_rb), (plan.kname, rb)
+            got[rb] = ops.conv3d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, with_res, res.to(dev) if with_res else None)
+    finally:
+        E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"], E.WINO["rb"], E.WINO["rb_min_chunks"] = saved
+    _close(got[True], ref)
+    assert torch.equal(got[True], got[False]), (got[True] - got[False]).abs().max().item()
+
+
+def test_winograd_rowbrick_weight_packing(dev):
+    """drc_pack_weights_wino_rb = drc_pack_weights_wino re-ordered to [xi][cb][cout tile][ch / 4][cout % 16][ch % 4] (cout padded to 32)."""
+    from disprcnn_amd import engine as E
+    for cout, cin, transposed, flip in [(32, 32, False, False), (20, 40, False, False), (64, 16, True, True)]:
+        w = synth.hash_uniform(f"RBW{cout}{cin}", (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), -1, 1).to(dev)
+        a = E.pack_weight_wino(w, transposed, flip).cpu()                # [64][cb][cout_pad16][16]
+        b = E.pack_weight_wino_rb(w, transposed, flip).cpu()             # [64][cb][cout_pad32][16] in rb order
+        cb, cp16, cp32 = a.shape[1], a.shape[2], b.shape[2]
+        a32 = torch.zeros(64, cb, cp32, 16)
+        a32[:, :, :cp16] = a
+        want = a32.view(64, cb, cp32 // 16, 16, 4, 4).permute(0, 1, 2, 4, 3, 5).reshape(64, cb, cp32, 16)   # [ct][j][g][s] -> [ct][g][j][s]
+        assert torch.equal(b, want)
+
+
 @pytest.mark.parametrize("n,C,cout,D,H,W,lo4,pad", [(3, 32, 32, 12, 28, 28, 0, 1), (2, 32, 32, 6, 28, 28, -6, 1), (5, 16, 48, 8, 10, 30, 3, 2),
                                                      (1, 32, 32, 24, 56, 56, 0, 1), (2, 32, 32, 4, 6, 2, -1, 1), (19, 32, 32, 12, 28, 28, 0, 1)])
 def test_conv3d_winograd_fused_cost_volume(dev, n, C, cout, D, H, W, lo4, pad):

@@ -116,7 +116,8 @@ def test_stride1_conv3d_kernel_selection():
         return E.plan_conv3d(x, y, 1, c, True)
 
     pl = plan(256, 32, (12, 28, 28))
-    assert pl.wino and pl.direct and pl.kname == "wino3d_kernel<2>"
+    assert pl.wino and pl.rb and pl.direct and pl.kname == "wino3d_rb_kernel<14>"       # round 3: the two-waves-per-SIMD row-brick kernel
+    assert plan(12, 32, (12, 28, 28)).kname == "wino3d_kernel<2>"                      # fewer 64-tile chunks than CUs: wino3d.hip
     pl = plan(256, 64, (3, 7, 7))                       # conv4 of Config A: odd dims
     assert not pl.wino and pl.direct and pl.kname.startswith("tapdirect")
     saved = E.WINO["enabled"]

@@ -1,0 +1,24 @@
+#!/bin/bash
+# pmc_rb.sh: dynamic instruction mix and stall counters of the rb kernel on the 32->32 layer (development tool; run via gpurun)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_rb
+rm -rf $OUT; mkdir -p $OUT
+CMD="python tools/exp_rb_time.py"
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_THREAD_CYCLES_VALU"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT -o $tag -- $CMD > $OUT/$tag.log 2>&1
+done
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/pmc_rb/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:40]
+        if "wino3d" not in k: continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    for k, d in acc.items():
+        print(f.split("/")[-1][:30], k, {c: round(v) for c, v in d.items()})
+PY
