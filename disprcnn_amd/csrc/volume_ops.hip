@@ -428,6 +428,89 @@ __global__ __launch_bounds__(kSAThreads) void upsample_softargmin_kernel(const f
     disp[idx] = sde / se;
 }
 
+// The same head for the shapes the network produces (D = 4 D' fine disparities), round 3.  What the generic kernel above spends its time
+// on -- 4 D' scattered global loads per thread (one texture request per wave each), a float -> int conversion and two LDS reads per fine
+// sample and pass, expf -- is gone:
+//   * a block owns 256 consecutive pixels of ONE ROI; the <= 3 coarse rows they touch are copied to LDS with coalesced row loads and
+//     each thread builds its bilinear (y, x) column of D' coarse values in REGISTERS;
+//   * the disparity loop is unrolled with D', D as template constants, so the coarse indices and blend weights of a fine sample
+//     (k0 = (int)(sd * d), td = sd * d - k0: the generic kernel's float expressions, evaluated by the compiler) are immediates: a fine
+//     sample is a multiply and an FMA, kept in a register for the second pass;
+//   * exp(v - m) = 2^((v - m) * log2 e): one v_exp_f32;
+//   * blocks are numbered XCD by XCD (workgroup b runs on XCD b % 8), so the blocks of a ROI share one L2: the generic kernel had every
+//     XCD fetch every ROI's cost volume from HBM (rocprofv3: 308 MB fetched per launch for 38.5 MB of input at 1,024 ROIs).
+template <int DP, int D>
+__global__ __launch_bounds__(256) void upsample_softargmin_t_kernel(const float* __restrict__ cost, float* __restrict__ disp, int N, int Hp, int Wp,
+                                                                    int H, int W, int mindisp, int blocks_per_roi) {
+    extern __shared__ float rows[];                // [3 rows][DP][Wp]
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int n = b / blocks_per_roi;
+    const int pix0 = (b - n * blocks_per_roi) * 256;
+    const int HW = H * W;
+    const int pl = pix0 + 255 < HW ? pix0 + 255 : HW - 1;
+    const float sy = H > 1 ? (float)(Hp - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(Wp - 1) / (float)(W - 1) : 0.f;
+    const int cy0 = (int)(sy * (pix0 / W));                            // first coarse row the block touches
+    int cy1 = (int)(sy * (pl / W)) + 1;
+    cy1 = cy1 > Hp - 1 ? Hp - 1 : cy1;
+    const int nrows = cy1 - cy0 + 1;                                   // <= 3 (the launcher checks 256 pixels span < 2 coarse rows + 1)
+    const float* c = cost + (long)n * DP * Hp * Wp;
+    // a (row, slice) line of Wp floats per 32 (Wp <= 32) or 64 lanes: no integer division by a run-time value in the copy loop
+    const int lpr = Wp <= 32 ? 32 : 64, xl = (int)threadIdx.x & (lpr - 1);
+    for (int rk = (int)threadIdx.x / lpr; rk < nrows * DP; rk += 256 / lpr) {
+        const int r = rk / DP, k = rk - r * DP;
+        if (xl < Wp) rows[rk * Wp + xl] = c[((long)k * Hp + cy0 + r) * Wp + xl];
+    }
+    __syncthreads();
+    const int pix = pix0 + (int)threadIdx.x;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix - y * W;
+    const float fy = sy * y, fx = sx * x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hp - 1), x1 = x0 + (x0 < Wp - 1);
+    const float ty = fy - y0, tx = fx - x0;
+    const float* r0 = rows + (y0 - cy0) * DP * Wp;
+    const float* r1 = rows + (y1 - cy0) * DP * Wp;
+    float cz[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        const float a = r0[k * Wp + x0] * (1.f - tx) + r0[k * Wp + x1] * tx;
+        const float bb = r1[k * Wp + x0] * (1.f - tx) + r1[k * Wp + x1] * tx;
+        cz[k] = a * (1.f - ty) + bb * ty;
+    }
+    constexpr float sd = D > 1 ? (float)(DP - 1) / (float)(D - 1) : 0.f;
+    float v[D];
+    float m = -INFINITY;                           // the maximum over the FINE samples (see the generic kernel)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        constexpr float dummy = 0.f; (void)dummy;
+        const float fd = sd * (float)d;
+        const int k0 = (int)fd;
+        const int k1 = k0 + (k0 < DP - 1);
+        const float td = fd - (float)k0;
+        v[d] = cz[k0] * (1.f - td) + cz[k1] * td;
+        m = fmaxf(m, v[d]);
+    }
+    float se = 0.f, sde = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float e = __builtin_amdgcn_exp2f((v[d] - m) * 1.44269504088896340736f);
+        se += e;
+        sde = fmaf(e, (float)(mindisp + d), sde);
+    }
+    disp[(long)n * HW + pix] = sde / se;
+}
+
+template <int DP, int D>
+static int launch_softargmin_t(const float* cost, float* disp, int N, int Hp, int Wp, int H, int W, int mindisp, hipStream_t stream) {
+    const int bpr = (H * W + 255) / 256;
+    const long blocks = (long)N * bpr;
+    hipLaunchKernelGGL((upsample_softargmin_t_kernel<DP, D>), dim3((unsigned)blocks), dim3(256), (size_t)3 * DP * Wp * sizeof(float), stream, cost, disp, N,
+                       Hp, Wp, H, W, mindisp, bpr);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // SPP helpers on blocked 2D tensors (submodule.py:76-90, :120-135).
 // One wave per pooled output voxel: 16 window positions x 4 channel quads per step, shuffle-reduce.
@@ -669,6 +752,17 @@ int drc_upsample_softargmin_fwd(const float* cost, float* disp, int N, int Dp, i
     const long total = (long)N * H * W;
     if (total == 0) return 0;
     if (!cost || !disp) return -1;
+    // the network's shapes (D = 4 D'): the register-column kernel, when 256 consecutive pixels touch at most 3 coarse rows and those fit LDS
+    if (D == 4 * Dp && H > 1 && W >= 86 && Wp <= 64 && (long)N * ((H * W + 255) / 256) < (1L << 31) && (size_t)3 * Dp * Wp * 4 <= 64 * 1024) {
+        // 256 pixels span at most ceil(255 / W) + 1 <= 4 fine rows = a coarse extent of < 3 * sy + 1 < 2 rows + the bilinear neighbour
+        const float sy = (float)(Hp - 1) / (float)(H - 1);
+        if (sy * (float)((255 + W - 1) / W) < 1.f) {
+            hipStream_t s = (hipStream_t)stream;
+            if (Dp == 12) return launch_softargmin_t<12, 48>(cost, disp, N, Hp, Wp, H, W, mindisp, s);
+            if (Dp == 24) return launch_softargmin_t<24, 96>(cost, disp, N, Hp, Wp, H, W, mindisp, s);
+            if (Dp == 6) return launch_softargmin_t<6, 24>(cost, disp, N, Hp, Wp, H, W, mindisp, s);
+        }
+    }
     const unsigned blocks = (unsigned)((total + kSAThreads - 1) / kSAThreads);
     hipLaunchKernelGGL(upsample_softargmin_kernel, dim3(blocks), dim3(kSAThreads), (size_t)Dp * kSAThreads * 4, (hipStream_t)stream, cost, disp, N, Dp, Hp, Wp, D, H, W, mindisp);
     return done();
