@@ -36,7 +36,9 @@ __device__ __forceinline__ void walk_rows(const BlkGeom& g, F f) {
         while (y >= g.H) { y -= g.H; if (++d == g.D) { d = 0; ++n; } }
     };
     // four rows per trip: the calls sit back to back in straight-line code, so their loads are in flight together (one load per
-    // trip leaves a streaming reduction latency-bound); f is still called in row order
+    // trip leaves a streaming reduction latency-bound).  The call order is FIXED but not plain row order: a thread that owns several
+    // xq of a row (tpr > THREADS) visits rows 0..3 of the trip for its first xq, then rows 0..3 for the next one -- the streaming
+    // reductions built on this walker (bn_stats, bn_bwd_reduce) are deterministic and their goldens were recorded with this order
     for (; row + 3 * rpb < r1; row += 4 * rpb) {
         const int n0 = n, d0 = d, y0 = y; next();
         const int n1 = n, d1 = d, y1 = y; next();

@@ -117,6 +117,35 @@ __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict
     }
 }
 
+// The same walk for more than 32,768 boxes (a KITTI pyramid has ~120 k anchors per view when PRE_NMS_TOP_N_TEST is off; the reference's
+// host walk takes any n, csrc/cuda/nms.cu:99-124): the removed-words live in LDS (one per column block) instead of registers.
+__global__ __launch_bounds__(64) void nms_walk_big_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks, uint8_t* __restrict__ keep) {
+    extern __shared__ uint64_t remv_lds[];                 // [col_blocks]
+    mask += (int64_t)blockIdx.x * n * col_blocks;
+    keep += (int64_t)blockIdx.x * n;
+    const int lane = threadIdx.x;
+    for (int j = lane; j < col_blocks; j += 64) remv_lds[j] = 0;
+    for (int c = 0; c < col_blocks; ++c) {
+        const int row = c * 64 + lane;
+        const uint64_t diag = row < n ? mask[(int64_t)row * col_blocks + c] : 0ULL;
+        const int nr = n - c * 64 < 64 ? n - c * 64 : 64;
+        uint64_t cur = remv_lds[c];                        // one wavefront: its own earlier LDS writes are visible in program order
+        uint64_t kept = 0;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        for (int r = 0; r < nr; ++r) {
+            const uint64_t dr = ((uint64_t)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readlane(dlo, r);
+            const uint64_t k = ((cur >> r) & 1ULL) ^ 1ULL;
+            kept |= k << r;
+            cur |= dr & (0ULL - k);
+        }
+        if (lane < nr) keep[c * 64 + lane] = (uint8_t)((kept >> lane) & 1ULL);
+        for (uint64_t km = kept; km; km &= km - 1) {
+            const uint64_t* p = mask + (int64_t)(c * 64 + __builtin_ctzll(km)) * col_blocks;
+            for (int j = c + 1 + lane; j < col_blocks; j += 64) remv_lds[j] |= p[j];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep,
@@ -125,10 +154,13 @@ extern "C" int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int
     if (n == 0 || sets == 0) return 0;
     if (!boxes_sorted || !mask_ws || !keep) return -1;
     const int col_blocks = (n + 63) / 64;
-    if (col_blocks > 64 * 8) return -5;
+    if (col_blocks > 8192) return -5;                      // 524,288 boxes: the big walk's removed-words fill 64 KB of LDS (and the mask 34 GB)
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, sets), dim3(64), 0, s, boxes_sorted, n, thresh, strict, mask_ws);
-    hipLaunchKernelGGL(nms_walk_kernel, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    if (col_blocks <= 64 * 8)
+        hipLaunchKernelGGL(nms_walk_kernel, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    else
+        hipLaunchKernelGGL(nms_walk_big_kernel, dim3(sets), dim3(64), (size_t)col_blocks * 8, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
     return (int)hipGetLastError();
 }
 

@@ -56,6 +56,21 @@ class Blocked:
             self.storage = storage.narrow(0, 0, self.numel + SLACK_FLOATS)
         self.device = device
 
+    @classmethod
+    def geometry(cls, N, C_, D, H, W, pd, ph, pw, device):
+        """The shape / stride record of a blocked tensor WITHOUT storage: enough to plan a launch (plans take pointers per call)."""
+        g = cls.__new__(cls)
+        g.N, g.C, g.D, g.H, g.W, g.pd, g.ph, g.pw = N, C_, D, H, W, pd, ph, pw
+        g.cb = (C_ + CB - 1) // CB
+        g.Dp, g.Hp, g.Wp = D + 2 * pd, H + 2 * ph, W + 2 * pw
+        g.h_stride = g.Wp * CB
+        g.d_stride = g.Hp * g.h_stride
+        g.cb_stride = g.Dp * g.d_stride
+        g.n_stride = g.cb * g.cb_stride
+        g.numel = N * g.n_stride
+        g.storage, g.device = None, device
+        return g
+
     @property
     def interior_off(self):
         return self.pd * self.d_stride + self.ph * self.h_stride + self.pw * CB

@@ -3,7 +3,8 @@
 ``nms(dets[N,4] xyxy, scores[N], threshold) -> int64 indices of the kept boxes, ascending`` (the CUDA op sorts the kept original
 indices, csrc/cuda/nms.cu:126-130; the CPU op returns nonzero(), csrc/cpu/nms_cpu.cpp:64).  GPU only: the suppression bitmask
 and the greedy walk run in libdisprcnn_hip.so (drc_nms_sorted_fwd); torch supplies the score sort and the final compaction
-(whose data-dependent output length is the one host sync, as in the reference)."""
+(whose data-dependent output length is the one host sync, as in the reference).  Any n up to 524,288 boxes: up to 32,768 the walk keeps its
+removed-words in registers, beyond that in LDS; the suppression mask takes n * ceil(n / 64) * 8 bytes, like the reference's."""
 import torch
 
 from .. import _lib

@@ -10,15 +10,20 @@ from .. import engine as E
 
 class EngineConv2d:
     """y = act(conv2d(x, conv.weight) + conv.bias) on dense [N,C,H,W] tensors.  Packed weights are rebuilt when the parameters
-    change (version counters); plans and blocked workspaces are cached per input shape (a short LRU: FPN levels, ROI batches)."""
+    change (version counters).  Storage is owned ONCE per map geometry (h, w) -- a short LRU: FPN levels, ROI windows -- and sized for a
+    capacity bucket of the unit count (engine.bucket_units, like the PSMNet runtime's WorkspacePool): the mask head sees a different
+    detection count (0..100) on every image, and a workspace per exact count would allocate and zero-fill two blocked tensors per conv and
+    image (ADVICE r2).  A smaller count runs on prefix views of the same storage (units are outermost, the zero halo is never written);
+    launch plans (no memory) are cached per count."""
 
     MAX_SHAPES = 12
+    MAX_PLANS = 32
 
     def __init__(self, conv, relu):
         if conv.groups != 1 or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.dilation[0] != conv.dilation[1]:
             raise NotImplementedError("EngineConv2d: square stride / padding / dilation, groups = 1")
         self.conv, self.relu = conv, bool(relu)
-        self._ver, self._plans = None, OrderedDict()
+        self._ver, self._geo = None, OrderedDict()
         self._wp = self._sc = self._sh = None
 
     def _weights(self, dev):
@@ -33,9 +38,13 @@ class EngineConv2d:
             if c.bias is not None:
                 self._sh[: w.shape[0]] = c.bias.detach().to(device=dev, dtype=torch.float32)
             self._w32, self._ver = w, ver
-            for ent in self._plans.values():
-                ent["w16"] = None
+            for geo in self._geo.values():
+                geo["w16"] = {}
         return self._wp, self._sc, self._sh
+
+    def nbytes(self):
+        """HBM held by the cached workspaces (tests: flat over varying unit counts)."""
+        return sum(4 * (g["x"].storage.numel() + g["y"].storage.numel()) for g in self._geo.values())
 
     def __call__(self, x):
         E.require_gpu(x, "EngineConv2d")
@@ -44,28 +53,36 @@ class EngineConv2d:
         k, s, p, d = c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]
         cout = c.out_channels
         dev = x.device
+        oh, ow = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
         if n == 0:
-            oh, ow = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
             return x.new_zeros(0, cout, oh, ow)
         wp, sc, sh = self._weights(dev)
-        key = (n, h, w, dev)
-        ent = self._plans.get(key)
-        if ent is None:
-            halo = max(p, 1)
-            oh, ow = (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
-            xb = E.Blocked(n, cin, 1, h, w, 0, halo, halo, dev)
-            yb = E.Blocked(n, cout, 1, oh, ow, 0, 1, 1, dev)
-            ent = dict(x=xb, y=yb, plan=E.plan_conv2d(xb, yb, k, s, p, d, cout, self.relu), w16=None)
-            self._plans[key] = ent
-            while len(self._plans) > self.MAX_SHAPES:
-                self._plans.popitem(last=False)
+        key = (h, w, dev)
+        halo = max(p, 1)
+        geo = self._geo.get(key)
+        if geo is None or geo["cap"] < n:
+            cap = E.bucket_units(n)
+            geo = dict(cap=cap, x=E.Blocked(cap, cin, 1, h, w, 0, halo, halo, dev), y=E.Blocked(cap, cout, 1, oh, ow, 0, 1, 1, dev),
+                       plans=OrderedDict(), w16={})
+            self._geo[key] = geo
+            while len(self._geo) > self.MAX_SHAPES:
+                self._geo.popitem(last=False)
+        self._geo.move_to_end(key)
+        xb = E.Blocked(n, cin, 1, h, w, 0, halo, halo, dev, storage=geo["x"].storage)
+        yb = E.Blocked(n, cout, 1, oh, ow, 0, 1, 1, dev, storage=geo["y"].storage)
+        plan = geo["plans"].get(n)
+        if plan is None:
+            plan = geo["plans"][n] = E.plan_conv2d(xb, yb, k, s, p, d, cout, self.relu)
+            while len(geo["plans"]) > self.MAX_PLANS:
+                geo["plans"].popitem(last=False)
         else:
-            self._plans.move_to_end(key)
-        if ent["w16"] is None:
-            ent["w16"] = ent["plan"].pack16(self._w32)
-        ent["x"].from_dense(x.float())
-        ent["plan"].run(ent["x"], wp, sc, sh, ent["y"], None, w16=ent["w16"])
-        return ent["y"].to_dense()[:, :, 0]
+            geo["plans"].move_to_end(n)
+        kind = plan.pack_kind                          # plans of different counts may read different packings (Winograd vs direct)
+        if kind not in geo["w16"]:
+            geo["w16"][kind] = plan.pack16(self._w32)
+        xb.from_dense(x.float())
+        plan.run(xb, wp, sc, sh, yb, None, w16=geo["w16"][kind])
+        return yb.to_dense()[:, :, 0]
 
 
 def linear(x, layer, relu=False):

@@ -88,6 +88,21 @@ class _Conv:
                                                bn.running_var.detach().to(device).float(), bn.eps, self.cout_pad)
 
 
+class _LazyTensors(dict):
+    """Workspace tensors by name; entries of `lazy` are built (allocated) on first access."""
+
+    def __init__(self):
+        super().__init__()
+        self.lazy = {}
+
+    def __missing__(self, name):
+        v = self[name] = self.lazy.pop(name)()
+        return v
+
+    def get(self, name, default=None):
+        return self[name] if (name in self or name in self.lazy) else default
+
+
 class PSMNetRuntime:
     def __init__(self, model, device):
         self.model = model
@@ -260,12 +275,15 @@ class PSMNetRuntime:
         quart = tuple(-(-s // 2) for s in half)
         if tuple(2 * s for s in half) != full or tuple(2 * s for s in quart) != half:
             raise ValueError(f"cost-volume dims {full} must be divisible by 4 (D,H,W multiples of 16; SURVEY 8)")
-        t = {}
+        t = _LazyTensors()
 
         def B(name, c, d, h, w):
             t[name] = pool.blocked(name, N, c, d, h, w, 1, 1, 1)
 
-        B("cost", 64, *full)
+        # the 64-channel volume is the largest tensor of the stage and the fused eval path (wino3d_cv_kernel) never touches it: it is
+        # allocated (and zero-filled) on first use -- training, the non-fused path -- and planned from its geometry alone
+        t.lazy["cost"] = lambda: pool.blocked("cost", N, 64, *full, 1, 1, 1)
+        cost_geom = E.Blocked.geometry(N, 64, *full, 1, 1, 1, self.device)
         for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t1", "cls_t2", "cls_t3"):
             B(n, 32, *full)
         for k in (1, 2, 3):
@@ -274,7 +292,7 @@ class PSMNetRuntime:
         for k in (1, 2, 3):
             t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
         p = {}
-        p["dres0.0"] = E.plan_conv3d(t["cost"], t["d0a"], 1, 32, True)
+        p["dres0.0"] = E.plan_conv3d(cost_geom, t["d0a"], 1, 32, True)
         p["dres0.2"] = E.plan_conv3d(t["d0a"], t["cost0a"], 1, 32, True)
         p["dres1.0"] = E.plan_conv3d(t["cost0a"], t["d1a"], 1, 32, True)
         p["dres1.2"] = E.plan_conv3d(t["d1a"], t["cost0"], 1, 32, False)

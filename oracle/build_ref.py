@@ -25,6 +25,14 @@ REF_CSRC = "/root/reference/disprcnn/csrc"
 OUT = os.path.join(HERE, "_ref")
 NAME = "disprcnn_ref_cpu"
 
+# The three reference files that get compiled / included are pinned by content: anything else than the surveyed sources is refused
+# before a compiler or an import sees it (build() runs this from the driver's test process).
+SHA256 = {
+    "cpu/ROIAlign_cpu.cpp": "826804743beed9b01bea0b823939eeb96fd61a93fef9144c1fb2bb11c53f3e84",
+    "cpu/nms_cpu.cpp": "38d0949a259c5c86db73d7c46f9222f29bd252fc18cd0d6a12f09e0a233724c3",
+    "cpu/vision.h": "2f677f95be56f4a9621e75e9febb608b5a93462f75059838d7a8efd7a8164020",
+}
+
 PATCHES = {   # file -> [(line number, old token, new token)]
     "cpu/ROIAlign_cpu.cpp": [(242, "input.type()", "input.scalar_type()")],
     "cpu/nms_cpu.cpp": [(71, "dets.type()", "dets.scalar_type()")],
@@ -54,6 +62,11 @@ def build(force=False, verbose=False):
         return built_module_path()
     if built_module_path() and not force:
         return built_module_path()
+    import hashlib
+    for rel, want in SHA256.items():
+        got = hashlib.sha256(open(os.path.join(REF_CSRC, rel), "rb").read()).hexdigest()
+        if got != want:
+            raise RuntimeError(f"{rel}: sha256 {got} is not the surveyed reference file's ({want}); refusing to compile it")
     from torch.utils import cpp_extension
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="drc_ref_")

@@ -247,3 +247,24 @@ def test_full_pipeline_images_to_disparity_maps(dev):
     ref = O.psmnet_forward(state_for("B"), cl, cr, 48, -48)
     err = (ld.get_field("disparity").cpu() - ref).abs()
     assert err.mean().item() <= 2e-3 and err.max().item() <= 1e-1, (err.mean().item(), err.max().item())     # crops of ~8 px wide boxes
+
+
+def test_engine_conv2d_storage_flat_over_unit_counts(dev):
+    """The mask head's convolutions see a different detection count on every image: EngineConv2d owns its blocked workspaces
+    once per map geometry, sized for a capacity bucket, and runs smaller counts on prefix views -- results equal conv2d at every count,
+    and the cached storage stops growing once the largest count was seen."""
+    import torch.nn.functional as F
+    from disprcnn_amd.modeling.head_ops import EngineConv2d
+    conv = torch.nn.Conv2d(24, 40, 3, padding=1)
+    conv.weight.data = synth.hash_uniform("ec2d:w", (40, 24, 3, 3), -0.2, 0.2)
+    conv.bias.data = synth.hash_uniform("ec2d:b", (40,), -0.5, 0.5)
+    ec = EngineConv2d(conv.to(dev), relu=True)
+    sizes = []
+    for n in (100, 7, 63, 1, 100, 33, 96, 2):
+        x = synth.hash_uniform(f"ec2d:x{n}", (n, 24, 14, 14))
+        got = ec(x.to(dev)).cpu()
+        ref = F.relu(F.conv2d(x, conv.weight.cpu(), conv.bias.cpu(), padding=1))
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5, n
+        sizes.append(ec.nbytes())
+    assert len(set(sizes)) == 1, sizes                                   # one allocation, at the first (largest) count
+    assert tuple(ec(torch.zeros(0, 24, 14, 14, device=dev)).shape) == (0, 40, 14, 14)

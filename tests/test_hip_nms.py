@@ -46,6 +46,20 @@ def test_nms_edge_cases(dev):
         nms(torch.zeros(3, 4), torch.zeros(3), 0.5)                                   # CPU tensors: no fallback
 
 
+def test_nms_more_than_32768_boxes(dev):
+    """n > 32,768 (a KITTI pyramid's ~120 k anchors when PRE_NMS_TOP_N_TEST is off): the walk with its removed-words in LDS."""
+    from disprcnn_amd.layers import nms
+    n = 33_500
+    g = torch.Generator().manual_seed(7)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([300.0, 90.0])
+    wh = 8.0 + torch.rand(n, 2, generator=g) * torch.tensor([60.0, 40.0])
+    dets = torch.cat((xy, xy + wh), 1)
+    scores = torch.rand(n, generator=g)
+    ref = N.nms(dets.numpy(), scores.numpy(), 0.5, strict=True)
+    got = nms(dets.to(dev), scores.to(dev), 0.5).cpu().numpy()
+    assert 10 < len(ref) < n // 4 and np.array_equal(got, ref)
+
+
 def test_nms_pair_equals_two_calls():
     """nms_pair (one sort + one launch pair for the two views of a stereo list) == two nms calls on the same scores."""
     from disprcnn_amd.layers import nms, nms_pair
