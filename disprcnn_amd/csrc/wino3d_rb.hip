@@ -31,7 +31,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define RB_WAVES 8
+#ifdef RB_RING3
+#define RB_RING_BYTES 49152
+#else
 #define RB_RING_BYTES 32768
+#endif
 #ifdef RB_ABL_NOBARRIER
 #define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
@@ -39,6 +43,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 
+// a barrier that leaves the two newest vector-memory requests (a ring slab's LDS-DMA pieces, issued last) in flight
+#ifdef RB_ABL_NOBARRIER
+#define RB_BARRIER_KEEP2() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory")
+#else
+#define RB_BARRIER_KEEP2() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 #ifdef RB_TRACE
 // development only: s_memtime stamps of block RB_TRACE_BLOCK, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps
 __device__ unsigned long long rb_trace_buf[2][64][16];
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         }
     // the MFMAs of one half step: frequency rows xh = 2*HALF, 2*HALF+1; tb = the lane's rows in the step's brick buffer,
     // rs = the half step's ring slab + the wave's cout tile + lane
-    auto consume = [&](auto first_tag, auto half_tag, const char* tb, const char* rs) __attribute__((always_inline)) {
+    auto consume = [&](auto first_tag, auto half_tag, const char* tb, const char* rs, auto&& between) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int HALF = decltype(half_tag)::value;
         f32x4 wf0[4], wf1[4], ta[4], tb_[4], tc[4], v0[4], v1[4];
@@ -245,6 +255,9 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
 #pragma unroll
         for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb + 2 * SB + xw * XWS);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        between();                                 // the staging loads of this half step: issued while the LDS reads above are in flight
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF == 0) {                 // xh 0: t0 - t2      (ta = t0, tb_ = t2)
 #pragma unroll
             for (int xw = 0; xw < 4; ++xw) v0[xw] = ta[xw] - tb_[xw];
@@ -295,6 +308,22 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         if (geo.valid && lane == 0 && acc[0][0].x + acc[1][1].y + acc[2][2].z + acc[3][3].w == 1.2345e-30f) p.y[0] = 1.f;
         return;
 #endif
+        // the last frequency: the residual's eight float4 are requested first, so that they travel under the inverse transform
+        const bool last = xd_ == 3 && geo.valid;
+        const int ct = ct0 + ctl;
+        f32x4 rv[8];
+        int64_t yo = 0;
+        if (last) {
+            yo = p.y_off0 + (int64_t)geo.n * p.y_n_stride + (int64_t)(2 * geo.dt) * p.y_d_stride + (int64_t)(2 * geo.ht) * p.y_h_stride +
+                 (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.y_cb_stride;
+            if (p.res) {
+                const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)(2 * geo.dt) * p.r_d_stride + (int64_t)(2 * geo.ht) * p.r_h_stride +
+                                   (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.r_cb_stride;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    rv[i] = *(const f32x4*)(p.res + ro + (i >> 2) * p.r_d_stride + ((i >> 1) & 1) * p.r_h_stride + (i & 1) * 16);
+            }
+        }
         f32x4 inv[4];
         {
             f32x4 hh[2][4];
@@ -321,27 +350,21 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
             for (int i = 0; i < 4; ++i) { o0[i] += inv[i]; o1[i] -= inv[i]; }
             return;
         }
-        if (!geo.valid) return;
-        const int ct = ct0 + ctl;
+        if (!last) return;
         const f32x4 bn_sc = *(const f32x4*)(p.scale + ct * 16 + g * 4);
         const f32x4 bn_sh = *(const f32x4*)(p.shift + ct * 16 + g * 4);
-        const int64_t yo = p.y_off0 + (int64_t)geo.n * p.y_n_stride + (int64_t)(2 * geo.dt) * p.y_d_stride + (int64_t)(2 * geo.ht) * p.y_h_stride +
-                           (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.y_cb_stride;
-        const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)(2 * geo.dt) * p.r_d_stride + (int64_t)(2 * geo.ht) * p.r_h_stride +
-                           (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.r_cb_stride;
 #pragma unroll
-        for (int oh = 0; oh < 2; ++oh)
+        for (int od = 0; od < 2; ++od)
 #pragma unroll
-            for (int ow = 0; ow < 2; ++ow) {
-                const int i = oh * 2 + ow;
+            for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
-                for (int od = 0; od < 2; ++od) {
+                for (int ow = 0; ow < 2; ++ow) {
+                    const int i = oh * 2 + ow;
                     f32x4 v_ = (od == 0 ? o0[i] : o1[i] - inv[i]) * bn_sc + bn_sh;
-                    if (p.res) v_ += *(const f32x4*)(p.res + ro + od * p.r_d_stride + oh * p.r_h_stride + ow * 16);
+                    if (p.res) v_ += rv[od * 4 + i];
                     if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
                     *(f32x4*)(p.y + yo + od * p.y_d_stride + oh * p.y_h_stride + ow * 16) = v_;
                 }
-            }
     };
 
     struct Cursor { int round, xd, cb; };
@@ -355,6 +378,11 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
     Geo geo = geo_of(0);
     Item itA = item_of(0, 0), itB = item_of(0, 1);
     ring_fill(0, 0, 0, 0);
+#ifdef RB_RING3
+    ring_fill(1, 0, 0, 1);
+    int sl0 = 0, sl1 = 1, sl2 = 2;                 // ring slabs of this half step, the next one, and the one being filled
+    if (ctl) __builtin_amdgcn_s_setprio(1);        // the later-dispatched half of the block loses every issue arbitration otherwise
+#endif
     {
         Raw r;
         stage_issue(itA, 0, 0, r); stage_finish(itA, 0, brick, r);
@@ -379,19 +407,43 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
         Raw r;
         RB_MARK(0);
-        ring_fill(1, c0.xd, c0.cb, 1);
-        stage_issue(itA, c1.xd, c1.cb, r);
+#ifdef RB_RING3
+        // three slabs: the weights of half step h+2 are requested at the END of half step h (slab (h+2) % 3 was last read in h-1),
+        // off the path of the staging loads, and the barriers leave those two newest requests in flight
         RB_MARK(1);
-        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane);
+        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane + sl0 * 16384, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
+        RB_MARK(2);
+        stage_finish(itA, c1.xd, nb, r);
+        RB_MARK(3);
+        ring_fill(sl2, c1.xd, c1.cb, 0);
+        RB_BARRIER_KEEP2();
+        RB_MARK(4);
+        RB_MARK(5);
+        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + sl1 * 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
+        RB_MARK(6);
+        stage_finish(itB, c1.xd, nb, r);
+        RB_MARK(7);
+        if (c0.cb == p.cb_in - 1) {
+            phase_end(c0.xd, geo);
+            if (next_round && c1.round < rounds) geo = geo_of(c1.round);
+        }
+        RB_MARK(8);
+        ring_fill(sl0, c1.xd, c1.cb, 1);
+        RB_BARRIER_KEEP2();
+        RB_MARK(9);
+        { const int t_ = sl0; sl0 = sl2; sl2 = sl1; sl1 = t_; }       // two half steps on: (sl0, sl1, sl2) <- (sl2, sl0, sl1)
+#else
+        ring_fill(1, c0.xd, c0.cb, 1);
+        RB_MARK(1);
+        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
         RB_MARK(2);
         stage_finish(itA, c1.xd, nb, r);
         RB_MARK(3);
         RB_BARRIER();
         RB_MARK(4);
         ring_fill(0, c1.xd, c1.cb, 0);
-        stage_issue(itB, c1.xd, c1.cb, r);
         RB_MARK(5);
-        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + 16384);
+        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
         RB_MARK(6);
         stage_finish(itB, c1.xd, nb, r);
         RB_MARK(7);
@@ -402,6 +454,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         RB_MARK(8);
         RB_BARRIER();
         RB_MARK(9);
+#endif
         c0 = c1;
         ++stepno;
     };

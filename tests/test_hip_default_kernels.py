@@ -9,6 +9,8 @@ Tolerances as in test_hip_parity.py: mean <= 1e-3 px, max <= 2e-2 px
 import pytest
 import torch
 
+from disprcnn_amd import engine as E
+
 from oracle import psmnet_oracle as O
 from disprcnn_amd.utils import synth
 from tests.helpers import golden_npz, state_for
@@ -134,8 +136,16 @@ def test_workspace_memory_flat_over_roi_counts(dev):
         for n in counts:
             outs[n] = m.forward_from_features(fl[:n], fr[:n], (112, 112)).cpu()
         torch.cuda.synchronize()
-    assert m._rt.workspace_bytes() == base_bytes, "a smaller ROI count allocated workspace memory"
-    assert torch.cuda.memory_allocated() - base_alloc < 8 << 20, (torch.cuda.memory_allocated(), base_alloc)   # only small per-call outputs
+        # the one tensor the pool builds late: the materialised 64-channel volume (round 3: allocated on first use -- the fused eval path
+        # of the big counts never touches it, the generic kernel of the smallest counts does), once, at the pool's capacity
+        cost_bytes = 4 * E.Blocked.geometry(32, 64, 12, 28, 28, 1, 1, 1, dev).numel
+        first_bytes, first_alloc = m._rt.workspace_bytes(), torch.cuda.memory_allocated()
+        assert first_bytes - base_bytes in (0, cost_bytes + 4 * E.SLACK_FLOATS), (first_bytes, base_bytes, cost_bytes)
+        for n in counts:
+            m.forward_from_features(fl[:n], fr[:n], (112, 112))
+        torch.cuda.synchronize()
+    assert m._rt.workspace_bytes() == first_bytes, "a ROI count seen before allocated workspace memory"
+    assert torch.cuda.memory_allocated() - first_alloc < 8 << 20, (torch.cuda.memory_allocated(), first_alloc)   # only small per-call outputs
     assert len(m._rt._pools) == 1 and len(m._rt._ws) == len(set(counts))
     for n in (3, 12, 30):
         fresh = _model(dev, "A", 48, 0)
