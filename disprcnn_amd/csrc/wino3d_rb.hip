@@ -31,11 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define RB_WAVES 8
-#ifdef RB_RING3
-#define RB_RING_BYTES 49152
-#else
 #define RB_RING_BYTES 32768
-#endif
 #ifdef RB_ABL_NOBARRIER
 #define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
@@ -43,12 +39,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 
-// a barrier that leaves the two newest vector-memory requests (a ring slab's LDS-DMA pieces, issued last) in flight
-#ifdef RB_ABL_NOBARRIER
-#define RB_BARRIER_KEEP2() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory")
-#else
-#define RB_BARRIER_KEEP2() asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
 #ifdef RB_TRACE
 // development only: s_memtime stamps of block RB_TRACE_BLOCK, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps
 __device__ unsigned long long rb_trace_buf[2][64][16];
@@ -66,8 +56,12 @@ extern "C" int drc_rb_trace_read(unsigned long long* out) {
 
 namespace {
 
-template <int TW>
-__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_tapconv_params p, int NS) {
+// CV = the cost volume folded into the staging loads (dres0[0], stackhourglass.py:115-130; the round-2 wino3d_cv_kernel's job): instead of a
+// materialised volume the items read the blocked 2D feature maps -- channel blocks < cbi from the left map at (y, x), the others from the
+// right map at (y, x - i), i = lo4 + slice -- and a load whose voxel is outside the volume or fails 0 <= x - i < W' is pointed at halo
+// column 0 of its row (zero).
+template <int TW, bool CV>
+__device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, const drc_costvol_src& cv, int NS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SB = 256 * TW;                   // bytes per row slot: [xw 4][g 4][wt TW] float4
     constexpr int XWS = 64 * TW;                   // bytes per w-frequency plane of a slot
@@ -132,7 +126,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
     // one column PAIR with the neighbour's pair fetched by ds_bpermute / DPP -- half the loads, the same time; loads issued a half step
     // ahead or right before the barriers -- the wait is the LDS-DMA ring fill, not the loads; L2-warming touches -- slower: every extra
     // vector-memory instruction costs its issue slot behind the other seven waves' requests.)
-    struct Item { unsigned goff, loff; bool valid; };
+    struct Item { unsigned goff, loff; bool valid; int x0, d0; };       // x0, d0 (CV): volume column / slice of the patch origin
     auto item_of = [&](int round, int k) __attribute__((always_inline)) {
         Item it;
         const int chunk = round * nbk + pos;
@@ -165,8 +159,14 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         const int ht = t % TH; t /= TH;
         const int dt = t % TD;
         const int n = t / TD;
-        it.goff = (unsigned)((n * p.x_n_stride + (int64_t)(2 * dt + cls.dd0) * p.x_d_stride + (int64_t)(2 * ht + h + cls.dh0) * p.x_h_stride +
-                              (int64_t)(2 * wt + cls.dw0) * 16 + gq * 4) * 4);
+        if constexpr (CV) {         // byte offset of halo column 0 of feature-map row y = 2ht + h - 1 (+ the channel quad)
+            it.goff = (unsigned)((n * cv.n_stride + (int64_t)(2 * ht + h - 1 + cv.pad) * cv.h_stride + gq * 4) * 4);
+            it.x0 = 2 * wt - 1; it.d0 = 2 * dt - 1;
+        } else {
+            it.goff = (unsigned)((n * p.x_n_stride + (int64_t)(2 * dt + cls.dd0) * p.x_d_stride + (int64_t)(2 * ht + h + cls.dh0) * p.x_h_stride +
+                                  (int64_t)(2 * wt + cls.dw0) * 16 + gq * 4) * 4);
+            it.x0 = it.d0 = 0;
+        }
         it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + wt * 16);
         return it;
     };
@@ -178,12 +178,30 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         return;
 #endif
         if (!it.valid) return;
-        const char* sa = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_a(xd) * xd4);
-        const char* sb = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_b(xd) * xd4);
+        if constexpr (CV) {
+            const bool right = cb >= cv.cbi;                                      // wave-uniform
+            const char* base = (const char*)((right ? cv.right : cv.left) + (int64_t)(right ? cb - cv.cbi : cb) * cv.cb_stride);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
-            r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
+            for (int ab = 0; ab < 2; ++ab) {
+                const int d = it.d0 + (ab == 0 ? slice_a(xd) : slice_b(xd));
+                const bool ind = (unsigned)d < (unsigned)p.OD;
+                const int sh = right ? cv.lo4 + d : 0;                              // the right map is read at x - i
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int x = it.x0 + w;
+                    const bool ok = ind && (unsigned)x < (unsigned)cv.Wp && (unsigned)(x - cv.lo4 - d) < (unsigned)cv.Wp;
+                    const unsigned off = it.goff + (ok ? (unsigned)((x - sh + cv.pad) * 64) : 0u);
+                    (ab == 0 ? r.a[w] : r.b[w]) = *(const f32x4*)(base + off);
+                }
+            }
+        } else {
+            const char* sa = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_a(xd) * xd4);
+            const char* sb = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_b(xd) * xd4);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
+                r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
+            }
         }
     };
     // depth butterfly, w butterfly, four w-frequencies into brick buffer `bb`
@@ -256,7 +274,10 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb + 2 * SB + xw * XWS);
         }
         __builtin_amdgcn_sched_barrier(0);
-        between();                                 // the staging loads of this half step: issued while the LDS reads above are in flight
+        // the staging loads of this half step (8 vector-memory instructions, ~100 issue cycles each behind the other waves' requests) are
+        // issued while the LDS reads above are in flight.  (SIMD partners issuing theirs between their two MFMA rows instead, so that one
+        // wave's load issue sits beside the other's MFMAs: 3 % slower.)
+        between();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF == 0) {                 // xh 0: t0 - t2      (ta = t0, tb_ = t2)
 #pragma unroll
@@ -378,11 +399,6 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
     Geo geo = geo_of(0);
     Item itA = item_of(0, 0), itB = item_of(0, 1);
     ring_fill(0, 0, 0, 0);
-#ifdef RB_RING3
-    ring_fill(1, 0, 0, 1);
-    int sl0 = 0, sl1 = 1, sl2 = 2;                 // ring slabs of this half step, the next one, and the one being filled
-    if (ctl) __builtin_amdgcn_s_setprio(1);        // the later-dispatched half of the block loses every issue arbitration otherwise
-#endif
     {
         Raw r;
         stage_issue(itA, 0, 0, r); stage_finish(itA, 0, brick, r);
@@ -407,32 +423,6 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
         Raw r;
         RB_MARK(0);
-#ifdef RB_RING3
-        // three slabs: the weights of half step h+2 are requested at the END of half step h (slab (h+2) % 3 was last read in h-1),
-        // off the path of the staging loads, and the barriers leave those two newest requests in flight
-        RB_MARK(1);
-        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane + sl0 * 16384, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
-        RB_MARK(2);
-        stage_finish(itA, c1.xd, nb, r);
-        RB_MARK(3);
-        ring_fill(sl2, c1.xd, c1.cb, 0);
-        RB_BARRIER_KEEP2();
-        RB_MARK(4);
-        RB_MARK(5);
-        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + sl1 * 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
-        RB_MARK(6);
-        stage_finish(itB, c1.xd, nb, r);
-        RB_MARK(7);
-        if (c0.cb == p.cb_in - 1) {
-            phase_end(c0.xd, geo);
-            if (next_round && c1.round < rounds) geo = geo_of(c1.round);
-        }
-        RB_MARK(8);
-        ring_fill(sl0, c1.xd, c1.cb, 1);
-        RB_BARRIER_KEEP2();
-        RB_MARK(9);
-        { const int t_ = sl0; sl0 = sl2; sl2 = sl1; sl1 = t_; }       // two half steps on: (sl0, sl1, sl2) <- (sl2, sl0, sl1)
-#else
         ring_fill(1, c0.xd, c0.cb, 1);
         RB_MARK(1);
         consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
@@ -454,7 +444,6 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
         RB_MARK(8);
         RB_BARRIER();
         RB_MARK(9);
-#endif
         c0 = c1;
         ++stepno;
     };
@@ -467,6 +456,16 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_t
 #undef RB_MFMA_ROW
 }
 
+template <int TW>
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_tapconv_params p, int NS) {
+    wino3d_rb_body<TW, false>(p, drc_costvol_src{}, NS);
+}
+
+template <int TW>
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_cv_kernel(const drc_tapconv_params p, const drc_costvol_src cv, int NS) {
+    wino3d_rb_body<TW, true>(p, cv, NS);
+}
+
 // slots a 64-tile chunk can touch: two per tile row plus two per slab
 inline int rb_slots(int TW, int TH) {
     const int rows_max = 63 / TW + 2;
@@ -476,13 +475,14 @@ inline int rb_slots(int TW, int TH) {
 }
 
 template <int TW>
-int launch_rb(const drc_tapconv_params& p, hipStream_t stream) {
+int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_t stream) {
     const int NS = rb_slots(TW, p.OH / 2);
     const size_t lds = RB_RING_BYTES + (size_t)2 * NS * 256 * TW;
     if (lds > 163840 || NS * TW * 4 > 1024) return -4;
     static bool attr_set = false;                  // idempotent: racing first calls set the same value
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)wino3d_rb_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        hipError_t e = hipFuncSetAttribute((const void*)wino3d_rb_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino3d_rb_cv_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -492,7 +492,10 @@ int launch_rb(const drc_tapconv_params& p, hipStream_t stream) {
     long per_cg = 256 / n_cg;                      // one block (8 waves, up to 160 KB of LDS) per CU
     if (per_cg > chunks) per_cg = chunks;
     if (per_cg < 1) per_cg = 1;
-    hipLaunchKernelGGL((wino3d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
+    if (cv)
+        hipLaunchKernelGGL((wino3d_rb_cv_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, *cv, NS);
+    else
+        hipLaunchKernelGGL((wino3d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
     return (int)hipGetLastError();
 }
 
@@ -551,10 +554,10 @@ extern "C" int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int
     return RB_RING_BYTES + (size_t)2 * NS * 256 * TW <= 163840 && NS * TW * 4 <= 1024;
 }
 
-extern "C" int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* stream) {
+static int rb_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void* stream) {
     if (!pp) return -1;
     const drc_tapconv_params& p = *pp;
-    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if ((!cv && !p.x) || !p.w || !p.y || !p.scale || !p.shift) return -1;
     if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
     if (p.N == 0) return 0;
     if (p.cout_pad <= 0 || (p.cout_pad & 31) || p.cb_in <= 0) return -2;
@@ -562,10 +565,23 @@ extern "C" int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* str
     if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 || k.sw != 1)
         return -4;
     if (!drc_conv3d_k3_wino_rb_supported(p.cout_pad, p.OD, p.OH, p.OW)) return -4;
-    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;             // 32-bit item offsets over the whole batch
+    if (cv) {
+        if (!cv->left || !cv->right) return -1;
+        if (cv->pad < 1 || cv->cbi <= 0 || p.cb_in != 2 * cv->cbi || cv->Wp != p.OW) return -2;
+        if ((int64_t)p.N * cv->n_stride * 4 >= (1LL << 32)) return -5;
+    } else if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) {
+        return -5;                                                              // 32-bit item offsets over the whole batch
+    }
     if ((int64_t)p.N * p.OD * p.OH * p.OW / 8 >= (1LL << 31) - 64 || (int64_t)64 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
     hipStream_t s = (hipStream_t)stream;
-    return p.OW == 28 ? launch_rb<14>(p, s) : launch_rb<7>(p, s);
+    return p.OW == 28 ? launch_rb<14>(p, cv, s) : launch_rb<7>(p, cv, s);
+}
+
+extern "C" int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* stream) { return rb_fwd(pp, nullptr, stream); }
+
+extern "C" int drc_conv3d_k3_wino_rb_costvol_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void* stream) {
+    if (!cv) return -1;
+    return rb_fwd(pp, cv, stream);
 }
 
 extern "C" int drc_pack_weights_wino_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream) {

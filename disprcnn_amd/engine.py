@@ -609,7 +609,7 @@ class ConvPlan:
         if left.N < p.N or right.N < r_first + p.N:
             raise ValueError("run_costvol: fewer feature maps than volume units")
         if w16 is None or w16.shape[0] != 64:
-            raise ValueError("run_costvol: pass w16 = plan.pack16(weight, kind='wino')")
+            raise ValueError("run_costvol: pass w16 = plan.pack16(weight) (the plan's own packing: wino3d.hip's or wino3d_rb.hip's)")
         cv = _lib.DrcCostvolSrc()
         cv.left = _base_ptr(left)
         cv.right = _base_ptr(right) + 4 * r_first * right.n_stride
@@ -624,11 +624,15 @@ class ConvPlan:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        st = _lib.lib().drc_conv3d_k3_wino_costvol_fwd(C.byref(p), C.byref(cv), self.slide_ct, _stream_ptr(self.device))
-        _lib.check(st, "drc_conv3d_k3_wino_costvol_fwd")
+        if self.rb:
+            st = _lib.lib().drc_conv3d_k3_wino_rb_costvol_fwd(C.byref(p), C.byref(cv), _stream_ptr(self.device))
+            _lib.check(st, "drc_conv3d_k3_wino_rb_costvol_fwd")
+        else:
+            st = _lib.lib().drc_conv3d_k3_wino_costvol_fwd(C.byref(p), C.byref(cv), self.slide_ct, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv3d_k3_wino_costvol_fwd")
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            TIMING.append(("wino3d_cv_kernel<%d>" % self.slide_ct, self.flops, e0, e1))
+            TIMING.append((self.kname.replace("rb_kernel", "rb_cv_kernel") if self.rb else "wino3d_cv_kernel<%d>" % self.slide_ct, self.flops, e0, e1))
 
 
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)

@@ -322,7 +322,7 @@ class PSMNetRuntime:
 
         if cv is not None:
             c, pl = W["dres0.0"], p["dres0.0"]
-            pl.run_costvol(cv[0], cv[1], cv[2], c.w16_for(pl, kind="wino"), c.scale, c.shift, t["d0a"])
+            pl.run_costvol(cv[0], cv[1], cv[2], c.w16_for(pl), c.scale, c.shift, t["d0a"])
         else:
             run("dres0.0", "dres0.0", "cost", "d0a")
         run("dres0.2", "dres0.2", "d0a", "cost0a")

@@ -187,6 +187,8 @@ typedef struct drc_costvol_src {
  * the same weights, epilogue and limits as drc_conv3d_k3_wino_fwd (N * n_stride * 4 < 2^32).  Results are bit-identical to
  * drc_cost_volume_blocked_fwd followed by drc_conv3d_k3_wino_fwd. */
 int drc_conv3d_k3_wino_costvol_fwd(const drc_tapconv_params* p, const drc_costvol_src* cv, int cout_tiles_per_wave, void* stream);
+/* The same fused launch on the row-brick kernel (drc_conv3d_k3_wino_rb_fwd's shapes and weight packing): bit-identical results. */
+int drc_conv3d_k3_wino_rb_costvol_fwd(const drc_tapconv_params* p, const drc_costvol_src* cv, void* stream);
 
 /* Conv2d 3x3, stride 1, dilation 1, pad 1 (same parameter block as drc_conv2d_k3_direct_fwd; R, WT ignored) as Winograd
  * F(2x2, 3x3): 16 instead of 36 multiplies per (cin, cout) pair and 2x2 output tile.  Needs even OH, OW and

@@ -262,8 +262,7 @@ def test_conv3d_winograd_fused_cost_volume(dev, n, C, cout, D, H, W, lo4, pad):
     finally:
         E.DIRECT["enabled"], E.SLIDE["min_od"], E.SLIDE["min_units"], E.WINO["enabled"] = saved
     assert plan.wino
-    w16p = plan.pack16(w.to(dev))                      # the materialised path's own packing (wino3d.hip or, at n = 19, wino3d_rb.hip)
-    w16 = plan.pack16(w.to(dev), kind="wino")          # the fused launch reads the wino3d.hip packing
+    w16p = w16 = plan.pack16(w.to(dev))                # the plan's own packing (wino3d.hip; at n = 19 wino3d_rb.hip -- both have a fused form)
     both = E.Blocked(2 * n, C, 1, H, W, 0, pad, pad, dev).from_dense(torch.cat((fl, fr), 0).to(dev))      # left maps, then right maps
     E.cost_volume_blocked(fl.to(dev), fr.to(dev), xb, lo4, lo4 + D, 0)
     plan.run(xb, w16p, scale, shift, y0, w16=w16p)
