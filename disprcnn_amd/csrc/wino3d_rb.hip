@@ -77,9 +77,12 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     const int ctl = wave >> 2;                     // cout tile within the block's 32 couts (waves w and w+4 share a SIMD)
 
     const drc_tap_class cls = p.cls[0];
-    const int TD = p.OD >> 1, TH = p.OH >> 1;
-    const int tiles = p.N * TD * TH * TW;
-    const int rows_total = p.N * TD * TH;
+    // Maps wider than 2 TW columns (Config B's 56-wide volume at TW = 14) are walked as WS side-by-side strips of TW tile columns: a
+    // "slab" is the (n, depth tile, strip) plane of TH tile rows, tiles run (n, dt, strip, ht, wt) -- everything below sees TW-wide maps
+    // whose columns start at strip * 2 TW (the strips share their boundary columns like tiles do).
+    const int TD = p.OD >> 1, TH = p.OH >> 1, WS = (p.OW >> 1) / TW;
+    const int tiles = p.N * TD * WS * TH * TW;
+    const int rows_total = p.N * TD * WS * TH;
     const int chunks = (tiles + 63) >> 6;
     const int n_cg = p.cout_pad / 32;
     int cg, pos;
@@ -113,11 +116,12 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         q.wt = tile - R * TW;
         int t = R;
         q.ht = t % TH; t /= TH;
+        q.wt += (t % WS) * TW; t /= WS;             // the tile's column in the whole map
         q.dt = t % TD;
         q.n = t / TD;
         int slot = 2 * (R - R0) + 2 * (R / TH - R0 / TH);
         slot = slot > NS - 4 ? NS - 4 : slot;
-        q.lds = (unsigned)(slot * SB + g * GS + q.wt * 16);
+        q.lds = (unsigned)(slot * SB + g * GS + (tile - R * TW) * 16);
         return q;
     };
     // A staging item = (row slot, tile column wt, channel quad gq), thread t takes items t and t + 512: it loads the row's columns
@@ -157,14 +161,15 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         R = R > rows_total - 1 ? rows_total - 1 : R;
         int t = R;
         const int ht = t % TH; t /= TH;
+        const int wg = (t % WS) * TW + wt; t /= WS;     // the item's tile column in the whole map
         const int dt = t % TD;
         const int n = t / TD;
         if constexpr (CV) {         // byte offset of halo column 0 of feature-map row y = 2ht + h - 1 (+ the channel quad)
             it.goff = (unsigned)((n * cv.n_stride + (int64_t)(2 * ht + h - 1 + cv.pad) * cv.h_stride + gq * 4) * 4);
-            it.x0 = 2 * wt - 1; it.d0 = 2 * dt - 1;
+            it.x0 = 2 * wg - 1; it.d0 = 2 * dt - 1;
         } else {
             it.goff = (unsigned)((n * p.x_n_stride + (int64_t)(2 * dt + cls.dd0) * p.x_d_stride + (int64_t)(2 * ht + h + cls.dh0) * p.x_h_stride +
-                                  (int64_t)(2 * wt + cls.dw0) * 16 + gq * 4) * 4);
+                                  (int64_t)(2 * wg + cls.dw0) * 16 + gq * 4) * 4);
             it.x0 = it.d0 = 0;
         }
         it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + wt * 16);
@@ -486,7 +491,7 @@ int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long tiles = (long)p.N * (p.OD / 2) * (p.OH / 2) * TW;
+    const long tiles = (long)p.N * (p.OD / 2) * (p.OH / 2) * (p.OW / 2);
     const long chunks = (tiles + 63) / 64;
     const int n_cg = p.cout_pad / 32;
     long per_cg = 256 / n_cg;                      // one block (8 waves, up to 160 KB of LDS) per CU
@@ -548,8 +553,8 @@ __global__ __launch_bounds__(256) void wino_weights_rb_kernel(const float* __res
 
 extern "C" int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int OW) {
     if (cout_pad <= 0 || (cout_pad & 31) || OD <= 0 || OH <= 0 || OW <= 0 || ((OD | OH | OW) & 1)) return 0;
-    const int TW = OW / 2;
-    if (TW != 14 && TW != 7) return 0;
+    if (OW != 14 && OW % 28) return 0;                      // 14-wide maps: TW = 7; multiples of 28: strips of TW = 14 tile columns
+    const int TW = OW == 14 ? 7 : 14;
     const int NS = rb_slots(TW, OH / 2);
     return RB_RING_BYTES + (size_t)2 * NS * 256 * TW <= 163840 && NS * TW * 4 <= 1024;
 }
@@ -574,7 +579,7 @@ static int rb_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void*
     }
     if ((int64_t)p.N * p.OD * p.OH * p.OW / 8 >= (1LL << 31) - 64 || (int64_t)64 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
     hipStream_t s = (hipStream_t)stream;
-    return p.OW == 28 ? launch_rb<14>(p, cv, s) : launch_rb<7>(p, cv, s);
+    return p.OW == 14 ? launch_rb<7>(p, cv, s) : launch_rb<14>(p, cv, s);
 }
 
 extern "C" int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* stream) { return rb_fwd(pp, nullptr, stream); }

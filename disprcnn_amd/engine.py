@@ -684,7 +684,7 @@ def plan_conv3d(x, y, stride, cout, relu):
             if (WINO.get("rb") and chunks * (pl.p.cout_pad // 32) >= WINO["rb_min_chunks"]
                     and _lib.lib().drc_conv3d_k3_wino_rb_supported(pl.p.cout_pad, y.D, y.H, y.W)):
                 pl.rb = True
-                pl.kname = "wino3d_rb_kernel<%d>" % (y.W // 2)
+                pl.kname = "wino3d_rb_kernel<%d>" % (7 if y.W == 14 else 14)
     elif (not pl.slide and stride == 1 and SLIDE["enabled"] and DIRECT["enabled"] and getattr(pl, "slide_small_ok", False)
           and (y.D | y.H | y.W) & 1):
         # odd maps (no Winograd) at small batch: the direct kernel with one cout tile per wave

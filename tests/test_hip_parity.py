@@ -193,6 +193,8 @@ def test_conv3d_winograd_kernel_vs_oracle(dev, n, cin, cout, dims, with_res):
     (5, 64, 64, (6, 14, 14), True, True),        # hourglass conv2 at half resolution (TW = 7, two cout groups, four channel blocks)
     (1, 32, 32, (2, 28, 28), False, True),       # fewer chunks than blocks, a partial last chunk
     (4, 40, 64, (4, 6, 28), True, True),         # three channel blocks (one partial), TH = 3: a chunk spans three slabs
+    (2, 32, 32, (4, 8, 56), True, True),         # a 56-wide map (Config B's volume): two strips of 14 tile columns
+    (1, 16, 64, (2, 56, 84), False, True),       # three strips, TH = 28, one (partial) channel block, two cout groups
     (7, 48, 32, (2, 2, 14), True, False),        # TH = 1: more row slots than the LDS holds -> the engine keeps wino3d.hip
     (2, 32, 32, (4, 20, 20), True, False)])      # a width the row-brick kernel is not built for
 def test_conv3d_winograd_rowbrick_kernel(dev, n, cin, cout, dims, with_res, expect_rb):
@@ -238,12 +240,14 @@ def test_winograd_rowbrick_weight_packing(dev):
 
 
 @pytest.mark.parametrize("n,C,cout,D,H,W,lo4,pad", [(3, 32, 32, 12, 28, 28, 0, 1), (2, 32, 32, 6, 28, 28, -6, 1), (5, 16, 48, 8, 10, 30, 3, 2),
-                                                     (1, 32, 32, 24, 56, 56, 0, 1), (2, 32, 32, 4, 6, 2, -1, 1), (19, 32, 32, 12, 28, 28, 0, 1)])
+                                                     (1, 32, 32, 24, 56, 56, 0, 1), (2, 32, 32, 4, 6, 2, -1, 1), (19, 32, 32, 12, 28, 28, 0, 1),
+                                                     (8, 32, 32, 8, 56, 56, -2, 1)])
 def test_conv3d_winograd_fused_cost_volume(dev, n, C, cout, D, H, W, lo4, pad):
     """wino3d_cv_kernel (dres0[0] reading the 2D feature maps, cost volume never materialised; stackhourglass.py:115-130):
     bit-identical to drc_cost_volume_blocked_fwd + drc_conv3d_k3_wino_fwd, and within the layer tolerance of the oracle's
     volume convolved directly.  Covers negative / positive mindisp, widths below the disparity range, feature halos > 1,
-    a right side named as a later range of the same tensor, and partial tile groups."""
+    a right side named as a later range of the same tensor, and partial tile groups.  The two largest cases take the round-3 row-brick
+    kernel and its fused form (wino3d_rb.hip: 28-wide maps, and a 56-wide map walked as two strips)."""
     from disprcnn_amd import engine as E
     fl = synth.hash_uniform(f"CV{n}{C}{H}{W}:l", (n, C, H, W))
     fr = synth.hash_uniform(f"CV{n}{C}{H}{W}:r", (n, C, H, W))

@@ -21,7 +21,7 @@ lib = C.CDLL(os.environ["DRC_LIB"])
 buf = np.zeros((2, 64, 16), dtype=np.uint64)
 st = lib.drc_rb_trace_read(buf.ctypes.data_as(C.c_void_p))
 assert st == 0, st
-names = ["h0 start", "fill+loads issued", "consumed", "item A finished", "barrier passed", "fill+loads issued", "consumed", "item B finished", "phase end done", "barrier passed", "-", "-"]
+names = ["h0 start", "fill issued", "consumed", "item A finished", "barrier passed", "fill issued", "consumed", "item B finished", "phase end done", "barrier passed", "-", "-"]
 t = buf.astype(np.int64)
 for wv in range(2):
     d = np.diff(t[wv, :, :12], axis=1)
