@@ -324,7 +324,7 @@ def train_step_extra(dev, model_a, world):
         sync_ms = []
 
         def train_step():
-            opt.zero_grad(set_to_none=True)
+            sync.zero_grad()                     # .grad = zeroed views of the flat all-reduce buffer: the backward fills it directly
             loss = crit(fwd(), {"disparity": tgt, "mask": msk})
             loss.backward()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

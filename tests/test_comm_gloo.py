@@ -32,6 +32,18 @@ def _worker(rank, world, port, n_rois, q):
             b.grad = torch.full((2, 3), 4.0)
         comm.GradientSync([w, b, frozen])()
         assert torch.allclose(w.grad, torch.full((5,), 1.5)) and torch.allclose(b.grad, torch.full((2, 3), 2.0)) and frozen.grad is None
+        # the copy-free form: zero_grad() makes every .grad a view of the flat buffer, autograd accumulates into it, one collective in place
+        w2 = torch.nn.Parameter(torch.arange(5.0)); b2 = torch.nn.Parameter(torch.ones(2, 3))
+        sync = comm.GradientSync([w2, b2, frozen])
+        sync.zero_grad()
+        ptrs = (w2.grad.data_ptr(), b2.grad.data_ptr())
+        ((w2 * float(rank + 1)).sum() + (b2.sum() * 4.0 if rank == 0 else b2.sum() * 0.0)).backward()
+        assert (w2.grad.data_ptr(), b2.grad.data_ptr()) == ptrs and sync._attached()         # accumulated in place
+        sync()
+        assert (w2.grad.data_ptr(), b2.grad.data_ptr()) == ptrs
+        assert torch.allclose(w2.grad, torch.full((5,), 1.5)) and torch.allclose(b2.grad, torch.full((2, 3), 2.0))
+        sync.zero_grad()
+        assert float(w2.grad.abs().sum()) == 0.0 and w2.grad.data_ptr() == ptrs[0]
         q.put((rank, lo, hi, full[:, 0, 0].tolist(), float(red["loss"])))
     finally:
         dist.destroy_process_group()
