@@ -83,6 +83,10 @@ _SIGS = {
     "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
+    "drc_linear_scratch_floats": (C.c_int64, [_I, _I, _I]),
+    "drc_linear_packed_floats": (C.c_int64, [_I, _I]),
+    "drc_linear_pack_rows": (_I, [_P, _I, _I, _P, _P]),
+    "drc_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, C.c_int64, _P]),
     "drc_conv3d_k3_wino_rb_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv3d_k3_wino_rb_supported": (_I, [_I, _I, _I, _I]),
     "drc_conv3d_k3_wino_rb_costvol_fwd": (_I, [C.POINTER(DrcTapconvParams), C.POINTER(DrcCostvolSrc), _P]),

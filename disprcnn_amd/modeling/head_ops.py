@@ -85,8 +85,48 @@ class EngineConv2d:
         return yb.to_dense()[:, :, 0]
 
 
+_PACKED_W = {}     # id(weight) -> (version key, packed tensor): the layer's weights in the GEMM's operand layout, rebuilt when they change
+
+
+def _pack_rows(a):
+    from .. import _lib
+    lib = _lib.lib()
+    R, K = a.shape
+    out = torch.empty(lib.drc_linear_packed_floats(R, K), dtype=torch.float32, device=a.device)
+    st = lib.drc_linear_pack_rows(E._ptr(a), R, K, E._ptr(out), E._stream_ptr(a.device))
+    _lib.check(st, "drc_linear_pack_rows")
+    return out
+
+
 def linear(x, layer, relu=False):
-    """x [R, in] @ layer.weight^T + bias (library GEMM); layer is an nn.Linear or an nn.Conv2d that acts on a full window."""
-    w = layer.weight.detach().to(device=x.device, dtype=torch.float32).reshape(layer.weight.shape[0], -1)
-    y = torch.addmm(layer.bias.detach().to(device=x.device, dtype=torch.float32), x.float(), w.t()) if layer.bias is not None else x.float() @ w.t()
-    return torch.relu_(y) if relu else y
+    """act(x [R, in] @ layer.weight^T + bias) on the hand-written fp32-MFMA GEMM (csrc/linear.hip: drc_linear_fwd); layer is an nn.Linear
+    or an nn.Conv2d that acts on a full window (its weight flattened to [out, in], K contiguous).  The weights are packed into the GEMM's
+    operand layout once per parameter version, the activations per call.  GPU only."""
+    from .. import _lib
+    E.require_gpu(x, "linear")
+    dev = x.device
+    wt = layer.weight
+    key = (wt._version, wt.data_ptr(), dev, tuple(wt.shape))
+    ent = _PACKED_W.get(id(wt))
+    if ent is None or ent[0] != key:
+        w2 = wt.detach().to(device=dev, dtype=torch.float32).reshape(wt.shape[0], -1).contiguous()
+        ent = _PACKED_W[id(wt)] = (key, _pack_rows(w2), w2.shape[1])
+        if len(_PACKED_W) > 64:                                       # parameters of discarded models
+            _PACKED_W.pop(next(iter(_PACKED_W)))
+    wp, Kw = ent[1], ent[2]
+    b = None if layer.bias is None else layer.bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    x = x.float().contiguous()
+    M, K = x.shape
+    N = wt.shape[0]
+    if Kw != K:
+        raise ValueError(f"linear: input has {K} features, the layer expects {Kw}")
+    y = torch.empty(M, N, dtype=torch.float32, device=dev)
+    if M == 0:
+        return y
+    lib = _lib.lib()
+    xp = _pack_rows(x)
+    nscr = lib.drc_linear_scratch_floats(M, N, K)
+    scr = E.scratch(dev, "linear", nscr) if nscr else None
+    st = lib.drc_linear_fwd(E._ptr(xp), E._ptr(wp), E._ptr(b), E._ptr(y), M, N, K, int(bool(relu)), E._ptr(scr), nscr, E._stream_ptr(dev))
+    _lib.check(st, "drc_linear_fwd")
+    return y

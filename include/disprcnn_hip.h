@@ -348,6 +348,21 @@ int drc_disparity_paste_fwd(const float* disp, int S, const int32_t* boxes, cons
 int drc_roi_depth_maps_fwd(const float* disp, int S, const int32_t* boxes, const float* fuxb, int R, int H, int W, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * f4. Fully connected layers of the 2D stage's heads (roi_heads/box_head/roi_box_feature_extractors.py:85-130: the 7x7/stride-7
+ *   convolution on 7x7 ROI features = a 25088 -> 2048 FC, then 2048 -> 2048; roi_box_predictors.py; the mask predictor's 2x2/stride-2
+ *   transposed convolution and 1x1 logits): y[M][N] = act(x[M][K] . w[N][K]^T + bias[N]) as a hand-written fp32-MFMA GEMM (linear.hip).
+ *   x and w are PACKED operands: drc_linear_pack_rows turns a row-major [R][K] matrix (K contiguous) into [R/16][K/16][k%16/4][r%16][k%4],
+ *   zero-padded to whole 16 x 16 blocks (drc_linear_packed_floats floats), so that a wavefront's operand load is one contiguous KiB; pack
+ *   the weights once per parameter version, the activations per call.  bias may be NULL.  K is split over several waves per output tile
+ *   when M x N alone cannot fill the chip: scratch must then hold drc_linear_scratch_floats(M, N, K) floats of partial tiles, which a
+ *   second launch adds in split order (no atomics). */
+int64_t drc_linear_packed_floats(int R, int K);
+int drc_linear_pack_rows(const float* a, int R, int K, float* out, void* stream);
+int64_t drc_linear_scratch_floats(int M, int N, int K);
+int drc_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int relu, float* scratch,
+                   int64_t scratch_floats, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * a10. PSMLoss / EndPointErrorLoss (utils/loss_utils.py:9-32, utils/stereo_utils.py:185-208).
  *   sums5 = { sum m*smoothl1(p1-t), sum m*smoothl1(p2-t), sum m*smoothl1(p3-t), sum m, sum m*|p1-t| }   (overwritten)
  *   (pred2/pred3 may be NULL for the eval form).  scratch: DRC_LOSS_SCRATCH_FLOATS floats of per-block partials, added in

@@ -268,3 +268,27 @@ def test_engine_conv2d_storage_flat_over_unit_counts(dev):
         sizes.append(ec.nbytes())
     assert len(set(sizes)) == 1, sizes                                   # one allocation, at the first (largest) count
     assert tuple(ec(torch.zeros(0, 24, 14, 14, device=dev)).shape) == (0, 40, 14, 14)
+
+
+@pytest.mark.parametrize("M,N,K,relu,bias", [(300, 2048, 25088, True, True), (65, 2048, 2048, True, True), (7, 12, 2048, False, True),
+                                              (3, 5, 20, False, False), (130, 70, 36, True, True), (0, 8, 16, False, True)])
+def test_linear_mfma_gemm_vs_reference(dev, M, N, K, relu, bias):
+    """head_ops.linear = drc_linear_fwd (csrc/linear.hip), the hand-written fp32-MFMA GEMM behind the stereo box head's fully connected
+    layers (roi_box_feature_extractors.py:85-130: 25088 -> 2048 -> 2048), its predictors and the mask predictor: vs a float64 matmul, incl.
+    the split-K path, ragged M / N tiles, a K that is not a multiple of 16, no bias, and an empty ROI batch."""
+    from disprcnn_amd.modeling.head_ops import linear
+    lin = torch.nn.Linear(K, N, bias=bias)
+    lin.weight.data = synth.hash_uniform(f"lin{M}{N}{K}:w", (N, K), -1.0, 1.0) / (K ** 0.5)
+    if bias:
+        lin.bias.data = synth.hash_uniform(f"lin{N}:b", (N,), -0.5, 0.5)
+    x = synth.hash_uniform(f"lin{M}{K}:x", (M, K), -1.0, 1.0)
+    got = linear(x.to(dev), lin.to(dev), relu=relu).cpu()
+    ref = x.double() @ lin.weight.detach().cpu().double().t()
+    if bias:
+        ref = ref + lin.bias.detach().cpu().double()
+    ref = torch.relu(ref) if relu else ref
+    assert got.shape == (M, N) and got.dtype == torch.float32
+    if M:
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+        again = linear(x.to(dev), lin, relu=relu).cpu()
+        assert torch.equal(got, again)                       # split-K partials are added in a fixed order
