@@ -1,6 +1,6 @@
 """Engine-backed layers of the 2D stage's heads: nn.Conv2d / nn.Linear parameter holders whose arithmetic runs on the HIP engine
-(convolutions: the same MFMA kernels as the backbone, bias in the folded-BN epilogue slot) or, for the plain fully connected layers,
-as library GEMMs (torch.addmm -> hipBLASLt).  Inference only; there is no CPU path."""
+(convolutions: the same MFMA kernels as the backbone, bias in the folded-BN epilogue slot) or, for the fully connected layers, on the
+hand-written fp32-MFMA GEMM of csrc/linear.hip (round 3; rounds 1-2: torch.addmm -> hipBLASLt).  Inference only; there is no CPU path."""
 from collections import OrderedDict
 
 import torch
@@ -98,31 +98,29 @@ def _pack_rows(a):
     return out
 
 
-def linear(x, layer, relu=False):
-    """act(x [R, in] @ layer.weight^T + bias) on the hand-written fp32-MFMA GEMM (csrc/linear.hip: drc_linear_fwd); layer is an nn.Linear
-    or an nn.Conv2d that acts on a full window (its weight flattened to [out, in], K contiguous).  The weights are packed into the GEMM's
-    operand layout once per parameter version, the activations per call.  GPU only."""
+def gemm_bias_act(x, weight_param, w2d_fn, bias, relu, tag=""):
+    """act(x [M,K] @ W^T + bias) with W = w2d_fn(weight_param) [N,K] on drc_linear_fwd.  The packed form of W is cached per
+    (parameter, tag) and rebuilt when the parameter's version or storage changes."""
     from .. import _lib
-    E.require_gpu(x, "linear")
+    E.require_gpu(x, "gemm_bias_act")
     dev = x.device
-    wt = layer.weight
-    key = (wt._version, wt.data_ptr(), dev, tuple(wt.shape))
-    ent = _PACKED_W.get(id(wt))
+    key = (weight_param._version, weight_param.data_ptr(), dev, tuple(weight_param.shape))
+    ck = (id(weight_param), tag)
+    ent = _PACKED_W.get(ck)
     if ent is None or ent[0] != key:
-        w2 = wt.detach().to(device=dev, dtype=torch.float32).reshape(wt.shape[0], -1).contiguous()
-        ent = _PACKED_W[id(wt)] = (key, _pack_rows(w2), w2.shape[1])
+        w2 = w2d_fn(weight_param.detach().to(device=dev, dtype=torch.float32)).contiguous()
+        ent = _PACKED_W[ck] = (key, _pack_rows(w2), tuple(w2.shape))
         if len(_PACKED_W) > 64:                                       # parameters of discarded models
             _PACKED_W.pop(next(iter(_PACKED_W)))
-    wp, Kw = ent[1], ent[2]
-    b = None if layer.bias is None else layer.bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+    wp, (N, Kw) = ent[1], ent[2]
     x = x.float().contiguous()
     M, K = x.shape
-    N = wt.shape[0]
     if Kw != K:
-        raise ValueError(f"linear: input has {K} features, the layer expects {Kw}")
+        raise ValueError(f"gemm_bias_act: input has {K} features, the layer expects {Kw}")
     y = torch.empty(M, N, dtype=torch.float32, device=dev)
     if M == 0:
         return y
+    b = None if bias is None else bias.detach().to(device=dev, dtype=torch.float32).contiguous()
     lib = _lib.lib()
     xp = _pack_rows(x)
     nscr = lib.drc_linear_scratch_floats(M, N, K)
@@ -130,3 +128,10 @@ def linear(x, layer, relu=False):
     st = lib.drc_linear_fwd(E._ptr(xp), E._ptr(wp), E._ptr(b), E._ptr(y), M, N, K, int(bool(relu)), E._ptr(scr), nscr, E._stream_ptr(dev))
     _lib.check(st, "drc_linear_fwd")
     return y
+
+
+def linear(x, layer, relu=False):
+    """act(x [R, in] @ layer.weight^T + bias) on the hand-written fp32-MFMA GEMM (csrc/linear.hip: drc_linear_fwd); layer is an nn.Linear
+    or an nn.Conv2d that acts on a full window (its weight flattened to [out, in], K contiguous).  The weights are packed into the GEMM's
+    operand layout once per parameter version, the activations per call.  GPU only."""
+    return gemm_bias_act(x, layer.weight, lambda w: w.reshape(w.shape[0], -1), layer.bias, relu)

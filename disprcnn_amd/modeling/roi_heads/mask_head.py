@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from ...structures.bounding_box import BoxList
-from ..head_ops import EngineConv2d
+from ..head_ops import EngineConv2d, gemm_bias_act
 from ..poolers import Pooler
 
 
@@ -56,14 +56,14 @@ class MaskRCNNC4Predictor(nn.Module):
     def forward(self, x):
         """x [R,C,h,w] -> class logits [R,ncls,2h,2w]."""
         r, c, h, w = x.shape
-        wt = self.conv5_mask.weight.detach().to(device=x.device, dtype=torch.float32)           # [Cin, Cout, 2, 2]
-        cout = wt.shape[1]
-        t = x.permute(0, 2, 3, 1).reshape(-1, c) @ wt.reshape(c, cout * 4)                      # [R*h*w, Cout*2*2]
-        t = t.view(r, h, w, cout, 2, 2) + self.conv5_mask.bias.detach().to(x.device).float().view(1, 1, 1, cout, 1, 1)
-        t = torch.relu_(t).permute(0, 1, 4, 2, 5, 3).reshape(-1, cout)                          # rows = output pixels (y, dy, x, dx)
-        wl = self.mask_fcn_logits.weight.detach().to(device=x.device, dtype=torch.float32).view(-1, cout)
-        lg = torch.addmm(self.mask_fcn_logits.bias.detach().to(x.device).float(), t, wl.t())
-        return lg.view(r, 2 * h, 2 * w, wl.shape[0]).permute(0, 3, 1, 2).contiguous()
+        cout, ncls = self.conv5_mask.weight.shape[1], self.mask_fcn_logits.weight.shape[0]
+        # the 2x2 / stride-2 transposed convolution has no overlapping taps: a GEMM of the input pixels [R*h*w, Cin] against
+        # W [(Cout, dy, dx), Cin] with the bias repeated over (dy, dx) and the ReLU fused (drc_linear_fwd)
+        t = gemm_bias_act(x.permute(0, 2, 3, 1).reshape(-1, c), self.conv5_mask.weight, lambda wt: wt.reshape(c, cout * 4).t(),
+                          self.conv5_mask.bias.detach().repeat_interleave(4), True, tag="deconv2x2")
+        t = t.view(r, h, w, cout, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(-1, cout)             # rows = output pixels (y, dy, x, dx)
+        lg = gemm_bias_act(t, self.mask_fcn_logits.weight, lambda wl: wl.view(ncls, cout), self.mask_fcn_logits.bias, False)
+        return lg.view(r, 2 * h, 2 * w, ncls).permute(0, 3, 1, 2).contiguous()
 
 
 class MaskPostProcessor(nn.Module):
