@@ -56,8 +56,11 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 // resolved against each other in registers -- the only truly sequential part, ~20 cycles per row, no memory access; (3) the kept rows'
 // mask rows are ORed into the removed-words of the later blocks with independent loads, four rows in flight.  (Round 2, first form:
 // one dependent global load per kept row -- 1.27 ms for the Stereo RPN's 6,000 boxes, 27 % of the 2D stage.)
+// (Round 3: templated on the removed-words per lane, so that the usual proposal counts -- the RPN's 6,000 boxes per view = 94 column blocks,
+// two words per lane -- keep 16 kept rows' mask rows in flight per round instead of 4: the walk is a chain of L2 round trips.)
+template <int kMaxWords>
 __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks, uint8_t* __restrict__ keep) {
-    constexpr int kMaxWords = 8;                           // up to 64*64*8 = 32768 boxes
+    constexpr int kRows = kMaxWords <= 2 ? 16 : (kMaxWords <= 4 ? 8 : 4);       // kept rows whose mask rows are loaded together
     mask += (int64_t)blockIdx.x * n * col_blocks;          // batched launch: one wavefront per box set
     keep += (int64_t)blockIdx.x * n;
     uint64_t remv[kMaxWords];
@@ -93,15 +96,15 @@ __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict
         // OR the kept rows into the later blocks' removed-words
         uint64_t km = kept;
         while (km) {
-            int rows[4];
+            int rows[kRows];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kRows; ++q) {
                 rows[q] = km ? __builtin_ctzll(km) : -1;
                 km &= km - 1;                              // (0 & anything stays 0)
             }
-            uint64_t v[4][kMaxWords];
+            uint64_t v[kRows][kMaxWords];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kRows; ++q) {
                 const uint64_t* p = mask + (int64_t)(c * 64 + (rows[q] < 0 ? 0 : rows[q])) * col_blocks;
 #pragma unroll
                 for (int w = 0; w < kMaxWords; ++w) {
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < kRows; ++q)
 #pragma unroll
                 for (int w = 0; w < kMaxWords; ++w) remv[w] |= v[q][w];
         }
@@ -157,8 +160,12 @@ extern "C" int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int
     if (col_blocks > 8192) return -5;                      // 524,288 boxes: the big walk's removed-words fill 64 KB of LDS (and the mask 34 GB)
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, sets), dim3(64), 0, s, boxes_sorted, n, thresh, strict, mask_ws);
-    if (col_blocks <= 64 * 8)
-        hipLaunchKernelGGL(nms_walk_kernel, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    if (col_blocks <= 64 * 2)
+        hipLaunchKernelGGL(nms_walk_kernel<2>, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    else if (col_blocks <= 64 * 4)
+        hipLaunchKernelGGL(nms_walk_kernel<4>, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    else if (col_blocks <= 64 * 8)
+        hipLaunchKernelGGL(nms_walk_kernel<8>, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
     else
         hipLaunchKernelGGL(nms_walk_big_kernel, dim3(sets), dim3(64), (size_t)col_blocks * 8, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
     return (int)hipGetLastError();
