@@ -89,6 +89,9 @@ _SIGS = {
     "drc_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, C.c_int64, _P]),
     "drc_conv3d_k3_wino_rb_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_conv3d_k3_wino_rb_supported": (_I, [_I, _I, _I, _I]),
+    "drc_conv2d_k3_wino_rb_supported": (_I, [_I, _I, _I]),
+    "drc_conv2d_k3_wino_rb_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_pack_weights_wino2d_rb": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_conv3d_k3_wino_rb_costvol_fwd": (_I, [C.POINTER(DrcTapconvParams), C.POINTER(DrcCostvolSrc), _P]),
     "drc_pack_weights_wino_rb": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_box_decode_fwd": (_I, [_P, _P, _P, C.c_int64, _I, _I, _P, C.c_float, C.c_float, C.c_float, _P]),

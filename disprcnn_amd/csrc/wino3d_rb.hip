@@ -60,8 +60,12 @@ namespace {
 // materialised volume the items read the blocked 2D feature maps -- channel blocks < cbi from the left map at (y, x), the others from the
 // right map at (y, x - i), i = lo4 + slice -- and a load whose voxel is outside the volume or fails 0 <= x - i < W' is pointed at halo
 // column 0 of its row (zero).
-template <int TW, bool CV>
+// D2 = the 2D form (Conv2d 3x3, stride 1, pad 1 as Winograd F(2x2, 3x3); reference submodule.py:13-17 `convbn`, backbone/resnet.py): one
+// "slice" (no depth butterfly), 16 frequency points, a tile's accumulators go straight from the in-plane inverse to the epilogue.
+// Bit-identical to wino2d.hip.
+template <int TW, bool CV, bool D2>
 __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, const drc_costvol_src& cv, int NS) {
+    static_assert(!(CV && D2), "the fused cost volume is a 3D input");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SB = 256 * TW;                   // bytes per row slot: [xw 4][g 4][wt TW] float4
     constexpr int XWS = 64 * TW;                   // bytes per w-frequency plane of a slot
@@ -80,7 +84,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     // Maps wider than 2 TW columns (Config B's 56-wide volume at TW = 14) are walked as WS side-by-side strips of TW tile columns: a
     // "slab" is the (n, depth tile, strip) plane of TH tile rows, tiles run (n, dt, strip, ht, wt) -- everything below sees TW-wide maps
     // whose columns start at strip * 2 TW (the strips share their boundary columns like tiles do).
-    const int TD = p.OD >> 1, TH = p.OH >> 1, WS = (p.OW >> 1) / TW;
+    const int TD = D2 ? 1 : p.OD >> 1, TH = p.OH >> 1, WS = (p.OW >> 1) / TW;
     const int tiles = p.N * TD * WS * TH * TW;
     const int rows_total = p.N * TD * WS * TH;
     const int chunks = (tiles + 63) >> 6;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
-                r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
+                if constexpr (!D2) r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
             }
         }
     };
@@ -219,8 +223,12 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         f32x4 d[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            d[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); d[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
-            d[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); d[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
+            if constexpr (D2) {
+                d[w] = r.a[w];
+            } else {
+                d[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); d[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
+                d[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); d[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
+            }
         }
         char* dst = bb + it.loff;
         *(f32x4*)(dst + 0 * XWS) = d[0] - d[2];
@@ -335,7 +343,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         return;
 #endif
         // the last frequency: the residual's eight float4 are requested first, so that they travel under the inverse transform
-        const bool last = xd_ == 3 && geo.valid;
+        const bool last = (D2 || xd_ == 3) && geo.valid;
         const int ct = ct0 + ctl;
         f32x4 rv[8];
         int64_t yo = 0;
@@ -346,7 +354,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                 const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)(2 * geo.dt) * p.r_d_stride + (int64_t)(2 * geo.ht) * p.r_h_stride +
                                    (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.r_cb_stride;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < (D2 ? 4 : 8); ++i)
                     rv[i] = *(const f32x4*)(p.res + ro + (i >> 2) * p.r_d_stride + ((i >> 1) & 1) * p.r_h_stride + (i & 1) * 16);
             }
         }
@@ -360,6 +368,21 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
             }
             inv[0] = hh[0][0] + hh[0][1] + hh[0][2]; inv[1] = hh[0][1] - hh[0][2] - hh[0][3];
             inv[2] = hh[1][0] + hh[1][1] + hh[1][2]; inv[3] = hh[1][1] - hh[1][2] - hh[1][3];
+        }
+        if constexpr (D2) {
+            if (!last) return;
+            const f32x4 bn_sc = *(const f32x4*)(p.scale + ct * 16 + g * 4);
+            const f32x4 bn_sh = *(const f32x4*)(p.shift + ct * 16 + g * 4);
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                for (int ow = 0; ow < 2; ++ow) {
+                    f32x4 v_ = inv[oh * 2 + ow] * bn_sc + bn_sh;
+                    if (p.res) v_ += rv[oh * 2 + ow];
+                    if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
+                    *(f32x4*)(p.y + yo + oh * p.y_h_stride + ow * 16) = v_;
+                }
+            return;
         }
         if (xd_ == 0) {
 #pragma unroll
@@ -395,7 +418,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 
     struct Cursor { int round, xd, cb; };
     auto advance = [&](Cursor c) __attribute__((always_inline)) {
-        if (++c.cb == p.cb_in) { c.cb = 0; if (++c.xd == 4) { c.xd = 0; ++c.round; } }
+        if (++c.cb == p.cb_in) { c.cb = 0; if (D2 || ++c.xd == 4) { c.xd = 0; ++c.round; } }
         return c;
     };
 
@@ -453,7 +476,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         ++stepno;
     };
 #pragma unroll 1
-    for (int ph = 0; ph < rounds * 4; ++ph) {
+    for (int ph = 0; ph < rounds * (D2 ? 1 : 4); ++ph) {
         do_step(std::true_type{});
 #pragma unroll 1
         for (int c = 1; c < p.cb_in; ++c) do_step(std::false_type{});
@@ -463,12 +486,17 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 
 template <int TW>
 __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_tapconv_params p, int NS) {
-    wino3d_rb_body<TW, false>(p, drc_costvol_src{}, NS);
+    wino3d_rb_body<TW, false, false>(p, drc_costvol_src{}, NS);
 }
 
 template <int TW>
 __global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_cv_kernel(const drc_tapconv_params p, const drc_costvol_src cv, int NS) {
-    wino3d_rb_body<TW, true>(p, cv, NS);
+    wino3d_rb_body<TW, true, false>(p, cv, NS);
+}
+
+template <int TW>
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino2d_rb_kernel(const drc_tapconv_params p, int NS) {
+    wino3d_rb_body<TW, false, true>(p, drc_costvol_src{}, NS);
 }
 
 // slots a 64-tile chunk can touch: two per tile row plus two per slab
@@ -480,7 +508,7 @@ inline int rb_slots(int TW, int TH) {
 }
 
 template <int TW>
-int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_t stream) {
+int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_t stream, bool d2 = false) {
     const int NS = rb_slots(TW, p.OH / 2);
     const size_t lds = RB_RING_BYTES + (size_t)2 * NS * 256 * TW;
     if (lds > 163840 || NS * TW * 4 > 1024) return -4;
@@ -488,16 +516,19 @@ int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)wino3d_rb_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino3d_rb_cv_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wino2d_rb_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long tiles = (long)p.N * (p.OD / 2) * (p.OH / 2) * (p.OW / 2);
+    const long tiles = (long)p.N * (d2 ? 1 : p.OD / 2) * (p.OH / 2) * (p.OW / 2);
     const long chunks = (tiles + 63) / 64;
     const int n_cg = p.cout_pad / 32;
     long per_cg = 256 / n_cg;                      // one block (8 waves, up to 160 KB of LDS) per CU
     if (per_cg > chunks) per_cg = chunks;
     if (per_cg < 1) per_cg = 1;
-    if (cv)
+    if (d2)
+        hipLaunchKernelGGL((wino2d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
+    else if (cv)
         hipLaunchKernelGGL((wino3d_rb_cv_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, *cv, NS);
     else
         hipLaunchKernelGGL((wino3d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
@@ -549,6 +580,39 @@ __global__ __launch_bounds__(256) void wino_weights_rb_kernel(const float* __res
     }
 }
 
+// the 2D weights: U = (G x G) g in the rb packing with 16 frequency points [xh*4 + xw][cb][cout tile][ch / 4][cout % 16][ch % 4]
+__global__ __launch_bounds__(256) void wino2d_weights_rb_kernel(const float* __restrict__ w, int cout, int cin, int transposed, int flip,
+                                                                float* __restrict__ out) {
+    const int cb_n = (cin + 15) / 16, cout_pad = (cout + 31) / 32 * 32;
+    const long pairs = (long)cb_n * cout_pad * 16;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < pairs; idx += (long)gridDim.x * 256) {
+        long t = idx;
+        const int s = (int)(t & 3); t >>= 2;
+        const int jj = (int)(t & 15); t >>= 4;
+        const int gq = (int)(t & 3); t >>= 2;
+        const int ctile = (int)(t % (cout_pad / 16));
+        const int cb = (int)(t / (cout_pad / 16));
+        const int co = ctile * 16 + jj, ci = cb * 16 + gq * 4 + s;
+        const bool live = co < cout && ci < cin;
+        const float* src = w + (transposed ? ((long)ci * cout + co) : ((long)co * cin + ci)) * 9;
+        float a[3][3], b[3][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k / 3][k % 3] = live ? src[flip ? 8 - k : k] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float g0 = a[kh][0], g1 = a[kh][1], g2 = a[kh][2];
+            b[kh][0] = g0; b[kh][1] = 0.5f * (g0 + g1 + g2); b[kh][2] = 0.5f * (g0 - g1 + g2); b[kh][3] = g2;
+        }
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) {
+            const float g0 = b[0][xw], g1 = b[1][xw], g2 = b[2][xw];
+            const float u[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
+#pragma unroll
+            for (int xh = 0; xh < 4; ++xh) out[(long)(xh * 4 + xw) * pairs + idx] = u[xh];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int OW) {
@@ -587,6 +651,36 @@ extern "C" int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* str
 extern "C" int drc_conv3d_k3_wino_rb_costvol_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void* stream) {
     if (!cv) return -1;
     return rb_fwd(pp, cv, stream);
+}
+
+extern "C" int drc_conv2d_k3_wino_rb_supported(int cout_pad, int OH, int OW) {
+    return drc_conv3d_k3_wino_rb_supported(cout_pad, 2, OH, OW);
+}
+
+extern "C" int drc_conv2d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD != 1 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (p.cout_pad <= 0 || (p.cout_pad & 31) || p.cb_in <= 0) return -2;
+    const drc_tap_class& k = p.cls[0];
+    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 1 || k.nh != 3 || k.nw != 3 || k.sh != 1 || k.sw != 1) return -4;
+    if (!drc_conv2d_k3_wino_rb_supported(p.cout_pad, p.OH, p.OW)) return -4;
+    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;
+    if ((int64_t)p.N * p.OH * p.OW / 4 >= (1LL << 31) - 64 || (int64_t)16 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
+    hipStream_t s = (hipStream_t)stream;
+    return p.OW == 14 ? launch_rb<7>(p, nullptr, s, true) : launch_rb<14>(p, nullptr, s, true);
+}
+
+extern "C" int drc_pack_weights_wino2d_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream) {
+    if (cout <= 0 || cin <= 0) return -2;
+    if (!w || !out) return -1;
+    const long pairs = (long)((cin + 15) / 16) * ((cout + 31) / 32 * 32) * 16;
+    long blocks = (pairs + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wino2d_weights_rb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, cout, cin, transposed, flip, out);
+    return (int)hipGetLastError();
 }
 
 extern "C" int drc_pack_weights_wino_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream) {

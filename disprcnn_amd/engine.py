@@ -280,6 +280,20 @@ def pack_weight_wino_rb(w, transposed=False, flip=False):
     return out
 
 
+def pack_weight_wino2d_rb(w, transposed=False, flip=False):
+    """The 2D transformed weights in the packing of wino3d_rb.hip's 2D form: [16][cb_in][cout tile][ch / 4][cout % 16][ch % 4]."""
+    w = w.detach().contiguous().float()
+    require_gpu(w, "pack_weight_wino2d_rb")
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("pack_weight_wino2d_rb expects a 3x3 kernel")
+    a, b = w.shape[:2]
+    cout, cin = (b, a) if transposed else (a, b)
+    out = torch.empty(16, (cin + CB - 1) // CB, (cout + 31) // 32 * 32, 16, dtype=torch.float32, device=w.device)
+    st = _lib.lib().drc_pack_weights_wino2d_rb(_ptr(w), cout, cin, int(transposed), int(flip), _ptr(out), _stream_ptr(w.device))
+    _lib.check(st, "drc_pack_weights_wino2d_rb")
+    return out
+
+
 def pack_weight_wino2d(w, transposed=False, flip=False):
     """3x3 weights [Cout,Cin,3,3] (or [Cin,Cout,3,3] with transposed; flip reverses the taps) -> Winograd F(2,3)^2 transformed
     [16 frequency points][cb_in][cout_pad][16] (drc_pack_weights_wino2d): the packing of wino2d.hip."""
@@ -500,15 +514,15 @@ class ConvPlan:
     def pack_kind(self):
         """Name of the weight packing pack16 returns (a layer may run under plans of several kinds: one packing is kept per kind)."""
         if self.wino:
-            return "wino2d" if self.c2d else ("wino_rb" if self.rb else "wino")
+            return ("wino2d_rb" if self.rb else "wino2d") if self.c2d else ("wino_rb" if self.rb else "wino")
         return "deconv_direct" if self.deconv_direct else ("t16" if self.needs_t16 else "tap")
 
     def pack16(self, w, transposed=False, flip=False, kind=None):
         """The weight packing this plan's LDS-free kernel reads (None when the plan runs an LDS-staged kernel)."""
         if kind == "wino":
             return pack_weight_wino(w, transposed, flip)
-        if self.wino and self.rb and not self.c2d:
-            return pack_weight_wino_rb(w, transposed, flip)
+        if self.wino and self.rb:
+            return pack_weight_wino2d_rb(w, transposed, flip) if self.c2d else pack_weight_wino_rb(w, transposed, flip)
         if self.wino:
             return pack_weight_wino2d(w, transposed, flip) if self.c2d else pack_weight_wino(w, transposed, flip)
         if self.deconv_direct:
@@ -545,7 +559,10 @@ class ConvPlan:
             e0.record(torch.cuda.current_stream(self.device))
         if (w.dim() == 3) != self.pointwise:
             raise ValueError("weights are not in the packing this plan expects (engine.pack_conv_weight)")
-        if self.wino and self.c2d:
+        if self.wino and self.c2d and self.rb:
+            st = _lib.lib().drc_conv2d_k3_wino_rb_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_conv2d_k3_wino_rb_fwd")
+        elif self.wino and self.c2d:
             st = _lib.lib().drc_conv2d_k3_wino_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv2d_k3_wino_fwd")
         elif self.direct and self.c2d:
@@ -641,6 +658,8 @@ WINO = {"enabled": True,      # stride-1 3x3x3 layers with even output dims as W
         "rb": True,           # 28- and 14-wide maps: the two-waves-per-SIMD row-brick kernel (wino3d_rb.hip) ...
         "rb_min_chunks": 256} # ... when every CU gets at least one (64-tile chunk, 32-cout group) unit
 WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
+          "rb": False, "rb_min_chunks": 256,  # the row-brick kernel's 2D form (widths 14 or multiples of 28): bit-identical, measured equal
+                                              # (32 crops: 70.7 vs 77.2 us at 32ch@112^2, 198 vs 201 at 128ch@56^2, 442 vs 404 at 320->128) -> off
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
 DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
@@ -810,6 +829,11 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
             pl.wino = True
             pl.slide_ct = wct
             pl.kname = "wino2d_kernel<%d>" % wct
+            chunks = x.N * (y.H // 2) * (y.W // 2) // 64
+            if (WINO2D.get("rb") and chunks * (pl.p.cout_pad // 32) >= WINO2D["rb_min_chunks"]
+                    and _lib.lib().drc_conv2d_k3_wino_rb_supported(pl.p.cout_pad, y.H, y.W)):
+                pl.rb = True
+                pl.kname = "wino2d_rb_kernel<%d>" % (7 if y.W == 14 else 14)
     elif k == 3 and stride == 1 and pad == dilation and TAP2D["enabled"]:
         tile = choose_tile_2d(y.H, y.W, dilation)
         if tile is not None:

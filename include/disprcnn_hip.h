@@ -167,6 +167,12 @@ int drc_conv3d_k3_wino_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave,
 int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int OW);
 int drc_conv3d_k3_wino_rb_fwd(const drc_tapconv_params* p, void* stream);
 int drc_pack_weights_wino_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream);
+/* The 2D form of the row-brick kernel: Conv2d 3x3 / stride 1 / pad 1 as Winograd F(2x2, 3x3) (same parameter block and results as
+ * drc_conv2d_k3_wino_fwd: bit-identical), for 14-wide maps and widths that are multiples of 28 (the PSMNet feature CNN's 112- and
+ * 56-wide maps); weights from drc_pack_weights_wino2d_rb: [16][ceil(Cin/16)][cout_pad/16][ch/4][cout%16][ch%4], cout padded to 32. */
+int drc_conv2d_k3_wino_rb_supported(int cout_pad, int OH, int OW);
+int drc_conv2d_k3_wino_rb_fwd(const drc_tapconv_params* p, void* stream);
+int drc_pack_weights_wino2d_rb(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream);
 
 /* Source of a cost volume that is never materialised: the two channel-blocked, zero-haloed 2D feature maps of N ROI pairs /
  * image pairs.  Voxel (n, cb, y, x) of a side lives at side + n*n_stride + cb*cb_stride + (y+pad)*h_stride + (x+pad)*16 (floats);

@@ -310,6 +310,39 @@ def test_conv2d_winograd_kernel_vs_oracle(dev, n, cin, cout, hw, with_res):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("n,cin,cout,hw,with_res,expect_rb", [
+    (3, 32, 32, (112, 112), True, True),         # firstconv / layer1 of the PSMNet feature CNN: four strips of 14 tile columns
+    (2, 64, 64, (56, 56), False, True),          # layer2: two strips, two cout groups
+    (2, 320, 128, (56, 56), True, True),         # lastconv[0]: 20 channel blocks, four cout groups
+    (5, 20, 40, (6, 28), True, False),           # cout padded to 48: not a multiple of 32 -> wino2d.hip
+    (3, 48, 64, (10, 14), False, True),          # a 14-wide map (TW = 7), TH = 5
+    (2, 32, 32, (30, 60), True, False)])         # a width the row-brick kernel is not built for
+def test_conv2d_winograd_rowbrick_kernel(dev, n, cin, cout, hw, with_res, expect_rb):
+    """The 2D form of wino3d_rb.hip (round 3; Conv2d 3x3 of submodule.py:13-17 on the 112- / 56-wide maps of the feature CNN) against the
+    direct convolution and, bit for bit, against wino2d.hip."""
+    from disprcnn_amd import ops, engine as E
+    x = synth.hash_uniform(f"RB2{cin}{cout}{hw}:x", (n, cin) + hw)
+    w = synth.hash_uniform(f"RB2{cin}{cout}:w", (cout, cin, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("RB2:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("RB2:b", (cout,), -0.5, 0.5)
+    res = synth.hash_uniform(f"RB2{cout}{hw}:r", (n, cout) + hw) if with_res else None
+    ref = F.conv2d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref + res) if with_res else ref
+    saved = (E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"])
+    got = {}
+    try:
+        for rb in (True, False):
+            E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"] = True, 0, rb, 0
+            xb = E.Blocked(n, cin, 1, *hw, 0, 1, 1, dev)
+            plan = E.plan_conv2d(xb, E.Blocked(n, cout, 1, *hw, 0, 1, 1, dev), 3, 1, 1, 1, cout, True)
+            assert plan.wino and plan.c2d and plan.rb == (rb and expect_rb), (plan.kname, rb)
+            got[rb] = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, 1, 1, with_res, res.to(dev) if with_res else None)
+    finally:
+        E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"] = saved
+    _close(got[True], ref)
+    assert torch.equal(got[True], got[False]), (got[True] - got[False]).abs().max().item()
+
+
 def test_winograd2d_weight_transform_vs_oracle(dev):
     """drc_pack_weights_wino2d against U = (G x G) g in float64, incl. the in/out swap and tap flip of the data gradient."""
     from disprcnn_amd import engine as E
