@@ -32,6 +32,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define RB_WAVES 8
 #define RB_RING_BYTES 32768
+#ifndef RB_PAIR
+#define RB_PAIR 0              // 1: staging items of one column pair, the neighbour's pair fetched with ds_bpermute (half the loads;
+                               //    bit-identical, measured 3-6 % slower: the exchange puts an LDS round trip into every item)
+#endif
 #ifdef RB_ABL_NOBARRIER
 #define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
@@ -134,7 +138,11 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     // one column PAIR with the neighbour's pair fetched by ds_bpermute / DPP -- half the loads, the same time; loads issued a half step
     // ahead or right before the barriers -- the wait is the LDS-DMA ring fill, not the loads; L2-warming touches -- slower: every extra
     // vector-memory instruction costs its issue slot behind the other seven waves' requests.)
-    struct Item { unsigned goff, loff; bool valid; int x0, d0; };       // x0, d0 (CV): volume column / slice of the patch origin
+    constexpr bool kPair = RB_PAIR != 0;
+    constexpr int kCols = kPair ? 2 : 4;           // columns an item loads
+    constexpr int PPS = TW + 1 <= 8 ? 8 : 16;      // pair mode: column pairs per slot (padded), slots per wave item
+    constexpr int SPW = 16 / PPS;
+    struct Item { unsigned goff, loff; bool valid, live; int x0, d0; };   // x0, d0 (CV): volume column / slice of the patch origin; live: wave-uniform
     auto item_of = [&](int round, int k) __attribute__((always_inline)) {
         Item it;
         const int chunk = round * nbk + pos;
@@ -143,10 +151,24 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         const int R0 = t0 / TW, R1 = t1 / TW;
         int nslots = 2 * (R1 - R0) + 2 * (R1 / TH - R0 / TH) + 4;
         nslots = nslots > NS ? NS : nslots;
-        const int q = (int)threadIdx.x + 512 * k;
-        it.valid = q < nslots * TW * 4;
-        const int s0 = q / (4 * TW), rem = q - s0 * (4 * TW);
-        const int wt = rem >> 2, gq = rem & 3;
+        int s0, wt, gq;
+        if constexpr (kPair) {
+            // a wave item (wave + 8k) = one slot of 16 column pairs (TW = 14) or two slots of 8 (TW = 7); lane = pair * 4 + quad, so lane + 4
+            // is the next pair of the same slot; pair TW only feeds its neighbour; every lane of a live wave item loads
+            s0 = (wave + 8 * k) * SPW + (SPW == 2 ? lane >> 5 : 0);
+            const int cp = (lane >> 2) & (PPS - 1);
+            gq = lane & 3;
+            it.valid = s0 < nslots && cp < TW;
+            it.live = __builtin_amdgcn_readfirstlane((wave + 8 * k) * SPW < nslots);
+            wt = cp < TW ? cp : TW;
+        } else {
+            const int q = (int)threadIdx.x + 512 * k;
+            it.valid = q < nslots * TW * 4;
+            it.live = true;
+            s0 = q / (4 * TW);
+            const int rem = q - s0 * (4 * TW);
+            wt = rem >> 2; gq = rem & 3;
+        }
         // slot -> (tile row relative to R0, patch row h): two slots per tile row plus two per slab touched
         int s = s0 < nslots ? s0 : nslots - 1;
         int left = TH - R0 % TH, base = 0, rel = 0, h = 0;
@@ -176,17 +198,17 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                                   (int64_t)(2 * wg + cls.dw0) * 16 + gq * 4) * 4);
             it.x0 = it.d0 = 0;
         }
-        it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + wt * 16);
+        it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + (wt < TW ? wt : 0) * 16);
         return it;
     };
-    struct Raw { f32x4 a[4], b[4]; };
+    struct Raw { f32x4 a[kCols], b[kCols]; };
     // (all uniform offsets are 32-bit: the launcher checks N * x_n_stride * 4 < 2^32 and the packed weights < 2^31 floats)
     const unsigned xcb4 = (unsigned)p.x_cb_stride * 4u, xd4 = (unsigned)p.x_d_stride * 4u;
     auto stage_issue = [&](const Item& it, int xd, int cb, Raw& r) __attribute__((always_inline)) {
 #ifdef RB_ABL_NOSTAGE
         return;
 #endif
-        if (!it.valid) return;
+        if (kPair ? !it.live : !it.valid) return;
         if constexpr (CV) {
             const bool right = cb >= cv.cbi;                                      // wave-uniform
             const char* base = (const char*)((right ? cv.right : cv.left) + (int64_t)(right ? cb - cv.cbi : cb) * cv.cb_stride);
@@ -196,7 +218,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                 const bool ind = (unsigned)d < (unsigned)p.OD;
                 const int sh = right ? cv.lo4 + d : 0;                              // the right map is read at x - i
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < kCols; ++w) {
                     const int x = it.x0 + w;
                     const bool ok = ind && (unsigned)x < (unsigned)cv.Wp && (unsigned)(x - cv.lo4 - d) < (unsigned)cv.Wp;
                     const unsigned off = it.goff + (ok ? (unsigned)((x - sh + cv.pad) * 64) : 0u);
@@ -207,7 +229,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
             const char* sa = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_a(xd) * xd4);
             const char* sb = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_b(xd) * xd4);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < kCols; ++w) {
                 r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
                 if constexpr (!D2) r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
             }
@@ -218,17 +240,25 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #ifdef RB_ABL_NOSTAGE
         return;
 #endif
-        if (!it.valid) return;
+        if (kPair ? !it.live : !it.valid) return;
         const float sgn = xd == 1 ? 1.f : -1.f;
         f32x4 d[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < kCols; ++w) {
             if constexpr (D2) {
                 d[w] = r.a[w];
             } else {
                 d[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); d[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
                 d[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); d[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
             }
+        }
+        if constexpr (kPair) {          // the next pair's columns from lane + 4 (scalars by value: __builtin_bit_cast on a vector-ELEMENT
+            auto nl = [&](float v) __attribute__((always_inline)) {            // lvalue reads element 0 with this hipcc)
+                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 4) & 63) * 4, __builtin_bit_cast(int, v)));
+            };
+#pragma unroll
+            for (int w = 0; w < 2; ++w) { d[2 + w].x = nl(d[w].x); d[2 + w].y = nl(d[w].y); d[2 + w].z = nl(d[w].z); d[2 + w].w = nl(d[w].w); }
+            if (!it.valid) return;
         }
         char* dst = bb + it.loff;
         *(f32x4*)(dst + 0 * XWS) = d[0] - d[2];
