@@ -662,6 +662,7 @@ WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (w
                                               # (32 crops: 70.7 vs 77.2 us at 32ch@112^2, 198 vs 201 at 128ch@56^2, 442 vs 404 at 320->128) -> off
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
+CONV2D_FILL = {"enabled": True}   # 3x3 Conv2d tile choice: trade MFMA padding for waves when a layer cannot fill the 1024 SIMDs
 DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
 DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/exp_conv.py)
         "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)
@@ -805,11 +806,16 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
     if k == 3 and DIRECT["enabled"] and DIRECT.get("conv2d", True):
         # LDS-free kernel: any stride (1|2) and dilation; the tile only has to give full voxel tiles
         best = None
+        ct_ = pl.p.cout_pad // 16
         for r in range(1, min(y.H, MAX_SLOTS) + 1):
             for wt in range(1, min(y.W, MAX_SLOTS // r) + 1):
                 nvt_ = -(-(r * wt) // 16)
+                ntile = x.N * (-(-y.H // r)) * (-(-y.W // wt))
                 waste = (-(-y.H // r)) * (-(-y.W // wt)) * nvt_ * 16 / (y.H * y.W)
-                key = (-round(waste, 2), r * wt, wt)
+                # small maps with many channels (the trunk's 512 -> 512 layers on 12 x 39: 12 whole-row tiles x 32 cout tiles = 384 waves for
+                # 1024 SIMDs, each walking K = 4608): a smaller tile that fills the chip beats the one with the least padding (round 3)
+                fill = min(1.0, ntile * ct_ / 1024.0) if CONV2D_FILL["enabled"] else 1.0
+                key = (round(fill / waste, 2), r * wt, wt)
                 if best is None or key > best[0]:
                     best = (key, r, wt)
         pl.c2d, pl.direct = True, True
