@@ -108,6 +108,9 @@ int launch(const drc_tapconv_params& p, hipStream_t s) {
 
 }  // namespace
 
+#ifndef PW_SMALL_WAVES
+#define PW_SMALL_WAVES 1024
+#endif
 extern "C" int drc_conv2d_k1_fwd(const drc_tapconv_params* pp, void* stream) {
     if (!pp) return -1;
     const drc_tapconv_params& p = *pp;
@@ -123,6 +126,9 @@ extern "C" int drc_conv2d_k1_fwd(const drc_tapconv_params* pp, void* stream) {
     // 4x4 tiles (64 voxels x 64 couts, 64 MFMAs per 8 loads) when that still gives >= 2 waves per SIMD; smaller otherwise
     if (ct % 4 == 0 && tiles / 4 * (ct / 4) >= 2048) return launch<4, 4>(p, s);
     if (ct % 2 == 0 && tiles / 4 * (ct / 2) >= 2048) return launch<4, 2>(p, s);
-    if (ct % 2 == 0) return launch<2, 2>(p, s);
-    return launch<2, 1>(p, s);
+    // small maps with many channels (the trunk's 2048 -> 512 / 256 layers on 12 x 39: 30 voxel pairs x 16 cout pairs = 480 waves, each
+    // walking K = 2048): one tile per wave fills the 1024 SIMDs (round 3)
+    if (ct % 2 == 0 && (tiles / 2 * (ct / 2) >= PW_SMALL_WAVES || (long)p.cb_in < 16)) return launch<2, 2>(p, s);
+    if (tiles / 2 * ct >= PW_SMALL_WAVES) return launch<2, 1>(p, s);
+    return launch<1, 1>(p, s);
 }

@@ -857,8 +857,16 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
         pl.pointwise = True
         ct = pl.p.cout_pad // 16
         tiles = -(-(x.N * y.H * y.W) // 16)
-        vc = (4, 4) if ct % 4 == 0 and tiles // 4 * (ct // 4) >= 2048 else (4, 2) if ct % 2 == 0 and tiles // 4 * (ct // 2) >= 2048 else \
-            (2, 2) if ct % 2 == 0 else (2, 1)
+        if ct % 4 == 0 and tiles // 4 * (ct // 4) >= 2048:
+            vc = (4, 4)
+        elif ct % 2 == 0 and tiles // 4 * (ct // 2) >= 2048:
+            vc = (4, 2)
+        elif ct % 2 == 0 and (tiles // 2 * (ct // 2) >= 1024 or x.cb < 16):        # mirrors drc_conv2d_k1_fwd's choice
+            vc = (2, 2)
+        elif tiles // 2 * ct >= 1024:
+            vc = (2, 1)
+        else:
+            vc = (1, 1)
         pl.kname = "pointwise_kernel<%d,%d>" % vc
     return pl
 

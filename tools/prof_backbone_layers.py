@@ -39,3 +39,13 @@ tot = sum(a[1] for a in agg.values())
 for k, a in agg.items():
     print(f"{k:10s} calls/iter {a[0]//3:3d}  ms/iter {a[1]/3:6.2f}  {100*a[1]/tot:5.1f}%  {a[2]/a[1]/1e9:6.1f} TF")
 print("total conv ms/iter", tot / 3)
+# per-layer list (sorted by time): name, kernel, geometry, us, TF
+rows = collections.OrderedDict()
+for i, (kname, flops, e0, e1) in enumerate(E.TIMING):
+    nm = order[i % per]
+    r = rows.setdefault(nm, [kname, 0.0, flops])
+    r[1] += e0.elapsed_time(e1) / 3
+if os.environ.get("LAYERS"):
+    for nm, (kname, ms, flops) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:int(os.environ["LAYERS"])]:
+        pl = ws["p"][nm]
+        print(f"{nm:28s} {kname:30s} N={pl.p.N} {pl.p.cb_in*16:4d}->{pl.p.cout_pad:4d} {pl.p.OH}x{pl.p.OW} R={pl.p.R} WT={pl.p.WT}: {ms*1e3:7.1f} us {flops/ms/1e9:6.1f} TF")
