@@ -6,9 +6,27 @@ from ... import _lib
 from ... import engine as E
 
 
+def _stem_s2d_weight(w):
+    """The 7x7 stride-2 pad-3 stem as a 4x4 stride-1 conv over the 2x2 pixel-unshuffled image (resnet.py:274-290 computes the same sums):
+    input row 2(Y+ty)+dy with ky-3 = 2ty+dy, ty in -2..1, so w'[o][4c+2dy+dx][ty+2][tx+2] = w[o][c][2(ty+2)+dy-1][2(tx+2)+dx-1]
+    (zero where that index is -1).  12 channels x 16 taps = 64 MFMA k-steps a tile instead of 49 taps x 16 padded channels = 196."""
+    co, ci = w.shape[:2]
+    out = w.new_zeros(co, ci, 2, 2, 4, 4)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            for a in range(4):
+                for b in range(4):
+                    ky, kx = 2 * a + dy - 1, 2 * b + dx - 1
+                    if ky >= 0 and kx >= 0:
+                        out[:, :, dy, dx, a, b] = w[:, :, ky, kx]
+    return out.reshape(co, ci * 4, 4, 4)
+
+
 class _Site:
-    def __init__(self, conv, bn, device):
+    def __init__(self, conv, bn, device, weight_fn=None):
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
+        if weight_fn is not None:
+            w = weight_fn(w)
         self.w = E.pack_conv_weight(w)
         self.w16 = E.pack_weight_t16(w) if tuple(w.shape[2:]) == (3, 3) else None      # 3x3 layers: LDS-free kernel's packing
         self._weight, self._ww = w, None
@@ -51,7 +69,7 @@ class BackboneRuntime:
         if self._w is not None and v == self._ver:
             return self._w
         body, fpn, dev = self.model.body, self.model.fpn, self.device
-        W = {"stem": _Site(body.stem.conv1, body.stem.bn1, dev)}
+        W = {"stem": _Site(body.stem.conv1, body.stem.bn1, dev, _stem_s2d_weight)}
         for li in range(1, 5):
             for b, u in enumerate(getattr(body, f"layer{li}")):
                 p = f"l{li}.{b}"
@@ -71,10 +89,10 @@ class BackboneRuntime:
         dev, body = self.device, self.model.body
         B2 = lambda c, h, w, pad: E.Blocked(N, c, 1, h, w, 0, pad, pad, dev)
         t, p, sched = {}, {}, []
-        t["img"] = B2(3, H, W_, 3)
         h1, w1 = _half(H), _half(W_)                                    # 7x7 s2 p3
+        t["img"] = B2(12, h1, w1, 2)                                    # 2x2 pixel-unshuffled image (see _stem_s2d_weight)
         t["stem"] = B2(64, h1, w1, 0)
-        p["stem"] = E.plan_conv2d(t["img"], t["stem"], 7, 2, 3, 1, 64, True)
+        p["stem"] = E.plan_conv2d(t["img"], t["stem"], 4, 1, 2, 1, 64, True)
         # max_pool2d(3, 2, 0, ceil_mode=True): out = ceil((n-3)/2)+1, dropping a last window that would start outside
         ph, pw = -(-(h1 - 3) // 2) + 1, -(-(w1 - 3) // 2) + 1
         if (ph - 1) * 2 >= h1: ph -= 1
@@ -144,7 +162,9 @@ class BackboneRuntime:
             c = Wt[plan]
             p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None, w16=_w16_for(c, p[plan]))
 
-        t["img"].from_dense(x)
+        if (H | W_) & 1:
+            x = torch.nn.functional.pad(x, (0, W_ & 1, 0, H & 1))
+        t["img"].from_dense(torch.nn.functional.pixel_unshuffle(x, 2))
         conv("stem", "img", "stem")
         h1, w1, ph, pw = ws["pool"]
         _lib.check(lib.drc_maxpool2d_blocked(E._ptr(t["stem"].storage), E._ptr(t["pool"].storage), N, 4, h1, w1, 0, 3, 2, ph, pw, 0, sp),
