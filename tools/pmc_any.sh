@@ -1,0 +1,26 @@
+#!/bin/bash
+# pmc_any.sh "<command>" <kernel-name-substring>: per-kernel-name counter sums (development tool; run via gpurun)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_any
+rm -rf $OUT; mkdir -p $OUT
+CMD="$1"; export PMC_FILTER="$2"
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $set -d $OUT -o $tag -- $CMD > $OUT/$tag.log 2>&1
+done
+python - <<'PY'
+import csv, glob, collections, os
+flt = os.environ.get("PMC_FILTER", "")
+for f in sorted(glob.glob("gpurun_out/pmc_any/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if flt not in k: continue
+        k = k[-44:]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    for k, d in acc.items():
+        print(k, "launches", len(n[k]), {c: round(v / len(n[k])) for c, v in d.items()})
+PY

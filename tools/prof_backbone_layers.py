@@ -3,7 +3,9 @@ import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from types import SimpleNamespace as NS
-from disprcnn_amd import engine as E
+from disprcnn_amd import engine as E, _lib
+if os.environ.get("DRC_LIB"):
+    _lib.LIB_PATH = os.environ["DRC_LIB"]
 from disprcnn_amd.modeling.backbone import build_backbone
 from disprcnn_amd.utils import synth
 dev = torch.device("cuda:0")
