@@ -58,7 +58,7 @@ def _half(n):       # conv k1/k3 stride 2 (pad k//2) and max_pool2d(1,2,0): floo
 class BackboneRuntime:
     def __init__(self, model, device):
         self.model, self.device = model, device
-        self._w, self._ver, self._ws = None, None, {}
+        self._w, self._ver, self._ws, self._levels = None, None, {}, None
 
     def _version(self):
         return tuple(t._version for t in list(self.model.parameters()) + list(self.model.buffers())) + \
@@ -133,7 +133,7 @@ class BackboneRuntime:
             feat, fch, fhw = stage_out[i - 1]
             t[f"td{i}"] = B2(256, fhw[0], fhw[1], 0)
             t[f"sum{i}"] = B2(256, fhw[0], fhw[1], 1)
-            t[f"out{i}"] = B2(256, fhw[0], fhw[1], 1 if i > 1 else 0)
+            t[f"out{i}"] = B2(256, fhw[0], fhw[1], 1)                 # halo 1: FPN top-down reads out3/out2, the RPN head all levels
             p[f"inner{i}"] = E.plan_conv2d(t[feat], t[f"sum{i}"], 1, 1, 0, 1, 256, False)
             p[f"layer{i}"] = E.plan_conv2d(t[f"sum{i}"], t[f"out{i}"], 3, 1, 1, 1, 256, False)
             fsched.append(("resize", last, f"td{i}", lhw, fhw))
@@ -141,7 +141,7 @@ class BackboneRuntime:
             fsched.append(("conv", f"layer{i}", f"sum{i}", f"out{i}", None))
             outs[i - 1] = f"out{i}"
             last, lhw = f"out{i}", fhw                                  # reference: last_inner = layer_block(lateral + top_down)
-        t["p6"] = B2(256, _half(thw[0]), _half(thw[1]), 0)
+        t["p6"] = B2(256, _half(thw[0]), _half(thw[1]), 1)
         outs[4] = "p6"
         ws = dict(t=t, p=p, sched=sched, fsched=fsched, outs=outs, pool=(h1, w1, ph, pw), thw=thw,
                   flops=sum(pl.flops for pl in p.values()))
@@ -180,5 +180,11 @@ class BackboneRuntime:
                                                            t[dst].ph, 16, 0, 0, sp), "drc_bilinear_resize_blocked")
         th, tw = ws["thw"]
         _lib.check(lib.drc_maxpool2d_blocked(E._ptr(t["in4"].storage), E._ptr(t["p6"].storage), N, 16, th, tw, t["in4"].ph, 1, 2,
-                                             t["p6"].H, t["p6"].W, 0, sp), "drc_maxpool2d_blocked")
+                                             t["p6"].H, t["p6"].W, t["p6"].ph, sp), "drc_maxpool2d_blocked")
+        self._levels = [t[o] for o in ws["outs"]]
         return tuple(t[o].to_dense()[:, :, 0] for o in ws["outs"])
+
+    def blocked_levels(self):
+        """The pyramid of the LAST forward in the engine's blocked layout (halo 1), for consumers that run on the engine themselves
+        (the Stereo-RPN head): valid until the next forward overwrites the workspace."""
+        return self._levels

@@ -57,6 +57,8 @@ class DispRCNN(nn.Module):
         n = left_images.tensors.shape[0]
         feats = self.backbone(torch.cat((left_images.tensors, right_images.tensors), dim=0))
         left_features, right_features = [f[:n] for f in feats], [f[n:] for f in feats]
-        left_prop, right_prop, _ = self.rpn(left_images, right_images, left_features, right_features)
+        rt = getattr(self.backbone, "_rt", None)
+        levels = rt.blocked_levels() if rt is not None and hasattr(rt, "blocked_levels") else None
+        left_prop, right_prop, _ = self.rpn(left_images, right_images, left_features, right_features, blocked_levels=levels)
         _, left_result, right_result, _ = self.roi_heads(left_features, right_features, left_prop, right_prop)
         return {"left": left_result, "right": right_result}

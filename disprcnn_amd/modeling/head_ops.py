@@ -85,6 +85,60 @@ class EngineConv2d:
         return yb.to_dense()[:, :, 0]
 
 
+class BlockedConv2d:
+    """A convolution of the heads that stays in the engine's blocked layout: y_blocked = act(conv2d(x_blocked) + bias).  The weight is
+    the channel-wise (dim 0) concatenation of one or more nn.Conv2d layers of equal geometry -- sibling 1x1 predictors read their
+    shared input once -- packed when a parameter's version changes; launch plans are cached per geometry (they hold no memory)."""
+
+    MAX_PLANS = 16
+
+    def __init__(self, convs, relu):
+        self.convs = list(convs) if isinstance(convs, (list, tuple)) else [convs]
+        c = self.convs[0]
+        for o in self.convs:
+            if (o.kernel_size, o.stride, o.padding, o.dilation, o.in_channels, o.groups) != \
+                    (c.kernel_size, c.stride, c.padding, c.dilation, c.in_channels, 1):
+                raise NotImplementedError("BlockedConv2d: sibling layers must share their geometry (groups = 1)")
+        self.k, self.stride, self.pad, self.dil = c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0]
+        self.cout = sum(o.out_channels for o in self.convs)
+        self.relu = bool(relu)
+        self._ver, self._plans = None, OrderedDict()
+
+    def _weights(self, dev):
+        ver = tuple((o.weight._version, o.weight.data_ptr(), None if o.bias is None else o.bias._version) for o in self.convs) + (dev,)
+        if ver != self._ver:
+            w = torch.cat([o.weight.detach().to(device=dev, dtype=torch.float32) for o in self.convs], 0)
+            cp = E.cout_pad_of(w.shape[0])
+            self._wp = E.pack_conv_weight(w)
+            self._sc = torch.ones(cp, device=dev)
+            self._sh = torch.zeros(cp, device=dev)
+            off = 0
+            for o in self.convs:
+                if o.bias is not None:
+                    self._sh[off: off + o.out_channels] = o.bias.detach().to(device=dev, dtype=torch.float32)
+                off += o.out_channels
+            self._w32, self._ver, self._w16 = w, ver, {}
+        return self._wp, self._sc, self._sh
+
+    def out_hw(self, h, w):
+        f = lambda n: (n + 2 * self.pad - self.dil * (self.k - 1) - 1) // self.stride + 1
+        return f(h), f(w)
+
+    def __call__(self, xb, yb):
+        wp, sc, sh = self._weights(xb.device)
+        key = (xb.N, xb.C, xb.H, xb.W, xb.ph, xb.pw, xb.n_stride, yb.H, yb.W, yb.ph, yb.pw, yb.n_stride)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = E.plan_conv2d(xb, yb, self.k, self.stride, self.pad, self.dil, self.cout, self.relu)
+            while len(self._plans) > self.MAX_PLANS:
+                self._plans.popitem(last=False)
+        kind = plan.pack_kind
+        if kind not in self._w16:
+            self._w16[kind] = plan.pack16(self._w32)
+        plan.run(xb, wp, sc, sh, yb, None, w16=self._w16[kind])
+        return yb
+
+
 _PACKED_W = {}     # id(weight) -> (version key, packed tensor): the layer's weights in the GEMM's operand layout, rebuilt when they change
 
 

@@ -15,7 +15,7 @@ from ... import engine as E
 from ...structures.bounding_box import BoxList
 from ...structures.boxlist_ops import double_view_boxlist_nms
 from ..box_coder import BoxCoder
-from ..head_ops import EngineConv2d
+from ..head_ops import BlockedConv2d, EngineConv2d
 from .anchor_generator import make_anchor_generator
 
 
@@ -48,6 +48,9 @@ class StereoRPN(nn.Module):
         self._conv = EngineConv2d(self.head.conv, relu=True)
         self._cls = EngineConv2d(self.head.cls_logits, relu=False)
         self._reg = EngineConv2d(self.head.bbox_pred, relu=False)
+        self._bconv = BlockedConv2d(self.head.conv, relu=True)
+        self._bpred = BlockedConv2d([self.head.cls_logits, self.head.bbox_pred], relu=False)      # one read of the 1024-channel map
+        self._bws = {}
 
     # ------------------------------------------------------------------ head: raw maps per level
     def _head(self, left_features, right_features):
@@ -60,10 +63,49 @@ class StereoRPN(nn.Module):
             regs.append(self._reg(t))
         return logits, regs
 
-    def proposals_dense(self, left_images, left_features, right_features):
+    def _head_blocked(self, levels):
+        """The same maps from the backbone's blocked pyramid (units [left_0..left_n-1, right_0..right_n-1] of each level, halo 1)
+        without leaving the blocked layout.  The 3x3 convolution writes image i's left map into channel blocks 0..31 and its right map
+        into blocks 32..63 of unit i of one [n][1024-channel] tensor -- the concatenation the predictors read, for free -- and both
+        predictors run as one 1x1 convolution (2A + 6A outputs) over it."""
+        logits, regs = [], []
+        a2, c2 = self.head.cls_logits.out_channels, self.head.conv.out_channels
+        for xb in levels:
+            n, dev = xb.N // 2, xb.device
+            key = (n, xb.H, xb.W, dev)
+            ws = self._bws.get(key)
+            if ws is None:
+                t = E.Blocked(n, 2 * c2, 1, xb.H, xb.W, 0, 0, 0, dev)
+                half = (c2 // 16) * t.cb_stride                              # floats of one view's channel blocks within a unit
+                if n == 1:                                                   # units (left, right) are already adjacent: one launch
+                    pairs = [(xb, E.Blocked(2, c2, 1, xb.H, xb.W, 0, 0, 0, dev, storage=t.storage))]
+                else:
+                    pairs = []
+                    for side in (0, 1):
+                        xv = E.Blocked(n, xb.C, 1, xb.H, xb.W, 0, xb.ph, xb.pw, dev, storage=xb.storage[side * n * xb.n_stride:])
+                        yv = E.Blocked.geometry(n, c2, 1, xb.H, xb.W, 0, 0, 0, dev)
+                        yv.n_stride, yv.storage = t.n_stride, t.storage[side * half:]
+                        pairs.append((xv, yv))
+                ws = self._bws[key] = dict(t=t, pairs=pairs, o=E.Blocked(n, self._bpred.cout, 1, xb.H, xb.W, 0, 0, 0, dev), src=xb.storage.data_ptr())
+                while len(self._bws) > 16:
+                    self._bws.pop(next(iter(self._bws)))
+            if ws["src"] != xb.storage.data_ptr():                           # a different backbone workspace of the same geometry
+                self._bws.pop(key)
+                return self._head_blocked(levels)
+            for xv, yv in ws["pairs"]:
+                self._bconv(xv, yv)
+            d = self._bpred(ws["t"], ws["o"]).to_dense()[:, :, 0]
+            logits.append(d[:, :a2])
+            regs.append(d[:, a2:])
+        return logits, regs
+
+    def proposals_dense(self, left_images, left_features, right_features, blocked_levels=None):
         """-> scores [N,T], left [N,T,4], right [N,T,4] over all T anchors of the pyramid (levels concatenated like the reference)."""
         dev = left_features[0].device
-        logits, regs = self._head(left_features, right_features)
+        if blocked_levels is not None and blocked_levels[0].N == 2 * left_features[0].shape[0] and self.head.conv.out_channels % 16 == 0:
+            logits, regs = self._head_blocked(blocked_levels)
+        else:
+            logits, regs = self._head(left_features, right_features)
         anchors = self.anchor_generator.level_anchors([tuple(f.shape[-2:]) for f in left_features], dev)
         n, a = logits[0].shape[0], logits[0].shape[1] // 2
         total = sum(int(x.shape[0]) for x in anchors)
@@ -80,11 +122,14 @@ class StereoRPN(nn.Module):
             off += h * w * a
         return scores, left, right
 
-    def forward(self, left_images, right_images, left_features, right_features, left_targets=None, right_targets=None):
+    def forward(self, left_images, right_images, left_features, right_features, left_targets=None, right_targets=None,
+                blocked_levels=None):
+        """blocked_levels: optionally the same pyramid in the engine's layout (BackboneRuntime.blocked_levels(): units [left, right],
+        halo 1), which lets the head skip the layout round trips; the results are the same maps."""
         if self.training:
             raise NotImplementedError("Stereo RPN training (losses, proposal sampling) belongs to the 2D stage's training, which is not built")
         E.require_gpu(left_features[0], "StereoRPN")
-        scores, left, right = self.proposals_dense(left_images, left_features, right_features)
+        scores, left, right = self.proposals_dense(left_images, left_features, right_features, blocked_levels)
         n = scores.shape[0]
         order = torch.sort(scores, 1, True)[1]
         left_result, right_result = [], []

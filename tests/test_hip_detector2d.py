@@ -197,6 +197,32 @@ def test_disprcnn_end_to_end_vs_oracle(dev):
         assert tuple(ld.get_field("mask").shape) == (len(ld), 1, 28, 28)
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 160, 256), (2, 96, 160), (1, 150, 250)])
+def test_stereo_rpn_blocked_head_matches_dense_head(dev, n, h, w):
+    """The Stereo-RPN head run on the backbone's blocked pyramid (no layout round trips, the two predictors as one 1x1 convolution)
+    gives the maps of the dense path (srpn.py:27-50), for one image pair (one launch over [left, right]) and for a batch."""
+    from disprcnn_amd.modeling.detector import DispRCNN, default_cfg_2d
+    m = DispRCNN(default_cfg_2d("R-50-FPN", post_nms_top_n_test=40))
+    sd = m.state_dict()
+    w_rpn = synth.synth_det_state({k[4:]: v for k, v in sd.items() if k.startswith("rpn.")}, gain=synth.DET_GAIN)
+    bb = synth.synth_backbone_state({k[9:]: v for k, v in sd.items() if k.startswith("backbone.")})
+    m.load_state_dict({**{"backbone." + k: v for k, v in bb.items()}, **{"rpn." + k: v for k, v in w_rpn.items()}}, strict=False)
+    m = m.to(dev).eval()
+    left, right = synth.synth_images(n, h, w, tag="blkhead")
+    with torch.no_grad():
+        feats = m.backbone(torch.cat((left, right), 0).to(dev))
+        levels = m.backbone._rt.blocked_levels()
+        assert [lv.N for lv in levels] == [2 * n] * 5 and all(lv.ph == 1 for lv in levels)
+        lg_d, rg_d = m.rpn._head([f[:n] for f in feats], [f[n:] for f in feats])
+        lg_b, rg_b = m.rpn._head_blocked(levels)
+        lg_b2, _ = m.rpn._head_blocked(levels)                       # cached workspace
+    for d, b, b2 in zip(lg_d, lg_b, lg_b2):
+        assert d.shape == b.shape and (d - b).abs().max().item() <= 1e-5 * max(1.0, d.abs().max().item())
+        assert torch.equal(b, b2)
+    for d, b in zip(rg_d, rg_b):
+        assert d.shape == b.shape and (d - b).abs().max().item() <= 1e-5 * max(1.0, d.abs().max().item())
+
+
 def test_full_pipeline_images_to_disparity_maps(dev):
     """test_net.py's data flow on the HIP path: stereo pair -> DispRCNN (2D stage) -> DispRCNN3D (instance disparity on the detections)
     -> DisparityMapProcessor (full-image maps).  The 2D stage's output IS the disparity stage's lr_result; each stage has its own parity
