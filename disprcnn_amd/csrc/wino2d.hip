@@ -13,7 +13,11 @@
 // (drc_pack_weights_wino2d).  The block's four waves run in lock step and share the weights of a half step (8 frequency
 // points) through a three-slab LDS ring, positions are numbered XCD by XCD, the first channel block of a tile group issues its
 // MFMAs with C = 0 -- all as in wino3d.hip.  After the last channel block the 16 x CT accumulators are inverse-transformed to
-// the 2x2 outputs and go through the usual epilogue.  Needs even OH, OW (the engine keeps other shapes on the direct kernel).
+// the 2x2 outputs and go through the usual epilogue.
+// Odd OH / OW (round 3): the last tile row / column keeps output row / column 0 only.  Its patch row 3 (column 3) lies one past the
+// zero halo -- the first row of the next plane, or the slack behind the tensor -- and may hold anything: in F(2,3) input row 3 enters
+// frequency point 3 only (v3 = d1 - d3), which enters output row 1 only (y1 = m1 - m2 - m3), the one that is not stored.  The caller
+// guarantees (Wp + 2) * 64 readable bytes behind the last plane (engine.Blocked's slack).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
     const int g = lane >> 4;
 
     const drc_tap_class cls = p.cls[0];
-    const int TH = p.OH >> 1, TW = p.OW >> 1;
+    const int TH = (p.OH + 1) >> 1, TW = (p.OW + 1) >> 1;    // odd maps: the last tile row / column is half used (see unit_end)
     const int tiles = p.N * TH * TW;
     const int groups = (tiles + 15) >> 4;
     // block -> (cout group, position), rounds of four tile groups: see wino3d.hip
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
             for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
                 for (int ow = 0; ow < 2; ++ow) {
+                    if (2 * geo.ht + oh >= p.OH || 2 * geo.wt + ow >= p.OW) continue;   // the unused half of an odd map's last tiles
                     f32x4 v_ = (ow == 0 ? hh[oh][0] + hh[oh][1] + hh[oh][2] : hh[oh][1] - hh[oh][2] - hh[oh][3]) * bn_sc + bn_sh;
                     if (p.res) v_ += *(const f32x4*)(p.res + ro + oh * p.r_h_stride + ow * 16 + (int64_t)(ct0 + ct) * p.r_cb_stride);
                     if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
 
 template <int CT>
 int launch(const drc_tapconv_params& p, hipStream_t stream) {
-    const long tiles = (long)p.N * (p.OH / 2) * (p.OW / 2);
+    const long tiles = (long)p.N * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long groups = (tiles + 15) / 16;
     const int n_cg = p.cout_pad / 16 / CT;
     // one block per CU; every cout group gets the same number of blocks
@@ -307,9 +312,8 @@ extern "C" int drc_conv2d_k3_wino_fwd(const drc_tapconv_params* pp, int cout_til
     if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
     const drc_tap_class& k = p.cls[0];
     if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 1 || k.nh != 3 || k.nw != 3 || k.sh != 1 || k.sw != 1) return -4;
-    if ((p.OH | p.OW) & 1) return -4;                                          // whole 2x2 tiles only
-    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;             // 32-bit lane offsets over the whole batch
-    if ((int64_t)p.N * p.OH * p.OW / 4 >= (1LL << 31) - 16 || (int64_t)16 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
+    if (((int64_t)p.N * p.x_n_stride + 2 * p.x_h_stride) * 4 >= (1LL << 32)) return -5;   // 32-bit lane offsets over the whole batch
+    if ((int64_t)p.N * ((p.OH + 1) / 2) * ((p.OW + 1) / 2) >= (1LL << 31) - 16 || (int64_t)16 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
     const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;
     if ((CT != 1 && CT != 2) || ct % CT) return -2;
     hipStream_t s = (hipStream_t)stream;

@@ -218,7 +218,8 @@ class RegressorBackward:
             if gpreds[k] is not None:
                 g = torch.empty_like(costs[k])           # overwritten: tile footprints gathered in a fixed order (no atomics)
                 foot = E.scratch(dev, "softargmin_bwd", nfoot)
-                st = lib.drc_upsample_softargmin_bwd(E._ptr(costs[k]), E._ptr(gpreds[k].contiguous().float()), E._ptr(g), N, Dp, Hp, Wp,
+                gk = gpreds[k].contiguous().float()      # (named: a temporary's block could be reused before the launch)
+                st = lib.drc_upsample_softargmin_bwd(E._ptr(costs[k]), E._ptr(gk), E._ptr(g), N, Dp, Hp, Wp,
                                                      mx - mn, H, W_, mn, E._ptr(foot), foot.numel(), sp)
                 _lib.check(st, "drc_upsample_softargmin_bwd")
             else:

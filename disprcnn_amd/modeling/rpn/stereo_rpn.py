@@ -95,8 +95,8 @@ class StereoRPN(nn.Module):
             for xv, yv in ws["pairs"]:
                 self._bconv(xv, yv)
             d = self._bpred(ws["t"], ws["o"]).to_dense()[:, :, 0]
-            logits.append(d[:, :a2])
-            regs.append(d[:, a2:])
+            logits.append(d[:, :a2].contiguous())
+            regs.append(d[:, a2:].contiguous())
         return logits, regs
 
     def proposals_dense(self, left_images, left_features, right_features, blocked_levels=None):
@@ -116,7 +116,8 @@ class StereoRPN(nn.Module):
         off = 0
         for lg, rg, an in zip(logits, regs, anchors):
             h, w = lg.shape[-2:]
-            st = _lib.lib().drc_srpn_proposals_fwd(E._ptr(lg.contiguous()), E._ptr(rg.contiguous()), E._ptr(an), E._ptr(wh), n, a, h, w, total, off,
+            lg, rg = lg.contiguous(), rg.contiguous()              # (named: a temporary would be freed -- and its block reused -- before the launch)
+            st = _lib.lib().drc_srpn_proposals_fwd(E._ptr(lg), E._ptr(rg), E._ptr(an), E._ptr(wh), n, a, h, w, total, off,
                                                    self.box_coder.bbox_xform_clip, E._ptr(scores), E._ptr(left), E._ptr(right), E._stream_ptr(dev))
             _lib.check(st, "drc_srpn_proposals_fwd")
             off += h * w * a

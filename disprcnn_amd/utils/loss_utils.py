@@ -44,7 +44,8 @@ class _PSMTrainLoss(Function):
         grads = []
         for p, w in zip((p1, p2, p3), _WEIGHTS):
             gp = torch.empty_like(p, memory_format=torch.contiguous_format)
-            st = _lib.lib().drc_psm_loss_grad(E._ptr(p.contiguous()), E._ptr(target), E._ptr(mask), p.numel(), E._ptr(sums), w, E._ptr(g),
+            pc = p.contiguous()
+            st = _lib.lib().drc_psm_loss_grad(E._ptr(pc), E._ptr(target), E._ptr(mask), p.numel(), E._ptr(sums), w, E._ptr(g),
                                               E._ptr(gp), E._stream_ptr(p.device))
             _lib.check(st, "drc_psm_loss_grad")
             grads.append(gp)

@@ -285,7 +285,10 @@ def test_conv3d_winograd_fused_cost_volume(dev, n, C, cout, D, H, W, lo4, pad):
 
 @pytest.mark.parametrize("n,cin,cout,hw,with_res", [(4, 32, 32, (112, 112), True), (3, 64, 64, (56, 56), False), (2, 128, 128, (28, 28), True),
                                                      (5, 7, 33, (2, 30), True), (9, 64, 32, (4, 4), False), (2, 20, 40, (8, 4), True),
-                                                     (1, 16, 16, (2, 2), False)])
+                                                     (1, 16, 16, (2, 2), False),
+                                                     # odd maps (round 3): half-used last tile row / column
+                                                     (2, 64, 64, (47, 155), True), (3, 32, 48, (13, 20), False), (2, 20, 40, (8, 5), True),
+                                                     (4, 16, 16, (1, 1), False), (2, 48, 32, (7, 7), True)])
 def test_conv2d_winograd_kernel_vs_oracle(dev, n, cin, cout, hw, with_res):
     """wino2d.hip (Winograd F(2x2,3x3), the default for stride-1 undilated 3x3 Conv2d layers on even maps with enough work)
     against the direct convolution: partial tile groups, 1..4 cout groups, channel counts that are not multiples of 16, with

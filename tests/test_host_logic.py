@@ -137,8 +137,8 @@ def test_stride1_conv3d_kernel_selection():
 
 
 def test_conv2d_3x3_kernel_selection():
-    """2D Winograd for stride-1 undilated 3x3 layers on even maps with enough tile groups; the direct kernel for odd maps,
-    strides, dilations and small problems (the backbone's deep stages)."""
+    """2D Winograd for stride-1 undilated 3x3 layers with enough tile groups; the direct kernel for strides, dilations and small
+    problems (the backbone's deep stages)."""
     from disprcnn_amd import engine as E
     dev = torch.device("cpu")
 
@@ -149,7 +149,13 @@ def test_conv2d_3x3_kernel_selection():
 
     assert plan(32, 32, (112, 112)).kname == "wino2d_kernel<2>"
     assert plan(32, 128, (56, 56)).wino
-    assert not plan(2, 64, (94, 311)).wino            # odd width
+    assert plan(2, 64, (94, 311)).wino                # odd width: half-used last tile column (round 3)
+    saved_odd = E.WINO2D["odd"]
+    E.WINO2D["odd"] = False
+    try:
+        assert not plan(2, 64, (94, 311)).wino
+    finally:
+        E.WINO2D["odd"] = saved_odd
     assert plan(2, 256, (24, 78)).wino                # a deep backbone stage: few tile groups, still ahead of the direct kernel
     assert not plan(2, 512, (12, 38)).wino            # too few tile groups per cout group
     assert not plan(32, 32, (112, 112), stride=2).wino
