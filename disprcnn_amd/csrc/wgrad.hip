@@ -23,7 +23,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 #define WG_WAVES 4
-#define WG_MAXM 28   /* k-steps (4 voxels each) per group: R*WT <= 112 */
 
 namespace {
 
@@ -52,17 +51,6 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
     const int nm = (nslots + 3) >> 2;
     float* lds_a = lds_all + wave * (p.lds_bytes_per_wave >> 2);
     float* lds_b = lds_a + a_floats;
-
-    // per-lane offsets of voxel slot 4m+g inside the a tile (tap (0,0)) and validity of the slot inside the tile
-    int a_off[WG_MAXM];
-    unsigned slot_ok = 0;
-#pragma unroll
-    for (int m = 0; m < WG_MAXM; ++m) {
-        const int s = 4 * m + g;
-        int r = s / p.WT, c = s - r * p.WT;
-        if (s < nslots) slot_ok |= 1u << m; else { r = 0; c = 0; }
-        a_off[m] = (p.in_mul * r * seg_vox + p.in_mul * c) * 16 + j;
-    }
 
     f32x4 acc[NT];
 #pragma unroll
@@ -96,28 +84,50 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
                     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(bsrc + (int64_t)r * p.b_h_stride + u * 4), LDS_PTR(lds_b + r * p.WT * 16 + u0 * 4), 16, 0, 0);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // slots that fall outside the output grid (ragged last tiles) contribute nothing: zero their b values
-        unsigned ok = slot_ok;
-        if (oh0 + p.R > p.OH || ow0 + p.WT > p.OW) {
+        // ---- accumulate: per k-step (4 voxel slots, this lane's is 4m+g) read B once, then one MFMA per tap with the tap-shifted A
+        // value.  The k loop is a runtime loop, software-pipelined by one step in two register sets (round 3: the fully unrolled form
+        // guarded every step by `m < nm`, and the branches kept the reads of a step from being issued under the previous step's MFMAs:
+        // 10 ds_reads, lgkmcnt(0), 9 MFMAs, repeat).  Slots outside the tile or the output grid (ragged last tiles) get b = 0.
+        int sr = g / p.WT, sc = g - sr * p.WT;           // (row, col) of this lane's slot, advanced by 4 slots per step
+        auto fetch = [&](float (&av)[NT], float& bv, int m) __attribute__((always_inline)) {
+            const int slot = 4 * m + g;
+            const bool ok = slot < nslots && oh0 + sr < p.OH && ow0 + sc < p.OW;
+            const int r = slot < nslots ? sr : 0, c = slot < nslots ? sc : 0;
+            const float* ap = lds_a + (p.in_mul * r * seg_vox + p.in_mul * c) * 16 + j;
+            const float b_ = lds_b[(slot < nslots ? slot : 0) * 16 + j];
+            bv = ok ? b_ : 0.f;
 #pragma unroll
-            for (int m = 0; m < WG_MAXM; ++m) {
-                const int s = 4 * m + g;
-                const int r = s / p.WT, c = s - r * p.WT;
-                if (oh0 + r >= p.OH || ow0 + c >= p.OW) ok &= ~(1u << m);
+            for (int t = 0; t < NT; ++t) {
+                const int tb = t / p.nw, tc = t - tb * p.nw;
+                av[t] = ap[(tb * p.sh * seg_vox + tc * p.sw) * 16];
             }
+            sc += 4;
+            while (sc >= p.WT) { sc -= p.WT; ++sr; }
+        };
+        auto mfmas = [&](const float (&av)[NT], float bv) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[t], 0, 0, 0);
+        };
+        float avA[NT], avB[NT], bvA, bvB;
+        fetch(avA, bvA, 0);
+        int m = 0;
+        for (; m + 2 < nm; m += 2) {
+            fetch(avB, bvB, m + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(avA, bvA);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(avA, bvA, m + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(avB, bvB);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- accumulate: for every k-step read B once, then one MFMA per tap with the tap-shifted A value
-#pragma unroll
-        for (int m = 0; m < WG_MAXM; ++m) {
-            if (m < nm) {                                   // wave-uniform
-                const float bv = ((ok >> m) & 1u) ? lds_b[(4 * m + g) * 16 + j] : 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int tb = t / p.nw, tc = t - tb * p.nw;
-                    const float av = lds_a[a_off[m] + (tb * p.sh * seg_vox + tc * p.sw) * 16];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
-                }
-            }
+        if (m + 2 == nm) {                              // two steps left
+            fetch(avB, bvB, m + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(avA, bvA);
+            mfmas(avB, bvB);
+        } else {                                        // one step left
+            mfmas(avA, bvA);
         }
         // all LDS reads of this group are consumed by the MFMAs above before the next group's DMA is issued (in-order wave)
     }

@@ -41,6 +41,11 @@ class Grads:
         return b
 
 
+# bytes of LDS a wave's (a, b) tile pair may take.  The kernel is bound by each wave's serial LDS-read -> MFMA chain, so waves per SIMD
+# matter more than tile size: 12 KiB (3 waves per SIMD) instead of rounds 1-2's 38 KiB (1) took the Config-B train step (8 crops) from
+# 50.9 to 44.1 ms; 9 KiB tiles are too ragged (47.4).  Double-buffering the staging inside a wave (tried, round 3) halves the occupancy
+# again and lost on every layer.  Layers with no tile under the cap (wide strided taps) fall back to 38 KiB.
+WGRAD_TILE = {"lds_cap": 12 * 1024, "lds_max": 38 * 1024}
 WGRAD_PARTIALS = {"enabled": True}     # partial sums + fixed-order reduce instead of the atomicAdd flush (tests flip it)
 
 
@@ -55,15 +60,18 @@ def wgrad(a, b, cls, in_mul, R=None, WT=None):
     span_h, span_w = (nh - 1) * cls["step"][1], (nw - 1) * cls["step"][2]
     # tile: R rows x WT cols of b with (rows_in*seg + R*WT)*64 B <= 38 KiB per wave
     best = None
-    for wt in sorted({-(-b.W // k) for k in range(1, b.W + 1) if -(-b.W // k) <= 112}):
-        for r in range(1, min(b.H, 112 // wt) + 1):
-            need = ((in_mul * (r - 1) + span_h + 1) * (in_mul * (wt - 1) + span_w + 1) + r * wt) * 64
-            if need > 38 * 1024:
-                continue
-            eff = (b.H * b.W) / ((-(-b.H // r)) * (-(-b.W // wt)) * (-(-(r * wt) // 4)) * 4)
-            key = (round(eff, 3), r * wt, wt)
-            if best is None or key > best[0]:
-                best = (key, r, wt, need)
+    for cap in (WGRAD_TILE["lds_cap"], WGRAD_TILE["lds_max"]):
+        for wt in sorted({-(-b.W // k) for k in range(1, b.W + 1) if -(-b.W // k) <= 112}):
+            for r in range(1, min(b.H, 112 // wt) + 1):
+                need = ((in_mul * (r - 1) + span_h + 1) * (in_mul * (wt - 1) + span_w + 1) + r * wt) * 64
+                if need > cap:
+                    continue
+                eff = (b.H * b.W) / ((-(-b.H // r)) * (-(-b.W // wt)) * (-(-(r * wt) // 4)) * 4)
+                key = (round(eff, 3), r * wt, wt)
+                if best is None or key > best[0]:
+                    best = (key, r, wt, need)
+        if best is not None:
+            break
     if best is None:
         raise ValueError("wgrad: no tile fits LDS")
     _, p.R, p.WT, need = best
