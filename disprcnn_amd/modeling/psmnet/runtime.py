@@ -5,6 +5,7 @@ Graph restated from the reference (stackhourglass.py:106-174, submodule.py:106-1
 schedule of launches over blocked, zero-haloed tensors.  Workspaces and launch plans are cached
 per input shape; halos are zeroed once at allocation and never written again.
 """
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -12,6 +13,7 @@ import torch
 from ... import engine as E
 from .submodule import SPP_BRANCHES, TRUNK_STAGES
 
+MAX_SLOTS = 4            # train-mode forward passes of one geometry that may await their backward at once (each owns a workspace pool)
 WS_MAX_PLANS = 48        # launch-plan sets kept per runtime (one per exact unit count; they hold views, not memory)
 
 
@@ -114,6 +116,37 @@ class PSMNetRuntime:
         self._pools = {}           # geometry key (no unit count) -> E.WorkspacePool owning the HBM, sized for the largest count seen
         self._training = False
         self._tape = None       # list of recorded ops while a differentiable train-mode forward runs
+        self._held = {}         # workspace slot -> token of the differentiable forward whose saved activations live there
+        self._slot = 0          # slot the running forward uses
+
+    # ------------------------------------------------------------------ workspace slots (forwards awaiting their backward)
+    def _pick_slot(self):
+        """The lowest slot no pending backward depends on.  Slot 0 when nothing is pending -- eval passes and the usual
+        forward/backward/step loop never touch another pool; a second forward before the first one's backward (gradient
+        accumulation over several batches, an eval pass between forward and backward; reference: plain autograd,
+        engine/trainer.py:101-115) gets a pool of its own."""
+        for s in range(MAX_SLOTS):
+            if s not in self._held:
+                return s
+        raise RuntimeError(f"PSMNet: {MAX_SLOTS} train-mode forward passes are waiting for their backward; run backward() (or drop "
+                           f"their outputs) first, or raise disprcnn_amd.modeling.psmnet.runtime.MAX_SLOTS")
+
+    def _slotted(self, key):
+        return key if self._slot == 0 else key + (("slot", self._slot),)
+
+    def _hold(self, slot):
+        class _Token:
+            pass
+        tok = _Token()
+        self._held[slot] = id(tok)
+        weakref.finalize(tok, PSMNetRuntime._release, weakref.ref(self), slot, id(tok))      # outputs dropped without a backward
+        return tok
+
+    @staticmethod
+    def _release(rt_ref, slot, tok_id):
+        rt = rt_ref() if isinstance(rt_ref, weakref.ref) else rt_ref
+        if rt is not None and rt._held.get(slot) == tok_id:
+            del rt._held[slot]
 
     def invalidate(self):
         self._weights_version = None
@@ -161,8 +194,8 @@ class PSMNetRuntime:
             if pool.gen != gen:
                 raise RuntimeError(
                     "PSMNet backward: the workspace of this forward pass was reused by a later forward (another batch of the "
-                    "same geometry, or an eval pass) before backward() ran, so the saved activations are gone. Call backward() "
-                    "before the next forward of this model (one forward/backward pair in flight per geometry).")
+                    "same geometry, or an eval pass) before backward() ran, so the saved activations are gone (retain_graph / a "
+                    "second backward through the same forward is not supported: run the forward again).")
 
     # ------------------------------------------------------------------ weights
     def _version(self):
@@ -265,11 +298,11 @@ class PSMNetRuntime:
 
     # ------------------------------------------------------------------ 3D regressor
     def _ws3d(self, N, Dp, Hp, Wp):
-        key = ("3d", N, Dp, Hp, Wp)
+        key = self._slotted(("3d", N, Dp, Hp, Wp))
         ws = self._ws_get(key)
         if ws is not None:
             return ws
-        pool = self._pool_for(("3d", Dp, Hp, Wp), N)
+        pool = self._pool_for(self._slotted(("3d", Dp, Hp, Wp)), N)
         full = (Dp, Hp, Wp)
         half = tuple(-(-s // 2) for s in full)
         quart = tuple(-(-s // 2) for s in half)
@@ -361,11 +394,11 @@ class PSMNetRuntime:
         return out
 
     def _ws3d16(self, N, Dp, Hp, Wp):
-        key = ("3d16", N, Dp, Hp, Wp)
+        key = self._slotted(("3d16", N, Dp, Hp, Wp))
         ws = self._ws_get(key)
         if ws is not None:
             return ws
-        pool = self._pool_for(("3d16", Dp, Hp, Wp), N)
+        pool = self._pool_for(self._slotted(("3d16", Dp, Hp, Wp)), N)
         full = (Dp, Hp, Wp)
         half = tuple(-(-s // 2) for s in full)
         quart = tuple(-(-s // 2) for s in half)
@@ -456,6 +489,7 @@ class PSMNetRuntime:
 
     def forward_features(self, fl, fr, out_hw, training=False):
         self._training = bool(training)
+        self._slot = self._pick_slot()
         params = [p for p in self.model.parameters() if p.requires_grad and not self._is_fe_param(p)]
         if training and torch.is_grad_enabled() and (fl.requires_grad or fr.requires_grad or params):
             return _RegressorTrainFn.apply(self, tuple(out_hw), fl, fr, *params)
@@ -499,13 +533,13 @@ class PSMNetRuntime:
 
     # ------------------------------------------------------------------ 2D feature CNN
     def _ws2d(self, N, H, W, side=None):
-        key = ("2d", N, H, W) if side is None else ("2d", N, H, W, side)
+        key = self._slotted(("2d", N, H, W) if side is None else ("2d", N, H, W, side))
         ws = self._ws_get(key)
         if ws is not None:
             return ws
         if H % 4 or W % 4 or H // 4 < 56 or W // 4 < 56:
             raise ValueError("PSMNet needs H,W multiples of 4 and >= 224 (fixed AvgPool2d(56), reference submodule.py:76)")
-        pool = self._pool_for(("2d", H, W, side), N)
+        pool = self._pool_for(self._slotted(("2d", H, W, side)), N)
         names = iter(range(1 << 30))
         B2 = lambda c, h, w, pad=1: pool.blocked(("t", next(names)), N, c, 1, h, w, 0, pad, pad)   # allocation order is deterministic
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
@@ -601,6 +635,7 @@ class PSMNetRuntime:
 
     def forward_images(self, left, right, training=False):
         self._training = bool(training)
+        self._slot = self._pick_slot()
         params = [p for p in self.model.parameters() if p.requires_grad]
         if training and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or params):
             return _PSMNetTrainFn.apply(self, left, right, *params)
@@ -652,8 +687,9 @@ class PSMNetRuntime:
 
 class _RegressorTrainFn(torch.autograd.Function):
     """Differentiable train-mode pass from the feature boundary: forward on the HIP engine (tape recorded), backward by
-    modeling/psmnet/train.py.  One forward/backward pair per geometry may be in flight (workspaces are reused); a backward
-    whose workspace was overwritten by a later forward raises (WorkspacePool.gen)."""
+    modeling/psmnet/train.py.  The forward keeps its workspace slot until its backward has run (or its outputs are dropped), so up to
+    MAX_SLOTS forward passes may be in flight -- gradient accumulation, an eval pass in between -- each on a pool of its own; the
+    generation check stays as a guard (a backward whose workspace was overwritten raises)."""
 
     @staticmethod
     def forward(ctx, rt, out_hw, fl, fr, *params):
@@ -662,6 +698,7 @@ class _RegressorTrainFn(torch.autograd.Function):
         try:
             preds = rt._forward_features_impl(fl.detach(), fr.detach(), out_hw, True)
             ctx.tape, ctx.info, ctx.gens = rt._tape, rt._last_train, rt._last_gens
+            ctx.slot, ctx.token = rt._slot, rt._hold(rt._slot)
         finally:
             rt._tape = None
         ctx.rt, ctx.params, ctx.need_in = rt, params, rt._need_input_grad
@@ -682,6 +719,7 @@ class _RegressorTrainFn(torch.autograd.Function):
             from ... import ops
             gcost = G.get("cost").to_dense()
             gfl, gfr = ops.cost_volume_backward(gcost, mx, mn)
+        rt._release(rt, ctx.slot, id(ctx.token))            # the saved activations are spent: the slot is free for the next forward
         return (None, None, gfl, gfr) + tuple(bw.pg.get(id(p)) for p in ctx.params)
 
 
@@ -696,6 +734,7 @@ class _PSMNetTrainFn(torch.autograd.Function):
         try:
             preds = rt._forward_images_impl(left.detach(), right.detach(), True)
             ctx.tape, ctx.info, ctx.ws2, ctx.gens = rt._tape, rt._last_train, rt._last_train_2d, rt._last_gens
+            ctx.slot, ctx.token = rt._slot, rt._hold(rt._slot)
         finally:
             rt._tape = None
         ctx.rt, ctx.params = rt, params
@@ -714,4 +753,5 @@ class _PSMNetTrainFn(torch.autograd.Function):
         gfl, gfr = ops.cost_volume_backward(G.get("cost").to_dense(), mx, mn)
         for ws2, gfeat in zip(ctx.ws2, (gfl, gfr)):
             FeaturesBackward(rt, ws2, Wt, bw.pg).run(ctx.tape, gfeat)
+        rt._release(rt, ctx.slot, id(ctx.token))
         return (None, None, None) + tuple(bw.pg.get(id(p)) for p in ctx.params)
