@@ -25,7 +25,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 #define C16_WAVES 4
+#ifndef C16_PF_BIG
+#define C16_PF_BIG 4
+#endif
+#ifndef C16_PF_SMALL
+#define C16_PF_SMALL 6
+#endif
 
 namespace {
 
@@ -46,6 +54,7 @@ __global__ __launch_bounds__(64 * C16_WAVES) void conv16_kernel(const drc_tapcon
     const int nslots = p.R * p.WT;
     const long w_cb = (long)p.cout_pad * 32;           // halfs per (tap, cb32)
     const long w_tap = w_cb * p.cb_in;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, -1, 0x00020000);
 
     for (long grp = (long)blockIdx.x * C16_WAVES + wave; grp < groups; grp += (long)gridDim.x * C16_WAVES) {
         long t = grp;
@@ -58,8 +67,10 @@ __global__ __launch_bounds__(64 * C16_WAVES) void conv16_kernel(const drc_tapcon
         const drc_tap_class cls = p.cls[ci];
         const int oh0 = rt_i * p.R, ow0 = wt_i * p.WT, ct0 = cg * CT;
 
-        // per-lane element offset of the voxel slot (vt, j) at tap offset 0 (padded input coordinates), channels 8g..8g+7
-        long lane_vo[VT];
+        // Operands come through buffer loads (round 3): descriptor in SGPRs, a loop-invariant 32-bit lane offset and the (channel
+        // block, tap) step as a scalar offset, so the step loop holds no vector address arithmetic.  The base of the voxel descriptor
+        // is the group's first input voxel at tap offset 0; lane offset = slot (vt, j) inside the tile, channels 8g..8g+7.
+        unsigned lane_vo[VT];
         bool valid[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) {
@@ -67,10 +78,12 @@ __global__ __launch_bounds__(64 * C16_WAVES) void conv16_kernel(const drc_tapcon
             int r = s / p.WT, c = s - r * p.WT;
             valid[vt] = s < nslots && oh0 + r < p.OH && ow0 + c < p.OW;
             if (!valid[vt]) { r = 0; c = 0; }
-            lane_vo[vt] = (long)n * p.x_n_stride + (long)(od * p.in_mul) * p.x_d_stride + (long)((oh0 + r) * p.in_mul) * p.x_h_stride +
-                          (long)((ow0 + c) * p.in_mul) * 32 + g * 8;
+            lane_vo[vt] = 2u * (unsigned)(r * p.in_mul * (int)p.x_h_stride + c * p.in_mul * 32 + g * 8);
         }
-        const _Float16* wl = w + (long)(ct0 * 16 + j) * 32 + g * 8;
+        const _Float16* xg = x + (long)n * p.x_n_stride + (long)(od * p.in_mul) * p.x_d_stride + (long)(oh0 * p.in_mul) * p.x_h_stride +
+                             (long)(ow0 * p.in_mul) * 32;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, -1, 0x00020000);
+        const unsigned wlo = 2u * (unsigned)((ct0 * 16 + j) * 32 + g * 8);
 
         f32x4 acc[VT][CT];
 #pragma unroll
@@ -80,36 +93,45 @@ __global__ __launch_bounds__(64 * C16_WAVES) void conv16_kernel(const drc_tapcon
 
         const int ntap = cls.nd * cls.nh * cls.nw;
         const int steps = ntap * p.cb_in;
-        f16x8 bA[VT], wA[CT], bB[VT], wB[CT];
-        auto load_step = [&](f16x8 (&B)[VT], f16x8 (&Wt)[CT], int st) __attribute__((always_inline)) {
-            const int cb = st / ntap, tp = st - cb * ntap;
-            const int a = tp / (cls.nh * cls.nw), rem = tp - a * (cls.nh * cls.nw);
-            const int b = rem / cls.nw, d = rem - b * cls.nw;
-            const long xo = (long)cb * p.x_cb_stride + (long)(cls.dd0 + a * cls.sd) * p.x_d_stride + (long)(cls.dh0 + b * cls.sh) * p.x_h_stride +
-                            (long)(cls.dw0 + d * cls.sw) * 32;
-            const int widx = cls.wbase + a * cls.wsd + b * cls.wsh + d * cls.wsw;
+        // ring of NB operand sets, PF steps ahead of the MFMAs: a step is only VT*CT 16-cycle MFMAs, a load round trip ~2000 cycles
+        constexpr int PF = VT * CT >= 8 ? C16_PF_BIG : C16_PF_SMALL;
+        constexpr int NB = PF + 1;
+        f16x8 B[NB][VT], Wt[NB][CT];
+        int f_cb = 0, f_a = 0, f_b = 0, f_d = 0;       // (channel block, tap) of the next step to request; past the end: the last step again
+        auto fetch = [&](int set) __attribute__((always_inline)) {
+            const unsigned xo = 2u * (unsigned)(f_cb * (int)p.x_cb_stride + (cls.dd0 + f_a * cls.sd) * (int)p.x_d_stride +
+                                                (cls.dh0 + f_b * cls.sh) * (int)p.x_h_stride + (cls.dw0 + f_d * cls.sw) * 32);
+            const unsigned wo = 2u * (unsigned)((cls.wbase + f_a * cls.wsd + f_b * cls.wsh + f_d * cls.wsw) * (int)w_tap + f_cb * (int)w_cb);
 #pragma unroll
-            for (int vt = 0; vt < VT; ++vt) B[vt] = *(const f16x8*)(x + xo + lane_vo[vt]);
-            const _Float16* wp = wl + (long)widx * w_tap + (long)cb * w_cb;
+            for (int vt = 0; vt < VT; ++vt) B[set][vt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, lane_vo[vt], xo, 0));
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) Wt[ct] = *(const f16x8*)(wp + ct * 512);
+            for (int ct = 0; ct < CT; ++ct) Wt[set][ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo + ct * 1024, wo, 0));
+            if (f_cb * ntap + (f_a * cls.nh + f_b) * cls.nw + f_d + 1 < steps) {
+                if (++f_d == cls.nw) { f_d = 0; if (++f_b == cls.nh) { f_b = 0; if (++f_a == cls.nd) { f_a = 0; ++f_cb; } } }
+            }
         };
-        auto mfma_step = [&](const f16x8 (&B)[VT], const f16x8 (&Wt)[CT]) __attribute__((always_inline)) {
+        auto mfma_step = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[ct], B[vt], acc[vt][ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wt[set][ct], B[set][vt], acc[vt][ct], 0, 0, 0);
         };
-        load_step(bA, wA, 0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch(u);
         int st = 0;
-#pragma unroll 1
-        for (; st + 2 <= steps; st += 2) {
-            load_step(bB, wB, st + 1);
-            mfma_step(bA, wA);
-            if (st + 2 < steps) load_step(bA, wA, st + 2);
-            mfma_step(bB, wB);
+        for (; st + NB <= steps; st += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                fetch((u + PF) % NB);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (st < steps) mfma_step(bA, wA);
+#pragma unroll
+        for (int u = 0; u < NB - 1; ++u)
+            if (st + u < steps) mfma_step(u);
 
         // ---- epilogue
         if (dense1) {
@@ -221,6 +243,8 @@ extern "C" int drc_conv16_fwd(const drc_tapconv_params* pp, void* stream) {
     if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0 || p.n_classes < 1 || p.n_classes > DRC_MAX_CLASSES) return -2;
     if (p.R <= 0 || p.WT <= 0 || p.R * p.WT > 64) return -2;
     if (p.in_mul < 1 || p.in_mul > 2 || p.out_mul < 1 || p.out_mul > 2) return -2;
+    // 32-bit byte offsets inside one unit's tensor and inside the weights (buffer loads)
+    if (p.x_n_stride * 2 >= (1LL << 31) || (int64_t)p.cb_in * p.cout_pad * 32 * 27 * 2 >= (1LL << 31)) return -5;
     const int vt = (p.R * p.WT + 15) / 16, ct = p.cout_pad / 16;
     hipStream_t s = (hipStream_t)stream;
     const bool two = ct % 2 == 0;

@@ -1,0 +1,258 @@
+// conv16t.hip -- fp16-storage 3x3x3 / 3x3 stride-1 convolutions with the input tile staged in LDS (gfx950 / CDNA4), round 3.
+//
+//   reference arithmetic: convbn_3d k3 s1 p1 of stackhourglass.py:7-51,63-88 (dres0/dres1, hourglass conv2/conv4, classif[0]) and the
+//   stride-1 undilated convbn 3x3 layers of feature_extraction (submodule.py:13-17,24-49,62-88); fp16 storage, fp32 accumulation as in
+//   conv16.hip (the reference is fp32-only; this path is held to a stated bound against the fp32 oracle).
+//
+// Why: conv16.hip reads both MFMA operands straight from global memory.  With `v_mfma_f32_16x16x32_f16` at 16x the fp32 rate a step
+// is 8 MFMAs = 128 cycles against 6 KiB of loads, and a wave's 27-tap footprint (3 slices x 10 x 10 voxel lines = 19 KiB) times the
+// 8 waves of a CU does not fit the 32 KiB L1: every tap went to L2 (234 TF = 9 % of the f16 peak on the stress shape, unchanged by a
+// deeper prefetch ring).  Here a block of four waves stages the (TR+2) x 16-voxel input rows of a 14-column output tile ONCE per
+// (channel block, depth tap) with LDS-DMA and all 27 / 9 taps read their B fragments from LDS; only the weights (shared by every
+// block, L1-resident) still come through the vector-memory path.
+//
+//   tile      : TR = 4*RW output rows x 14 columns of one (n, od); wave w owns rows w*RW .. w*RW+RW-1, lane (j, g) column j.
+//               Lanes j = 14, 15 compute two columns nobody stores (12.5 % of the MFMA work) so that a staged row is exactly one
+//               16-voxel line group: 1 KiB, one global_load_lds per row, no bank conflicts on the reads.
+//   LDS row   : [g = 0..3][voxel 0..15][8 halfs]: lane l of the DMA (g = l/16, v = l%16) fetches channels 8g..8g+7 of voxel v and lands at
+//               l*16 B; a B fragment of tap kw is ds_read_b128 at g*256 + (j+kw)*16 (+ row*1024): 16 consecutive 16-byte words per g.
+//               (j + kw > 15 only for the unused lanes; they read the next plane's first words.)
+//   stage     : one (tile, 32-channel block): ND*(TR+2) rows into the block's single buffer, then its 27 / 9 taps.  The DMA is NOT
+//               overlapped with the block's own MFMAs: vmcnt retires in order, so a weight load issued behind the next stage's DMA could
+//               not be consumed before that DMA had landed.  Instead several blocks are resident per CU (19-56 KiB each) and one
+//               block's staging wait is another's MFMA phase.
+//   weights   : [tap][cb32][cout_pad][32] fp16 (engine.pack_weight16), buffer loads a few taps ahead (L1-resident: every block of the
+//               launch reads the same <= 27 x CT KiB).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define T16_WAVES 4
+#define T16_COLS 14
+#ifndef T16_WPF_NARROW
+#define T16_WPF_NARROW 9   /* weight sets (taps) in flight ahead of the MFMAs, CT <= 2: a tap is only RW*CT 16-cycle MFMAs and the */
+#endif                     /* 27 x CT KiB of a stage's weights miss the L1 next to the DMA traffic (L2 round trip ~700+ cycles)    */
+#ifndef T16_WPF_WIDE
+#define T16_WPF_WIDE 5     /* CT = 4 (16 registers a set) */
+#endif
+
+namespace {
+
+template <int RW, int CT, int ND>
+__global__ __launch_bounds__(64 * T16_WAVES) void conv16t_kernel(const drc_tapconv_params p) {
+    constexpr int TR = RW * T16_WAVES;                 // output rows per block tile
+    constexpr int ROWS = ND * (TR + 2);                // staged rows per stage
+    constexpr int NT = ND * 9;
+    constexpr int WPF = CT <= 2 ? T16_WPF_NARROW : T16_WPF_WIDE;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const _Float16* x = (const _Float16*)p.x;
+    const drc_tap_class cls = p.cls[0];
+    const bool dense1 = p.reserved == 1;
+
+    const int n_ct = (p.OW + T16_COLS - 1) / T16_COLS, n_rt = (p.OH + TR - 1) / TR;
+    const int n_cg = p.cout_pad / 16 / CT;
+    const unsigned tiles = (unsigned)p.N * p.OD * n_rt * n_ct * n_cg;   // cout group fastest: neighbouring blocks share the input tile in L2
+    // 32-bit strides (halfs): the host checks that one unit of x / y / res stays below 2^31 bytes
+    const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride, xc = (int)p.x_cb_stride;
+    const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
+    const int rh = (int)p.r_h_stride, rd_ = (int)p.r_d_stride, rc = (int)p.r_cb_stride;
+    const long w_cb = (long)p.cout_pad * 32, w_tap = w_cb * p.cb_in;   // halfs
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, -1, 0x00020000);
+
+    struct Tile { int n, od, r0, c0, cg; };
+    auto tile_of = [&](unsigned t) __attribute__((always_inline)) {
+        Tile q;
+        unsigned u = t / (unsigned)n_cg; q.cg = (int)(t - u * (unsigned)n_cg); t = u;
+        u = t / (unsigned)n_ct; q.c0 = (int)(t - u * (unsigned)n_ct) * T16_COLS; t = u;
+        u = t / (unsigned)n_rt; q.r0 = (int)(t - u * (unsigned)n_rt) * TR; t = u;
+        u = t / (unsigned)p.OD; q.od = (int)(t - u * (unsigned)p.OD);
+        q.n = (int)u;
+        return q;
+    };
+    // DMA the rows of stage (tile, cb): row i = (depth tap i / (TR+2), tile row i % (TR+2)), waves take rows round robin
+    auto stage = [&](const Tile& q, int cb) __attribute__((always_inline)) {
+        const _Float16* src = x + (long)q.n * p.x_n_stride +
+                              (cb * xc + (q.od + cls.dd0) * xd + (q.r0 + cls.dh0) * xh + (q.c0 + cls.dw0 + j) * 32 + g * 8);
+        char* dst = lds;
+#pragma unroll
+        for (int i0 = 0; i0 < ROWS; i0 += T16_WAVES) {
+            const int i = i0 + wave;
+            if (i < ROWS) {
+                const int kd = i / (TR + 2), rr = i - kd * (TR + 2);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + (kd * xd + rr * xh)), LDS_PTR(dst + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[RW][CT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 1024);        // this lane's B-fragment offset inside a buffer (tap 0)
+    // a tile's channel blocks stay on one block: block b walks tiles b, b + gridDim.x, ...
+    for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+      const Tile q = tile_of(tile);
+      for (int cb = 0; cb < p.cb_in; ++cb) {
+        // ---- the stage's taps: weights WPF taps ahead through buffer loads (the first WPF requested ahead of the DMA, so they land
+        // with it), B fragments from LDS
+        const unsigned wlo = 2u * (unsigned)(((q.cg * CT) * 16 + j) * 32 + g * 8);
+        const char* bb = lds + lane_b;
+        f16x8 wt[WPF + 1][CT];
+        // taps are requested in order: tap t's weights sit at t * w_tap (canonical [tap][cb32][cout][32] packing, checked by the host)
+        unsigned wo = 2u * (unsigned)(cb * (int)w_cb);
+        const unsigned wstep = 2u * (unsigned)w_tap;
+        auto wfetch = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                wt[set][ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo + ct * 1024, wo, 0));
+            wo += wstep;
+        };
+#pragma unroll
+        for (int t = 0; t < WPF; ++t) wfetch(t);
+        stage(q, cb);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + WPF < NT) wfetch((t + WPF) % (WPF + 1));
+            const int kd = t / 9, kh = (t - kd * 9) / 3, kw = t - kd * 9 - kh * 3;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const f16x8 bv = *(const f16x8*)(bb + (kd * (TR + 2) + r + kh) * 1024 + kw * 16);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[t % (WPF + 1)][ct], bv, acc[r][ct], 0, 0, 0);
+            }
+        }
+
+        // ---- after a tile's last channel block: epilogue (fp32 BN / residual / ReLU, fp16 store) and clear
+        if (cb + 1 == p.cb_in) {
+            const int col = q.c0 + j;
+            const bool col_ok = j < T16_COLS && col < p.OW;
+            if (dense1) {
+                float* yd = (float*)p.y;
+                const float* rd = (const float*)p.res;
+                if (g == 0 && q.cg == 0 && col_ok) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        const int row = q.r0 + wave * RW + r;
+                        if (row < p.OH) {
+                            const long o = (((long)q.n * p.OD + q.od) * p.OH + row) * p.OW + col;
+                            float v = acc[r][0].x;
+                            if (rd) v += rd[o];
+                            yd[o] = v;
+                        }
+                    }
+                }
+            } else {
+                _Float16* y = (_Float16*)p.y + p.y_off0 + (long)q.n * p.y_n_stride;
+                const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)q.n * p.r_n_stride : nullptr;
+                const int row0 = q.r0 + wave * RW;
+                const int yl = q.od * yd_ + row0 * yh + col * 32 + g * 4, rl = q.od * rd_ + row0 * rh + col * 32 + g * 4;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int cot = q.cg * CT + ct;
+                    const f32x4 sc = *(const f32x4*)(p.scale + cot * 16 + g * 4);
+                    const f32x4 sh = *(const f32x4*)(p.shift + cot * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        const int row = q.r0 + wave * RW + r;
+                        if (col_ok && row < p.OH) {
+                            const int yo = yl + (cot >> 1) * yc + r * yh + (cot & 1) * 16;
+                            f32x4 v = acc[r][ct] * sc + sh;
+                            if (res) {
+                                const int ro = rl + (cot >> 1) * rc + r * rh + (cot & 1) * 16;
+                                const f16x4 rv = *(const f16x4*)(res + ro);
+                                v.x += (float)rv.x; v.y += (float)rv.y; v.z += (float)rv.z; v.w += (float)rv.w;
+                            }
+                            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            f16x4 hv;
+                            hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
+                            *(f16x4*)(y + yo) = hv;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // every wave is done reading the buffer before the next stage's DMA overwrites it
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+}
+
+template <int RW, int CT, int ND>
+int launch(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int TR = RW * T16_WAVES;
+    constexpr size_t lds = (size_t)(ND * (TR + 2) * 1024 + 1024);            // + one row of slack for the unused lanes' over-read
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv16t_kernel<RW, CT, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + T16_COLS - 1) / T16_COLS) * (p.cout_pad / 16 / CT);
+    if (tiles >= (1L << 31)) return -5;
+    long per_cu = (160 * 1024) / (long)lds;                           // resident blocks per CU (LDS); at most 4 (16 waves)
+    if (per_cu > 4) per_cu = 4;
+    long blocks = 256 * per_cu;
+    if (blocks > tiles) blocks = tiles;
+    hipLaunchKernelGGL((conv16t_kernel<RW, CT, ND>), dim3((unsigned)blocks), dim3(64 * T16_WAVES), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <int ND>
+int pick(const drc_tapconv_params& p, hipStream_t s) {
+    const int ct = p.cout_pad / 16;
+    // 4 rows per wave (16-row tiles) when the map has them; 2 otherwise (less padding on 8 / 24-row maps)
+    const bool tall = p.OH % 16 == 0 || p.OH >= 48;
+    if (ct % 4 == 0) return tall ? launch<4, 4, ND>(p, s) : launch<2, 4, ND>(p, s);
+    if (ct % 2 == 0) return tall ? launch<4, 2, ND>(p, s) : launch<2, 2, ND>(p, s);
+    return tall ? launch<4, 1, ND>(p, s) : launch<2, 1, ND>(p, s);
+}
+
+}  // namespace
+
+extern "C" int drc_conv16_k3_tile_supported(const drc_tapconv_params* pp) {
+    if (!pp) return 0;
+    const drc_tapconv_params& p = *pp;
+    const drc_tap_class& k = p.cls[0];
+    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1) return 0;
+    if ((k.nd != 1 && k.nd != 3) || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 || k.sw != 1) return 0;
+    if (k.out_off_d || k.out_off_h || k.out_off_w) return 0;
+    if (k.wbase != 0 || k.wsw != 1 || k.wsh != 3 || (k.nd == 3 && k.wsd != 9)) return 0;          // weights in tap order
+    if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return 0;
+    return 1;
+}
+
+extern "C" int drc_conv16_k3_tile_fwd(const drc_tapconv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y) return -1;
+    if (p.reserved != 1 && (!p.scale || !p.shift)) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (!drc_conv16_k3_tile_supported(pp)) return -4;
+    if ((int64_t)p.cb_in * p.cout_pad * 32 * 27 * 2 >= (1LL << 31)) return -5;          // 32-bit byte offsets inside the weights
+    if (p.x_n_stride * 2 >= (1LL << 31) || (p.reserved != 1 && p.y_n_stride * 2 >= (1LL << 31)) ||
+        (p.res && p.reserved != 1 && p.r_n_stride * 2 >= (1LL << 31)))
+        return -5;                                                                       // ... and inside one unit of x / y / res
+    hipStream_t s = (hipStream_t)stream;
+    return p.cls[0].nd == 3 ? pick<3>(p, s) : pick<1>(p, s);
+}

@@ -1069,6 +1069,9 @@ def choose_tile16(OH, OW):
     return best[1], best[2]
 
 
+C16_TILE = {"enabled": True}      # stride-1 3x3x3 / 3x3 fp16 layers on the LDS-tiled kernel (conv16t.hip); False: conv16.hip as in round 2
+
+
 class ConvPlan16:
     """A resolved conv16 launch (tap-grid classes as in ConvPlan).  dense1: the 32 -> 1 classifier conv, whose single cout is
     written as a dense fp32 [N,D,H,W] volume (+ an optional dense fp32 residual)."""
@@ -1096,6 +1099,11 @@ class ConvPlan16:
         ntaps = sum(c["n"][0] * c["n"][1] * c["n"][2] for c in classes)
         self.flops = 2 * x.N * OD * OH * OW * ntaps * x.C * cout
         self.kname = "conv16_kernel<%d,%d>" % (min(-(-(p.R * p.WT) // 16), 4), 2 if (p.cout_pad // 16) % 2 == 0 else 1)
+        self.tile = bool(C16_TILE["enabled"] and _lib.lib().drc_conv16_k3_tile_supported(C.byref(p)))
+        if self.tile:
+            ct = p.cout_pad // 16
+            self.kname = "conv16t_kernel<%d,%d,%d>" % (4 if (OH % 16 == 0 or OH >= 48) else 2, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1),
+                                                        classes[0]["n"][0])
 
     def run(self, x, w16, scale, shift, y, res=None):
         p = self.p
@@ -1119,8 +1127,12 @@ class ConvPlan16:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        st = _lib.lib().drc_conv16_fwd(C.byref(p), _stream_ptr(self.device))
-        _lib.check(st, "drc_conv16_fwd")
+        if self.tile:
+            st = _lib.lib().drc_conv16_k3_tile_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_conv16_k3_tile_fwd")
+        else:
+            st = _lib.lib().drc_conv16_fwd(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, "drc_conv16_fwd")
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(self.device))
             TIMING.append((self.kname, self.flops, e0, e1))

@@ -296,6 +296,13 @@ int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const
  * params.reserved = 1 ("dense1"): only cout 0 is produced, as dense fp32 y[N,OD,OH,OW] (+ dense fp32 res) -- the 32 -> 1
  * classifier conv with the cumulative head add (stackhourglass.py:78-88,142-144).  No reference counterpart (fp32-only). */
 int drc_conv16_fwd(const drc_tapconv_params* p, void* stream);
+/* The stride-1 3x3x3 / 3x3 (pad 1, one tap class) layers of the same parameter block with the input tile staged in LDS
+ * (conv16t.hip): 16- or 8-row x 14-column output tiles of one slice per block, all taps read their voxel fragments from LDS.
+ * R, WT are ignored.  Reads up to 15 voxel lines past a plane's last padded row / column on ragged maps (values there do not reach a
+ * stored output): the tensor must be followed by that much readable memory (engine.Blocked16's slack).  _supported: 1 if the
+ * parameter block describes such a layer. */
+int drc_conv16_k3_tile_supported(const drc_tapconv_params* p);
+int drc_conv16_k3_tile_fwd(const drc_tapconv_params* p, void* stream);
 /* fp32 features (NCHW if in_blocked_pad < 0, else the fp32 blocked 2D layout with that halo) -> fp16 blocked cost volume
  * [N][2][Dp+2][Hp+2][Wp+2][32] (block 0 = left, block 1 = shifted right; stackhourglass.py:115-128); C <= 32. */
 int drc_cost_volume16_blocked_fwd(const float* left, const float* right, void* cost16, int N, int C, int Dp, int Hp, int Wp,

@@ -52,6 +52,7 @@ def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, t
     cp = E.cout_pad_of(cout)
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale.to(dev); sh[:cout] = shift.to(dev)
+    assert plan.tile == (stride == 1 and not transposed)            # stride-1 layers: the LDS-tiled kernel (conv16t.hip)
     plan.run(xb, E.pack_weight16(w.to(dev), transposed), sc, sh, yb, rb)
     got = yb.to_dense().cpu()
     assert got.shape == ref.shape
