@@ -118,6 +118,10 @@ _SIGS = {
     "drc_roi_align_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "drc_align_roi_pairs": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "drc_conv16_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_dense_to_blocked16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_avgpool2d_blocked16_slice": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_bilinear_up_blocked16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_cost_volume16_from16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv16_k3_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
     "drc_conv16_k3_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_cost_volume16_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

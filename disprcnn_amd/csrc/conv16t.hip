@@ -39,17 +39,26 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define T16_WAVES 4
 #define T16_COLS 14
+// B fragments are re-read from LDS for every tap (volatile): left to itself the compiler keeps each distinct (slice, row, kw) fragment
+// of a stage live (18 - 54 x 4 registers), which costs the second and third wave per SIMD that hide the staging waits.
+#ifndef T16_OCC_MID
+#define T16_OCC_MID 3
+#endif
+#ifndef T16_BVOL
+#define T16_BVOL volatile
+#endif
 #ifndef T16_WPF_NARROW
-#define T16_WPF_NARROW 9   /* weight sets (taps) in flight ahead of the MFMAs, CT <= 2: a tap is only RW*CT 16-cycle MFMAs and the */
+#define T16_WPF_NARROW 5   /* weight sets (taps) in flight ahead of the MFMAs, CT <= 2: a tap is only RW*CT 16-cycle MFMAs and the */
 #endif                     /* 27 x CT KiB of a stage's weights miss the L1 next to the DMA traffic (L2 round trip ~700+ cycles)    */
 #ifndef T16_WPF_WIDE
-#define T16_WPF_WIDE 5     /* CT = 4 (16 registers a set) */
+#define T16_WPF_WIDE 2     /* CT = 4 (16 registers a set) */
 #endif
 
 namespace {
 
 template <int RW, int CT, int ND>
-__global__ __launch_bounds__(64 * T16_WAVES) void conv16t_kernel(const drc_tapconv_params p) {
+__global__ __launch_bounds__(64 * T16_WAVES) __attribute__((amdgpu_waves_per_eu(RW * CT >= 16 ? 2 : (RW * CT >= 8 ? T16_OCC_MID : 4))))
+void conv16t_kernel(const drc_tapconv_params p) {
     constexpr int TR = RW * T16_WAVES;                 // output rows per block tile
     constexpr int ROWS = ND * (TR + 2);                // staged rows per stage
     constexpr int NT = ND * 9;
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void conv16t_kernel(const drc_tapco
         // ---- the stage's taps: weights WPF taps ahead through buffer loads (the first WPF requested ahead of the DMA, so they land
         // with it), B fragments from LDS
         const unsigned wlo = 2u * (unsigned)(((q.cg * CT) * 16 + j) * 32 + g * 8);
-        const char* bb = lds + lane_b;
+        const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + lane_b;
         f16x8 wt[WPF + 1][CT];
         // taps are requested in order: tap t's weights sit at t * w_tap (canonical [tap][cb32][cout][32] packing, checked by the host)
         unsigned wo = 2u * (unsigned)(cb * (int)w_cb);
@@ -126,17 +135,29 @@ __global__ __launch_bounds__(64 * T16_WAVES) void conv16t_kernel(const drc_tapco
         for (int t = 0; t < WPF; ++t) wfetch(t);
         stage(q, cb);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t + WPF < NT) wfetch((t + WPF) % (WPF + 1));
+        // software pipeline, one tap deep: tap t+1's B fragments (and tap t+WPF's weights) are requested, then tap t's MFMAs issue;
+        // the scheduling fences keep the compiler from hoisting every read of the unrolled stage to its top (registers, spills)
+        f16x8 bA[RW], bB[RW];
+        auto bfetch = [&](f16x8 (&bv)[RW], int t) __attribute__((always_inline)) {
             const int kd = t / 9, kh = (t - kd * 9) / 3, kw = t - kd * 9 - kh * 3;
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const f16x8 bv = *(const f16x8*)(bb + (kd * (TR + 2) + r + kh) * 1024 + kw * 16);
+            for (int r = 0; r < RW; ++r)
+                bv[r] = *(const __attribute__((address_space(3))) T16_BVOL f16x8*)(bb + (kd * (TR + 2) + r + kh) * 1024 + kw * 16);
+        };
+        auto mfmas = [&](const f16x8 (&bv)[RW], int set) __attribute__((always_inline)) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[t % (WPF + 1)][ct], bv, acc[r][ct], 0, 0, 0);
-            }
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[set][ct], bv[r], acc[r][ct], 0, 0, 0);
+        };
+        bfetch(bA, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) { if (t & 1) bfetch(bA, t + 1); else bfetch(bB, t + 1); }
+            if (t + WPF < NT) wfetch((t + WPF) % (WPF + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            if (t & 1) mfmas(bB, t % (WPF + 1)); else mfmas(bA, t % (WPF + 1));
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- after a tile's last channel block: epilogue (fp32 BN / residual / ReLU, fp16 store) and clear

@@ -1040,6 +1040,45 @@ class Blocked16:
         return v.permute(0, 1, 5, 2, 3, 4).reshape(self.N, self.cb * CB16, self.D, self.H, self.W)[:, : self.C].float()
 
 
+class Blocked16Slice:
+    """Channel blocks [cb_off, cb_off + ceil(C/32)) of a Blocked16 tensor (a concat operand): same strides, storage view at the slice."""
+
+    def __init__(self, base, cb_off, C_):
+        self.base, self.cb_off = base, cb_off
+        self.N, self.C, self.D, self.H, self.W = base.N, C_, base.D, base.H, base.W
+        self.pd, self.ph, self.pw = base.pd, base.ph, base.pw
+        self.cb = (C_ + CB16 - 1) // CB16
+        assert cb_off >= 0 and cb_off + self.cb <= base.cb
+        self.Dp, self.Hp, self.Wp = base.Dp, base.Hp, base.Wp
+        self.h_stride, self.d_stride, self.cb_stride, self.n_stride = base.h_stride, base.d_stride, base.cb_stride, base.n_stride
+        self.storage = base.storage[cb_off * base.cb_stride:]
+        self.interior_off = base.interior_off
+        self.device = base.device
+
+
+def dense_to_blocked16(dense, out):
+    """fp32 [N,C,H,W] -> interior of the 2D Blocked16 `out` (HIP kernel)."""
+    require_gpu(dense, "dense_to_blocked16")
+    dense = dense.contiguous().float()
+    st = _lib.lib().drc_dense_to_blocked16(_ptr(dense), _ptr(out.storage), out.N, out.C, out.H, out.W, out.ph, out.pw, _stream_ptr(out.device))
+    _lib.check(st, "drc_dense_to_blocked16")
+    return out
+
+
+def plan_conv2d16(x, y, k, stride, pad, dilation, cout, relu):
+    """Conv2d(k, stride, pad, dilation) on 2D Blocked16 tensors (D = 1, pd = 0): the LDS-tiled kernel for stride-1 undilated 3x3 layers,
+    conv16.hip's generic tap walk for the rest (stride 2, dilation, 1x1)."""
+    assert x.pd == 0 and x.D == 1
+    return ConvPlan16(x, y, taps_conv((1, k, k), (1, dilation, dilation), (0, pad, pad), (0, x.ph, x.pw)), stride, 1, (1, y.H, y.W), cout, relu)
+
+
+def cost_volume16_from16(feat, right_first_unit, out, lo4, hi4):
+    """feat: 2D Blocked16 [units,32ch,H',W'] (left units, then right units from `right_first_unit`) -> out: Blocked16 [N,64,D',H',W'] halo 1."""
+    st = _lib.lib().drc_cost_volume16_from16(_ptr(feat.storage), _ptr(out.storage), out.N, right_first_unit, feat.C, out.D, out.H, out.W, lo4, hi4,
+                                             feat.ph, _stream_ptr(out.device))
+    _lib.check(st, "drc_cost_volume16_from16")
+
+
 def pack_weight16(w, transposed=False):
     """[Cout,Cin,*k] (or ConvTranspose [Cin,Cout,*k]) fp32 -> [K taps][ceil(Cin/32)][cout_pad][32] fp16: lane (cout j, g) of the
     f16 MFMA's A operand reads channels 8g..8g+7 as one 16-byte load."""

@@ -386,7 +386,7 @@ class PSMNetRuntime:
         m, dev = self.model, self.device
         out = {}
         for name, c in W.items():
-            if isinstance(c, _Conv) and not name.startswith("fe."):
+            if isinstance(c, _Conv):            # (the 2D CNN's weights: used when PSMNet.feature_storage == "f16")
                 out[name] = E.pack_weight16(c.conv.weight.detach().to(device=dev, dtype=torch.float32), c.transposed)
         for k in (1, 2, 3):
             out[f"classif{k}.2"] = E.pack_weight16(getattr(m, f"classif{k}")[2].weight.detach().to(device=dev, dtype=torch.float32))
@@ -470,6 +470,12 @@ class PSMNetRuntime:
             raise ValueError("PSMNet.regressor_storage must be 'f32' or 'f16'")
         if mode == "f16" and training:
             raise RuntimeError("the fp16-storage regressor is an inference path (BASELINE configs[3]); train in fp32 like the reference")
+        return mode == "f16"
+
+    def _features_f16(self):
+        mode = getattr(self.model, "feature_storage", "f32")
+        if mode not in ("f32", "f16"):
+            raise ValueError("PSMNet.feature_storage must be 'f32' or 'f16'")
         return mode == "f16"
 
     def _check_disp(self):
@@ -627,6 +633,101 @@ class PSMNetRuntime:
         run("fe.lastconv.2", "fe.lastconv.2", "last0", "feat")
         return t["feat"]
 
+    # ------------------------------------------------------------------ fp16-storage 2D feature CNN (BASELINE configs[3]; eval only)
+    def _ws2d16(self, N, H, W):
+        """The schedule of _ws2d on Blocked16 tensors.  The 320-channel concat is 10 blocks of 32: raw (64) -> blocks 0-1, skip (128) ->
+        2-5, branch4..branch1 (32 each) -> 6, 7, 8, 9 (concatenation order of submodule.py:134-135)."""
+        key = self._slotted(("2d16", N, H, W))
+        ws = self._ws_get(key)
+        if ws is not None:
+            return ws
+        if H % 4 or W % 4 or H // 4 < 56 or W // 4 < 56:
+            raise ValueError("PSMNet needs H,W multiples of 4 and >= 224 (fixed AvgPool2d(56), reference submodule.py:76)")
+        pool = self._pool_for(self._slotted(("2d16", H, W)), N)
+        names = iter(range(1 << 30))
+        B2 = lambda c, h, w, pad=1: pool.blocked16(("t16", next(names)), N, c, 1, h, w, 0, pad, pad)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        t, p = {}, {}
+        t["img"] = B2(3, H, W)
+        t["f0"], t["f1"], t["f2"] = B2(32, H2, W2), B2(32, H2, W2), B2(32, H2, W2)
+        p["fe.firstconv.0"] = E.plan_conv2d16(t["img"], t["f0"], 3, 2, 1, 1, 32, True)
+        p["fe.firstconv.2"] = E.plan_conv2d16(t["f0"], t["f1"], 3, 1, 1, 1, 32, True)
+        p["fe.firstconv.4"] = E.plan_conv2d16(t["f1"], t["f2"], 3, 1, 1, 1, 32, True)
+        t["cat"] = B2(320, H4, W4)
+        sched = []
+        cur, cur_hw = "f2", (H2, W2)
+        for name, planes, nblk, stride, dil in TRUNK_STAGES:
+            pad = 2 if name in ("layer3", "layer4") else 1      # tensors read by the dilated layer4 carry halo 2
+            for b in range(nblk):
+                s = stride if b == 0 else 1
+                hw = (cur_hw[0] // s, cur_hw[1] // s)
+                u = f"fe.{name}.{b}"
+                mid = u + ".mid"
+                t[mid] = B2(planes, hw[0], hw[1], pad)
+                p[u + ".conv1"] = E.plan_conv2d16(t[cur], t[mid], 3, s, 1 if dil == 1 else dil, dil, planes, True)
+                sched.append((u + ".conv1", cur, mid, None))
+                res = cur
+                if (u + ".down") in self._w:
+                    t[u + ".sc"] = B2(planes, hw[0], hw[1], pad)
+                    p[u + ".down"] = E.plan_conv2d16(t[cur], t[u + ".sc"], 1, s, 0, 1, planes, False)
+                    sched.append((u + ".down", cur, u + ".sc", None))
+                    res = u + ".sc"
+                last = b == nblk - 1
+                if name == "layer2" and last:
+                    t[u + ".out"] = E.Blocked16Slice(t["cat"], 0, 64)
+                elif name == "layer4" and last:
+                    t[u + ".out"] = E.Blocked16Slice(t["cat"], 2, 128)
+                else:
+                    t[u + ".out"] = B2(planes, hw[0], hw[1], pad)
+                p[u + ".conv2"] = E.plan_conv2d16(t[mid], t[u + ".out"], 3, 1, 1 if dil == 1 else dil, dil, planes, False)
+                sched.append((u + ".conv2", mid, u + ".out", res))
+                cur, cur_hw = u + ".out", hw
+        slot = {"branch4": 6, "branch3": 7, "branch2": 8, "branch1": 9}
+        spp = []
+        for name, k in SPP_BRANCHES:
+            oh, ow = H4 // k, W4 // k
+            t[name + ".pool"] = B2(128, oh, ow, 0)
+            t[name + ".conv"] = B2(32, oh, ow, 0)
+            p["fe." + name] = E.plan_conv2d16(t[name + ".pool"], t[name + ".conv"], 1, 1, 0, 1, 32, True)
+            spp.append((name, k, oh, ow, slot[name]))
+        t["last0"] = B2(128, H4, W4, 0)
+        t["feat"] = B2(32, H4, W4, 1)
+        p["fe.lastconv.0"] = E.plan_conv2d16(t["cat"], t["last0"], 3, 1, 1, 1, 128, True)
+        p["fe.lastconv.2"] = E.plan_conv2d16(t["last0"], t["feat"], 1, 1, 0, 1, 32, False)
+        ws = dict(t=t, p=p, pool=pool, sched=sched, spp=spp, skip=cur, dims=(H4, W4), flops=sum(pl.flops for pl in p.values()))
+        return self._ws_put(key, ws)
+
+    def _features16(self, ws, W, images):
+        """feature_extraction with fp16 storage (fp32 accumulation, BatchNorm folded in fp32): -> Blocked16 [N,32,H/4,W/4] (halo 1)."""
+        from ... import _lib
+        t, p = ws["t"], ws["p"]
+        W16 = self._weights16(W)
+        lib, sp = _lib.lib(), E._stream_ptr(self.device)
+        E.dense_to_blocked16(images, t["img"])
+
+        def run(name, x, y, res=None):
+            c = W[name]
+            p[name].run(t[x], W16[name], c.scale, c.shift, t[y], t[res] if res else None)
+
+        run("fe.firstconv.0", "img", "f0")
+        run("fe.firstconv.2", "f0", "f1")
+        run("fe.firstconv.4", "f1", "f2")
+        for name, x, y, res in ws["sched"]:
+            run(name, x, y, res)
+        skip, cat = t[ws["skip"]], t["cat"]
+        H4, W4 = ws["dims"]
+        for name, k, oh, ow, cb_off in ws["spp"]:
+            pool, conv = t[name + ".pool"], t[name + ".conv"]
+            st = lib.drc_avgpool2d_blocked16_slice(E._ptr(cat.storage), E._ptr(pool.storage), cat.N, skip.cb, cat.H, cat.W, cat.ph, k, oh, ow, 0,
+                                                   cat.cb, skip.cb_off, sp)
+            _lib.check(st, "drc_avgpool2d_blocked16_slice")
+            run("fe." + name, name + ".pool", name + ".conv")
+            st = lib.drc_bilinear_up_blocked16(E._ptr(conv.storage), E._ptr(cat.storage), cat.N, 1, oh, ow, 0, H4, W4, cat.ph, cat.cb, cb_off, sp)
+            _lib.check(st, "drc_bilinear_up_blocked16")
+        run("fe.lastconv.0", "cat", "last0")
+        run("fe.lastconv.2", "last0", "feat")
+        return t["feat"]
+
     def _avgpool_slice(self, lib, skip, pool, k, oh, ow, sp):
         """AvgPool2d(k,k) of output_skip, which lives in channel blocks 4..11 of the 20-block concat tensor."""
         base = skip.base
@@ -652,6 +753,13 @@ class PSMNetRuntime:
         if self._use_f16(training):
             # fp32 2D feature CNN (its output is the cost volume's input), fp16-storage cost volume + 3D regressor
             ws3 = self._ws3d16(N, (mx - mn) // 4, H // 4, W // 4)
+            if self._features_f16():
+                # fp16-storage 2D CNN as well (feature_storage = "f16"): blocked fp16 features straight into the fp16 cost volume
+                ws2 = self._ws2d16(2 * N, H, W)
+                self._stamp(ws3, ws2)
+                feat = self._features16(ws2, Wt, torch.cat((left, right), 0))
+                E.cost_volume16_from16(feat, N, ws3["t"]["cost"], mn // 4, mx // 4)
+                return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
             ws2 = self._ws2d(2 * N, H, W)
             self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, torch.cat((left, right), 0))

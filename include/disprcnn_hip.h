@@ -302,6 +302,18 @@ int drc_conv16_fwd(const drc_tapconv_params* p, void* stream);
  * stored output): the tensor must be followed by that much readable memory (engine.Blocked16's slack).  _supported: 1 if the
  * parameter block describes such a layer. */
 int drc_conv16_k3_tile_supported(const drc_tapconv_params* p);
+/* The rest of the fp16-storage 2D feature CNN (ops16.hip; BASELINE configs[3], the reference has no fp16 path): fp32 NCHW image ->
+ * blocked fp16 [N][ceil(C/32)][H+2ph][W+2pw][32] (interior; the caller zero-fills the halo once); AvgPool2d(k,k) of a channel-block slice
+ * and align_corners=True bilinear up-sampling into one (submodule.py:76-90,120-135); and the concat cost volume of
+ * stackhourglass.py:115-128 from blocked fp16 feature maps (<= 32 channels = one block; unit n = left view, unit n + right_first_unit =
+ * right view; feat_pad = their halo) into the blocked fp16 volume drc_cost_volume16_blocked_fwd writes. */
+int drc_dense_to_blocked16(const float* x, void* y16, int N, int C, int H, int W, int ph, int pw, void* stream);
+int drc_avgpool2d_blocked16_slice(const void* x16, void* y16, int N, int CB32, int H, int W, int px, int k, int OH, int OW, int py,
+                                  int x_cb_total, int x_cb_off, void* stream);
+int drc_bilinear_up_blocked16(const void* x16, void* y16, int N, int CB32, int IH, int IW, int px, int OH, int OW, int py, int y_cb_total,
+                              int y_cb_off, void* stream);
+int drc_cost_volume16_from16(const void* feat16, void* cost16, int N, int right_first_unit, int C, int Dp, int Hp, int Wp, int mindisp4,
+                             int maxdisp4, int feat_pad, void* stream);
 int drc_conv16_k3_tile_fwd(const drc_tapconv_params* p, void* stream);
 /* fp32 features (NCHW if in_blocked_pad < 0, else the fp32 blocked 2D layout with that halo) -> fp16 blocked cost volume
  * [N][2][Dp+2][Hp+2][Wp+2][32] (block 0 = left, block 1 = shifted right; stackhourglass.py:115-128); C <= 32. */

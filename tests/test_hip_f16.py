@@ -132,3 +132,35 @@ def test_stress_shape_64_rois_f16_vs_fp32(dev):
     oerr = (got[pick] - oref).abs()
     print("stress f16 vs CPU fp32 oracle (2 ROIs): mean/max |err| px", oerr.mean().item(), oerr.max().item())
     assert oerr.mean().item() <= 1e-1
+
+
+def test_f16_feature_cnn_vs_fp32_path(dev):
+    """Round 3: PSMNet.feature_storage = "f16" -- the 2D feature CNN on fp16-storage tensors too (conv16t.hip for the stride-1 3x3 layers,
+    conv16.hip for the strided / dilated / 1x1 ones, ops16.hip for the SPP pools, up-samplings and the cost volume), against the fp32
+    HIP path.  The feature maps agree to 4e-3 of their range (mean 6e-4: the fp16 rounding of ~60 layers, no border or plumbing term:
+    fp32 features rounded to fp16 and pushed through the same cost-volume kernel reproduce the regressor-only error, 0.052 px).  The
+    regressor amplifies that to a mean 0.35 px on this synthetic-weight network -- 7x the regressor-only figure -- so the SURVEY 8c
+    bound (5e-2 px) cannot be met with fp16 feature storage; the mode is opt-in, its error is what this test pins, and the headline
+    fp16 numbers keep the fp32 feature CNN."""
+    from disprcnn_amd import engine as E
+    left, right = synth.synth_images(4, 224, 224, tag="feat16")
+    m32 = _model(dev, "B", 48, -48, "f32")
+    m16 = _model(dev, "B", 48, -48, "f16")
+    m16.feature_storage = "f16"
+    with torch.no_grad():
+        ref = m32((left.to(dev), right.to(dev))).cpu()
+        got = m16((left.to(dev), right.to(dev))).cpu()
+    rt = m16._rt
+    ws16 = [w for k, w in rt._ws.items() if k[0] == "2d16"][0]
+    ws32 = m32._rt._ws[("2d", 8, 224, 224)]
+    assert ws16["p"]["fe.layer1.0.conv1"].tile and ws16["p"]["fe.lastconv.0"].tile and not ws16["p"]["fe.layer4.0.conv1"].tile
+    f32 = ws32["t"]["feat"].to_dense()[:, :, 0].cpu()
+    f16 = ws16["t"]["feat"].to_dense()[:, :, 0].cpu()
+    ferr = (f16 - f32).abs().max().item() / f32.abs().max().item()
+    err = (got - ref).abs()
+    print(f"f16 feature CNN: features max err / range {ferr:.2e}; disparity mean/max |err| px {err.mean().item():.4f} {err.max().item():.4f}")
+    assert torch.isfinite(got).all() and ferr <= 1e-2
+    assert err.mean().item() <= 0.5                                  # measured 0.345 (see above): a characterisation, not the 8c bound
+    with pytest.raises(ValueError):
+        m16.feature_storage = "bf16"
+        m16((left.to(dev), right.to(dev)))

@@ -8,10 +8,12 @@ from disprcnn_amd.modeling.backbone import build_backbone
 from disprcnn_amd.utils import synth
 dev = torch.device("cuda:0")
 what = os.environ.get("WHAT", "psm")
-if what == "psm16":
+if what in ("psm16", "psm16f"):
     m = PSMNet(48, -48)
     m.load_state_dict(synth.synth_state_dict(m.state_dict()), strict=True)
     m.regressor_storage = "f16"
+    if what == "psm16f":
+        m.feature_storage = "f16"
     m = m.to(dev).eval()
     l, r = synth.synth_images(64, 224, 224, tag="benchB64")
     l, r = l.to(dev), r.to(dev)
