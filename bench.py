@@ -388,13 +388,26 @@ def rank0_extras(dev, extra):
     with torch.no_grad():
         out16 = mB((l64, r64))
         t16 = _time(lambda: mB((l64, r64)), 1, 3)
+    # ... and with the 2D feature CNN on fp16-storage tensors as well (PSMNet.feature_storage = "f16", opt-in: round 3)
+    mB.feature_storage = "f16"
+    with torch.no_grad():
+        out16f = mB((l64, r64))
+        t16f = _time(lambda: mB((l64, r64)), 1, 3)
+    mB.feature_storage = "f32"
     mB.regressor_storage = "f32"
     with torch.no_grad():
-        err16 = (out16 - mB((l64, r64))).abs().mean().item()
+        ref64 = mB((l64, r64))
+        err16 = (out16 - ref64).abs().mean().item()
+        err16f = (out16f - ref64).abs().mean().item()
+    del ref64, out16f
     extra["stress_64roi_224x224x96_f16_storage"] = {"roi_pairs_per_s": round(64 / t16, 1), "ms_per_64_roi_image": round(t16 * 1e3, 2),
                                                     "regressor_direct_conv_equivalent_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / t16 / 1e12, 1),
                                                     "mean_abs_err_px_vs_f32_path": round(err16, 4),
                                                     "dtype": "f16 storage / f32 accumulate (v_mfma_f32_16x16x32_f16) for cost volume + 3D regressor; 2D CNN f32"}
+    extra["stress_64roi_224x224x96_f16_storage_all"] = {
+        "roi_pairs_per_s": round(64 / t16f, 1), "ms_per_64_roi_image": round(t16f * 1e3, 2), "mean_abs_err_px_vs_f32_path": round(err16f, 4),
+        "dtype": "f16 storage / f32 accumulate for the 2D feature CNN too (conv16t.hip LDS tiles + conv16.hip + ops16.hip); opt-in: the fp16 "
+                 "rounding of the 60-layer 2D CNN is amplified by the regressor (error above), the SURVEY 8c bound holds for the mode above only"}
     del l64, r64, out16
     # ---- BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
     # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
