@@ -36,7 +36,11 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
     const int per_cg = p.N * OD * n_rt * n_wt;       // groups of one cout group: (n, od, row tile, col tile)
     const long groups = (long)(p.cout_pad / 16 / CT) * per_cg;
     const long workers = (long)gridDim.x * DW_WAVES;
-    const long wid = (long)blockIdx.x * DW_WAVES + wave;
+    // blocks are numbered XCD by XCD (block b runs on XCD b % 8): an XCD then walks one contiguous share of the cout-group-major group
+    // list, i.e. 1/8 of the weights -- with consecutive shares spread round-robin every XCD's L2 pulled ALL weights (the trunk's
+    // 512 -> 512 layers on 12 x 39: 95 MB fetched per launch for 9.4 MB of weights, round 3)
+    const long bid = (gridDim.x & 7) == 0 ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    const long wid = bid * DW_WAVES + wave;
     long gcur = groups * wid / workers;              // equal contiguous shares
     const long gend = groups * (wid + 1) / workers;
     if (gcur >= gend) return;
@@ -112,6 +116,72 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
             _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                          \
                 acc[vt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[ct][s4], B[vt][s4], acc[vt][ct], 0, 0, 0);
 
+    // folded BN, residual, ReLU, store; clears the accumulators
+    auto epilogue = [&](const Group& cur) __attribute__((always_inline)) {
+            f32x4 bn_sc[CT], bn_sh[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                bn_sc[ct] = *(const f32x4*)(p.scale + (cur.ct0 + ct) * 16 + g * 4);
+                bn_sh[ct] = *(const f32x4*)(p.shift + (cur.ct0 + ct) * 16 + g * 4);
+            }
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) {
+                const int r = vr[vt], c = vc[vt];
+                if (r >= 0 && r < cur.nr && c < cur.nc) {
+                    const int64_t yo = p.y_off0 + (int64_t)cur.n * p.y_n_stride + (int64_t)cur.od * p.y_d_stride +
+                                       (int64_t)(cur.oh0 + r) * p.y_h_stride + (int64_t)(cur.ow0 + c) * 16 + g * 4;
+                    const int64_t ro = p.r_off0 + (int64_t)cur.n * p.r_n_stride + (int64_t)cur.od * p.r_d_stride +
+                                       (int64_t)(cur.oh0 + r) * p.r_h_stride + (int64_t)(cur.ow0 + c) * 16 + g * 4;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        f32x4 v = acc[vt][ct] * bn_sc[ct] + bn_sh[ct];
+                        if (p.res) v += *(const f32x4*)(p.res + ro + (int64_t)(cur.ct0 + ct) * p.r_cb_stride);
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        *(f32x4*)(p.y + yo + (int64_t)(cur.ct0 + ct) * p.y_cb_stride) = v;
+                    }
+                }
+            }
+            DW_CLEAR_ACC()
+    };
+
+    // Small tiles (VT*CT <= 4: <= 16 MFMAs = 512 cycles a step; the trunk's 512-channel layers on 12 x 39 maps walk 288 such steps per
+    // group): one step of prefetch left every step waiting out an L2 round trip (MFMA busy 26 %, 108 us for 4.4 GFLOP, round 3).  They
+    // run a ring of PF + 1 operand sets, PF steps ahead, pinned in front of the MFMAs; no prefetch across groups (a group is long).
+    if constexpr (VT * CT <= 4) {
+        constexpr int PF = VT * CT <= 2 ? 6 : 4, NB = PF + 1;
+        f32x4 rB[NB][VT], rW[NB][CT];
+#pragma unroll 1
+        for (; gcur < gend; ++gcur) {
+            const Group cur = decode(gcur);
+            set_lane_vo(cur);
+            const int last = steps - 1;
+#define DW_RING_PRO(U) if constexpr (U < PF) load_step(rB[U], rW[U], cur, lane_vo, U < last ? U : last);
+            DW_RING_PRO(0) DW_RING_PRO(1) DW_RING_PRO(2) DW_RING_PRO(3) DW_RING_PRO(4) DW_RING_PRO(5)
+#undef DW_RING_PRO
+            int s = 0;
+            // (explicit ring steps: left as a `#pragma unroll` loop the compiler kept the set index dynamic and put the ring in scratch)
+#define DW_RING_STEP(U)                                                                                \
+            if constexpr (U < NB) {                                                                    \
+                const int sf = s + U + PF;                                                             \
+                load_step(rB[(U + PF) % NB], rW[(U + PF) % NB], cur, lane_vo, sf < last ? sf : last);  \
+                __builtin_amdgcn_sched_barrier(0);                                                     \
+                DW_MFMA(rB[U], rW[U])                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                     \
+            }
+            for (; s + NB <= steps; s += NB) {
+                DW_RING_STEP(0) DW_RING_STEP(1) DW_RING_STEP(2) DW_RING_STEP(3) DW_RING_STEP(4) DW_RING_STEP(5) DW_RING_STEP(6)
+            }
+#undef DW_RING_STEP
+            const int rem = steps - s;
+#define DW_RING_TAIL(U)                                                                                \
+            if constexpr (U < NB - 1) { if (U < rem) { DW_MFMA(rB[U], rW[U]) } }
+            DW_RING_TAIL(0) DW_RING_TAIL(1) DW_RING_TAIL(2) DW_RING_TAIL(3) DW_RING_TAIL(4) DW_RING_TAIL(5)
+#undef DW_RING_TAIL
+            epilogue(cur);
+        }
+        return;
+    }
+
     f32x4 bA[VT], bB[VT], wA[CT], wB[CT];
     Group cur = decode(gcur);
     set_lane_vo(cur);
@@ -157,33 +227,7 @@ __global__ __launch_bounds__(64 * DW_WAVES) void downdirect_kernel(const drc_tap
             for (int ct = 0; ct < CT; ++ct) wA[ct] = wB[ct];
         }
 
-        // ---- epilogue: folded BN, residual, ReLU, store; clear the accumulators
-        {
-            f32x4 bn_sc[CT], bn_sh[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                bn_sc[ct] = *(const f32x4*)(p.scale + (cur.ct0 + ct) * 16 + g * 4);
-                bn_sh[ct] = *(const f32x4*)(p.shift + (cur.ct0 + ct) * 16 + g * 4);
-            }
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt) {
-                const int r = vr[vt], c = vc[vt];
-                if (r >= 0 && r < cur.nr && c < cur.nc) {
-                    const int64_t yo = p.y_off0 + (int64_t)cur.n * p.y_n_stride + (int64_t)cur.od * p.y_d_stride +
-                                       (int64_t)(cur.oh0 + r) * p.y_h_stride + (int64_t)(cur.ow0 + c) * 16 + g * 4;
-                    const int64_t ro = p.r_off0 + (int64_t)cur.n * p.r_n_stride + (int64_t)cur.od * p.r_d_stride +
-                                       (int64_t)(cur.oh0 + r) * p.r_h_stride + (int64_t)(cur.ow0 + c) * 16 + g * 4;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        f32x4 v = acc[vt][ct] * bn_sc[ct] + bn_sh[ct];
-                        if (p.res) v += *(const f32x4*)(p.res + ro + (int64_t)(cur.ct0 + ct) * p.r_cb_stride);
-                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        *(f32x4*)(p.y + yo + (int64_t)(cur.ct0 + ct) * p.y_cb_stride) = v;
-                    }
-                }
-            }
-            DW_CLEAR_ACC()
-        }
+        epilogue(cur);
         if (!has_next) break;
         ++gcur;
         cur = nxg;
