@@ -28,16 +28,17 @@ def nms(dets, scores, threshold, strict=True):
     return torch.sort(order[keep.bool()])[0]
 
 
-def nms_pair(dets_a, dets_b, scores, threshold, strict=True):
+def nms_pair(dets_a, dets_b, scores, threshold, strict=True, joint=False):
     """NMS of two box sets that share their scores (the left and right views of a stereo detection list) in one launch pair:
-    -> (keep_a, keep_b), each as nms() would return it.  One sort, one mask launch, one walk launch for both views."""
+    -> (keep_a, keep_b), each as nms() would return it; joint=True -> the ascending intersection of the two (what
+    double_view_boxlist_nms keeps, boxlist_ops.py:49-79).  One sort, one mask launch, one walk launch for both views."""
     E.require_gpu(dets_a, "nms_pair")
     n = dets_a.shape[0]
     if dets_b.shape != dets_a.shape or dets_a.dim() != 2 or dets_a.shape[1] != 4 or scores.shape != dets_a.shape[:1]:
         raise RuntimeError("nms_pair expects two [N,4] box sets and scores [N]")
     if n == 0:
         e = torch.empty(0, dtype=torch.int64, device=dets_a.device)
-        return e, e.clone()
+        return e if joint else (e, e.clone())
     order = torch.sort(scores.float(), dim=0, descending=True, stable=True)[1]
     boxes = torch.stack((dets_a.float().index_select(0, order), dets_b.float().index_select(0, order))).contiguous()
     mask = torch.empty(2 * n * ((n + 63) // 64), dtype=torch.int64, device=dets_a.device)
@@ -45,4 +46,6 @@ def nms_pair(dets_a, dets_b, scores, threshold, strict=True):
     st = _lib.lib().drc_nms_sorted_batch_fwd(E._ptr(boxes), 2, n, float(threshold), int(bool(strict)), E._ptr(mask), E._ptr(keep), E._stream_ptr(dets_a.device))
     _lib.check(st, "drc_nms_sorted_batch_fwd")
     kb = keep.bool()
+    if joint:           # the kept sets' intersection straight from the flags: one compaction instead of two + unique/sort/compare
+        return torch.sort(order[kb[0] & kb[1]])[0]
     return torch.sort(order[kb[0]])[0], torch.sort(order[kb[1]])[0]

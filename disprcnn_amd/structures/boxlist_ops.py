@@ -28,8 +28,7 @@ def double_view_boxlist_nms(left_boxlist, right_boxlist, nms_thresh, max_proposa
     if nms_thresh <= 0:
         return left_boxlist, right_boxlist
     if use_keep == "joint":       # both views share their scores, hence their order: one sort and one launch pair for the two
-        kl, kr = _box_nms_pair(left_boxlist.bbox, right_boxlist.bbox, left_boxlist.get_field(score_field), nms_thresh)
-        keep = intersect_sorted(kl, kr)
+        keep = _box_nms_pair(left_boxlist.bbox, right_boxlist.bbox, left_boxlist.get_field(score_field), nms_thresh, joint=True)
     elif use_keep == "left":
         keep = _box_nms(left_boxlist.bbox, left_boxlist.get_field(score_field), nms_thresh)
     else:
