@@ -11,7 +11,8 @@ import torch
 from torch import nn
 
 from ...structures.bounding_box import BoxList
-from ..head_ops import EngineConv2d, gemm_bias_act
+from ... import engine as E
+from ..head_ops import BlockedConv2d, gemm_bias_act
 from ..poolers import Pooler
 
 
@@ -30,15 +31,34 @@ class MaskRCNNFPNFeatureExtractor(nn.Module):
             nn.init.constant_(conv.bias, 0)
             self.add_module(name, conv)
             self.blocks.append(name)
-            self._engine.append(EngineConv2d(conv, relu=True))
+            self._engine.append(BlockedConv2d(conv, relu=True))
             nxt = feat
         self.out_channels = nxt
+        self._bufs = {}          # (h, w, device) -> two blocked ping-pong tensors sized for a capacity bucket of the detection count
 
     def forward(self, x, proposals):
+        """ROIAlign, then the conv chain WITHOUT leaving the engine's blocked layout (round 3): one conversion in, one out."""
         x = self.pooler(x, proposals)
+        n, c, h, w = x.shape
+        if n == 0:
+            return x.new_zeros(0, self.out_channels, h, w)
+        key = (h, w, x.device)
+        cmax = max([c] + [e.cout for e in self._engine])
+        buf = self._bufs.get(key)
+        if buf is None or buf[0].N < n:
+            cap = E.bucket_units(n)
+            buf = self._bufs[key] = tuple(E.Blocked(cap, cmax, 1, h, w, 0, 1, 1, x.device) for _ in range(2))
+            while len(self._bufs) > 4:
+                self._bufs.pop(next(iter(self._bufs)))
+        view = lambda b, ch: E.Blocked(n, ch, 1, h, w, 0, 1, 1, x.device, storage=b.storage) if ch == cmax else None
+        if any(e.cout != cmax for e in self._engine) or c != cmax:
+            raise NotImplementedError("mask head conv chain with varying widths")      # (the shipped CONV_LAYERS are 256 throughout)
+        src, dst = view(buf[0], c), view(buf[1], cmax)
+        src.from_dense(x.float())
         for conv in self._engine:
-            x = conv(x)
-        return x
+            conv(src, dst)
+            src, dst = dst, src
+        return src.to_dense()[:, :, 0]
 
 
 class MaskRCNNC4Predictor(nn.Module):
