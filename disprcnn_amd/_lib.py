@@ -127,6 +127,7 @@ _SIGS = {
     "drc_cost_volume16_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_nms_sorted_fwd": (_I, [_P, _I, C.c_float, _I, _P, _P, _P]),
     "drc_nms_sorted_batch_fwd": (_I, [_P, _I, _I, C.c_float, _I, _P, _P, _P]),
+    "drc_nms_sorted_pair_joint_fwd": (_I, [_P, _I, C.c_float, _I, _I, _P, _P, _P]),
     "drc_roi_train_targets_fwd": (_I, [_P, _P, _P, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "drc_bn_stats_blocked": (_I, [_P, _P, _P, _P, _P]),
     "drc_bn_finalize": (_I, [_P, _I, _I, C.c_longlong, C.c_float, C.c_float, _P, _P, _P, _P, _P]),

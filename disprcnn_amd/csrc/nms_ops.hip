@@ -120,6 +120,76 @@ __global__ __launch_bounds__(64) void nms_walk_kernel(const uint64_t* __restrict
     }
 }
 
+// The two views of a stereo list walked TOGETHER (round 3): wave w resolves view w exactly as above; after every 64-row chunk the two
+// kept-masks meet in LDS, their AND is the joint keep (double_view_boxlist_nms keeps the intersection, boxlist_ops.py:49-79) and the walk
+// stops once `max_keep` pairs survive -- the Stereo RPN keeps POST_NMS_TOP_N of its PRE_NMS_TOP_N score-sorted proposals, so most of the
+// chain of L2 round trips is never walked.  `keep` (joint flags) must be zero-filled; rows past the stopping chunk stay 0.
+template <int kMaxWords>
+__global__ __launch_bounds__(128) void nms_walk_joint_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks, int max_keep,
+                                                             uint8_t* __restrict__ keep) {
+    constexpr int kRows = kMaxWords <= 2 ? 16 : (kMaxWords <= 4 ? 8 : 4);
+    __shared__ uint64_t kept_lds[2][2];
+    const int view = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    mask += (int64_t)view * n * col_blocks;
+    uint64_t remv[kMaxWords];
+#pragma unroll
+    for (int w = 0; w < kMaxWords; ++w) remv[w] = 0;
+    auto diag_of = [&](int c) {
+        const int row = c * 64 + lane;
+        return (c < col_blocks && row < n) ? mask[(int64_t)row * col_blocks + c] : 0ULL;
+    };
+    uint64_t dnext = diag_of(0);
+    int total = 0;
+    for (int c = 0; c < col_blocks; ++c) {
+        const uint64_t diag = dnext;
+        dnext = diag_of(c + 1);
+        const int nr = n - c * 64 < 64 ? n - c * 64 : 64;
+        uint64_t word = 0;
+#pragma unroll
+        for (int w = 0; w < kMaxWords; ++w)
+            if (w == (c >> 6)) word = remv[w];
+        uint64_t cur = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((unsigned)(word >> 32), c & 63) << 32) |
+                       (uint64_t)(unsigned)__builtin_amdgcn_readlane((unsigned)word, c & 63);
+        uint64_t kept = 0;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        for (int r = 0; r < nr; ++r) {
+            const uint64_t dr = ((uint64_t)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readlane(dlo, r);
+            const uint64_t k = ((cur >> r) & 1ULL) ^ 1ULL;
+            kept |= k << r;
+            cur |= dr & (0ULL - k);
+        }
+        if (lane == 0) kept_lds[c & 1][view] = kept;
+        __syncthreads();
+        const uint64_t both = kept_lds[c & 1][0] & kept_lds[c & 1][1];
+        if (view == 0 && lane < nr) keep[c * 64 + lane] = (uint8_t)((both >> lane) & 1ULL);
+        total += __builtin_popcountll(both);
+        if (total >= max_keep) break;                      // uniform over the block
+        uint64_t km = kept;                                // each view propagates ITS kept rows (the views suppress independently)
+        while (km) {
+            int rows[kRows];
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) {
+                rows[q] = km ? __builtin_ctzll(km) : -1;
+                km &= km - 1;
+            }
+            uint64_t v[kRows][kMaxWords];
+#pragma unroll
+            for (int q = 0; q < kRows; ++q) {
+                const uint64_t* p = mask + (int64_t)(c * 64 + (rows[q] < 0 ? 0 : rows[q])) * col_blocks;
+#pragma unroll
+                for (int w = 0; w < kMaxWords; ++w) {
+                    const int j = w * 64 + lane;
+                    v[q][w] = (rows[q] >= 0 && j > c && j < col_blocks) ? p[j] : 0ULL;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kRows; ++q)
+#pragma unroll
+                for (int w = 0; w < kMaxWords; ++w) remv[w] |= v[q][w];
+        }
+    }
+}
+
 // The same walk for more than 32,768 boxes (a KITTI pyramid has ~120 k anchors per view when PRE_NMS_TOP_N_TEST is off; the reference's
 // host walk takes any n, csrc/cuda/nms.cu:99-124): the removed-words live in LDS (one per column block) instead of registers.
 __global__ __launch_bounds__(64) void nms_walk_big_kernel(const uint64_t* __restrict__ mask, int n, int col_blocks, uint8_t* __restrict__ keep) {
@@ -168,6 +238,26 @@ extern "C" int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int
         hipLaunchKernelGGL(nms_walk_kernel<8>, dim3(sets), dim3(64), 0, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
     else
         hipLaunchKernelGGL(nms_walk_big_kernel, dim3(sets), dim3(64), (size_t)col_blocks * 8, s, (const uint64_t*)mask_ws, n, col_blocks, keep);
+    return (int)hipGetLastError();
+}
+
+extern "C" int drc_nms_sorted_pair_joint_fwd(const float* boxes_sorted, int n, float thresh, int strict, int max_keep, uint64_t* mask_ws,
+                                             uint8_t* keep_joint, void* stream) {
+    if (n < 0) return -2;
+    if (n == 0) return 0;
+    if (!boxes_sorted || !mask_ws || !keep_joint) return -1;
+    const int col_blocks = (n + 63) / 64;
+    if (col_blocks > 64 * 8) return -5;                    // beyond 32,768 boxes: drc_nms_sorted_batch_fwd and an AND of its flags
+    if (max_keep <= 0 || max_keep > n) max_keep = n;
+    hipStream_t s = (hipStream_t)stream;
+    if (const hipError_t e = hipMemsetAsync(keep_joint, 0, (size_t)n, s)) return (int)e;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks, 2), dim3(64), 0, s, boxes_sorted, n, thresh, strict, mask_ws);
+    if (col_blocks <= 64 * 2)
+        hipLaunchKernelGGL(nms_walk_joint_kernel<2>, dim3(1), dim3(128), 0, s, (const uint64_t*)mask_ws, n, col_blocks, max_keep, keep_joint);
+    else if (col_blocks <= 64 * 4)
+        hipLaunchKernelGGL(nms_walk_joint_kernel<4>, dim3(1), dim3(128), 0, s, (const uint64_t*)mask_ws, n, col_blocks, max_keep, keep_joint);
+    else
+        hipLaunchKernelGGL(nms_walk_joint_kernel<8>, dim3(1), dim3(128), 0, s, (const uint64_t*)mask_ws, n, col_blocks, max_keep, keep_joint);
     return (int)hipGetLastError();
 }
 

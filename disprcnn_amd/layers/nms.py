@@ -28,6 +28,30 @@ def nms(dets, scores, threshold, strict=True):
     return torch.sort(order[keep.bool()])[0]
 
 
+def nms_pair_sorted_joint(dets_a, dets_b, threshold, max_keep=-1, strict=True):
+    """The joint keep of two box sets that are ALREADY in descending-score order (the Stereo RPN's proposals after its own sort):
+    ascending indices kept in both views, at most max_keep of them (the reference's intersect + keep[:max_proposals],
+    boxlist_ops.py:49-79).  No sort, the two views walked together and the walk stopped at max_keep (drc_nms_sorted_pair_joint_fwd)."""
+    E.require_gpu(dets_a, "nms_pair_sorted_joint")
+    n = dets_a.shape[0]
+    if dets_b.shape != dets_a.shape or dets_a.dim() != 2 or dets_a.shape[1] != 4:
+        raise RuntimeError("nms_pair_sorted_joint expects two [N,4] box sets")
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=dets_a.device)
+    if n > 32768:                                          # beyond the joint walk's register budget: the batched walk and an AND
+        s = torch.arange(n, 0, -1, dtype=torch.float32, device=dets_a.device)
+        k = nms_pair(dets_a, dets_b, s, threshold, strict, joint=True)
+        return k[:max_keep] if max_keep > 0 else k
+    boxes = torch.stack((dets_a.float(), dets_b.float())).contiguous()
+    mask = torch.empty(2 * n * ((n + 63) // 64), dtype=torch.int64, device=dets_a.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=dets_a.device)
+    st = _lib.lib().drc_nms_sorted_pair_joint_fwd(E._ptr(boxes), n, float(threshold), int(bool(strict)), int(max_keep), E._ptr(mask), E._ptr(keep),
+                                                  E._stream_ptr(dets_a.device))
+    _lib.check(st, "drc_nms_sorted_pair_joint_fwd")
+    k = keep.bool().nonzero().squeeze(1)
+    return k[:max_keep] if max_keep > 0 else k
+
+
 def nms_pair(dets_a, dets_b, scores, threshold, strict=True, joint=False):
     """NMS of two box sets that share their scores (the left and right views of a stereo detection list) in one launch pair:
     -> (keep_a, keep_b), each as nms() would return it; joint=True -> the ascending intersection of the two (what

@@ -150,7 +150,9 @@ class StereoRPN(nn.Module):
                 wl, wr = lb.xywh(), rb.xywh()
                 ok = ((wl[:, 2] >= self.min_size) & (wl[:, 3] >= self.min_size) & (wr[:, 2] >= self.min_size) & (wr[:, 3] >= self.min_size)).nonzero().squeeze(1)
                 lb, rb = lb[ok], rb[ok]
-            lb, rb = double_view_boxlist_nms(lb, rb, self.nms_thresh, max_proposals=self.post_nms_top_n, score_field="objectness")
+            # (the lists are in descending-score order -- `order` above -- and min_size filtering keeps the order)
+            lb, rb = double_view_boxlist_nms(lb, rb, self.nms_thresh, max_proposals=self.post_nms_top_n, score_field="objectness",
+                                             scores_sorted=True)
             left_result.append(lb)
             right_result.append(rb)
         return left_result, right_result, {}

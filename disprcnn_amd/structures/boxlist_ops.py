@@ -3,7 +3,7 @@ double_view_boxlist_nms (left and right views suppressed separately, the kept se
 NMS itself runs in libdisprcnn_hip.so (layers/nms.py); index bookkeeping is torch plumbing."""
 import torch
 
-from ..layers import nms as _box_nms, nms_pair as _box_nms_pair
+from ..layers import nms as _box_nms, nms_pair as _box_nms_pair, nms_pair_sorted_joint as _box_nms_joint
 from .bounding_box import BoxList
 
 
@@ -22,11 +22,17 @@ def intersect_sorted(a, b):
     return aux[:-1][aux[1:] == aux[:-1]]
 
 
-def double_view_boxlist_nms(left_boxlist, right_boxlist, nms_thresh, max_proposals=-1, score_field="scores", use_keep="joint"):
+def double_view_boxlist_nms(left_boxlist, right_boxlist, nms_thresh, max_proposals=-1, score_field="scores", use_keep="joint",
+                            scores_sorted=False):
+    """scores_sorted=True (an addition to the reference signature): the caller guarantees descending scores -- the Stereo RPN's lists --
+    so the joint keep needs no sort and the walk stops at max_proposals (same result)."""
     if use_keep not in ("joint", "left", "right"):
         raise ValueError(use_keep)
     if nms_thresh <= 0:
         return left_boxlist, right_boxlist
+    if use_keep == "joint" and scores_sorted:
+        keep = _box_nms_joint(left_boxlist.bbox, right_boxlist.bbox, nms_thresh, max_proposals)
+        return left_boxlist[keep], right_boxlist[keep]
     if use_keep == "joint":       # both views share their scores, hence their order: one sort and one launch pair for the two
         keep = _box_nms_pair(left_boxlist.bbox, right_boxlist.bbox, left_boxlist.get_field(score_field), nms_thresh, joint=True)
     elif use_keep == "left":

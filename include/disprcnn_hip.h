@@ -329,6 +329,12 @@ int drc_nms_sorted_fwd(const float* boxes_sorted, int n, float thresh, int stric
 /* The same for `sets` box sets of n boxes each in one launch pair (boxes_sorted [sets][n][4], mask_ws [sets][n*ceil(n/64)], keep [sets][n]):
  * the two views of double_view_boxlist_nms (reference structures/boxlist_ops.py:49-79) share their scores, hence their order. */
 int drc_nms_sorted_batch_fwd(const float* boxes_sorted, int sets, int n, float thresh, int strict, uint64_t* mask_ws, uint8_t* keep, void* stream);
+/* The two views of a stereo list (boxes_sorted [2][n][4], shared descending scores) walked together: keep_joint[n] = 1 where BOTH views
+ * keep the pair (what double_view_boxlist_nms intersects, structures/boxlist_ops.py:49-79), and the walk stops once max_keep pairs are
+ * kept (<= 0: all) -- rows after that chunk are 0, so the first max_keep set flags are exactly the reference's keep[:max_proposals]
+ * for score-sorted input.  n <= 32,768; mask_ws: 2 * n * ceil(n/64) words. */
+int drc_nms_sorted_pair_joint_fwd(const float* boxes_sorted, int n, float thresh, int strict, int max_keep, uint64_t* mask_ws,
+                                  uint8_t* keep_joint, void* stream);
 
 /* f4. Box arithmetic of the 2D detection stage (det_ops.hip).
  * drc_box_decode_fwd -- BoxCoder.decode (reference modeling/box_coder.py:161-244): codes [rows][groups][per_group], per_group = 4

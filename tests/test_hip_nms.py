@@ -76,3 +76,11 @@ def test_nms_pair_equals_two_calls():
         from disprcnn_amd.structures.boxlist_ops import intersect_sorted
         kj = nms_pair(a.to(dev), b.to(dev), s.to(dev), 0.7, joint=True)
         assert torch.equal(kj, intersect_sorted(ka, kb))
+        # score-sorted input: the joint walk with early exit == the first max_keep of the intersection, for any max_keep
+        from disprcnn_amd.layers import nms_pair_sorted_joint
+        o = torch.sort(s, descending=True, stable=True)[1]
+        a_s, b_s, s_s = a[o].to(dev), b[o].to(dev), s[o].to(dev)
+        full = nms_pair(a_s, b_s, s_s, 0.7, joint=True)
+        for mk in (-1, 1, 7, 64, 65, 200, 100000):
+            got = nms_pair_sorted_joint(a_s, b_s, 0.7, mk)
+            assert torch.equal(got, full[:mk] if mk > 0 else full), (tag, mk)
