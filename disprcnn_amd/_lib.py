@@ -45,6 +45,10 @@ class DrcCostvolSrc(C.Structure):
                 ("cbi", C.c_int32), ("pad", C.c_int32), ("lo4", C.c_int32), ("Wp", C.c_int32)]
 
 
+class DrcFpnPyramid(C.Structure):
+    _fields_ = [("feat", C.c_void_p * 8), ("H", C.c_int32 * 8), ("W", C.c_int32 * 8), ("scale", C.c_float * 8), ("n_levels", C.c_int32)]
+
+
 class DrcWgradParams(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p),
                 ("a_n_stride", C.c_int64), ("a_cb_stride", C.c_int64), ("a_d_stride", C.c_int64), ("a_h_stride", C.c_int64),
@@ -114,6 +118,7 @@ _SIGS = {
     "drc_bilinear_resize_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_maxpool2d_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_copy_blocks": (_I, [_P, _P, _I, _I, C.c_int64, _I, _I, _P]),
+    "drc_roi_align_fpn_fwd": (_I, [C.POINTER(DrcFpnPyramid), _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drc_roi_align_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P, _P, _P]),
     "drc_roi_align_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.c_float, _I, _P]),
     "drc_align_roi_pairs": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),

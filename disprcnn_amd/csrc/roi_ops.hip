@@ -42,20 +42,29 @@ __device__ __forceinline__ Bilin bilinear_setup(float y, float x, int height, in
 // stores are coalesced and neighbouring lanes gather neighbouring image columns (bin_w <= 1 px for rois up to 224 px wide).
 // Arithmetic per (sample, channel) and the accumulation order are the reference's, and the build uses -ffp-contract=off, so
 // the un-normalised output is BIT-IDENTICAL to csrc/cpu/ROIAlign_cpu.cpp (tests/golden/roi_golden.npz).
-template <int CC>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(const float* __restrict__ in, const float* __restrict__ rois,
-                                                                 float* __restrict__ out, int K, int C, int H, int W, int PH, int PW,
-                                                                 float spatial_scale, int sampling_ratio,
-                                                                 const float* __restrict__ mean, const float* __restrict__ stdv) {
+// FPN = true (round 3): one launch over all pyramid levels -- every roi reads its level's map, size and scale from `pyr` through
+// levels[k] -- instead of a nonzero / index_select / launch / index_copy per level (12 host syncs per stereo pair in the 2D stage's
+// three poolers).  Same per-sample arithmetic, so the outputs are those of the per-level launches.
+template <int CC, bool FPN>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_kernel(const float* __restrict__ in0, const float* __restrict__ rois,
+                                                                 float* __restrict__ out, int K, int C, int H0, int W0, int PH, int PW,
+                                                                 float spatial_scale0, int sampling_ratio,
+                                                                 const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                                 const drc_fpn_pyramid pyr, const int32_t* __restrict__ levels) {
     const int CG = C / CC;
     const long total = (long)K * CG * PH * PW;
-    const long plane = (long)H * W, oplane = (long)PH * PW;
+    const long oplane = (long)PH * PW;
     for (long idx = (long)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (long)gridDim.x * kThreads) {
         long t = idx;
         const int pw = (int)(t % PW); t /= PW;
         const int ph = (int)(t % PH); t /= PH;
         const int cg = (int)(t % CG);
         const int k = (int)(t / CG);
+        const int lv = FPN ? levels[k] : 0;
+        const float* in = FPN ? pyr.feat[lv] : in0;
+        const int H = FPN ? pyr.H[lv] : H0, W = FPN ? pyr.W[lv] : W0;
+        const float spatial_scale = FPN ? pyr.scale[lv] : spatial_scale0;
+        const long plane = (long)H * W;
         const float* r = rois + (long)k * 5;
         const int b = (int)r[0];
         // no rounding of the roi (ROIAlign_cpu.cpp:146-150); malformed rois forced to 1x1 (:157-158)
@@ -270,12 +279,32 @@ int drc_roi_align_fwd(const float* input, const float* rois, float* out, int K, 
     const long total = (long)K * (C / cc) * PH * PW;
     const dim3 grid(grid_for(total)), block(kThreads);
     hipStream_t s = (hipStream_t)stream;
+    const drc_fpn_pyramid none = {};
     if (cc == 4)
-        hipLaunchKernelGGL(roi_align_fwd_kernel<4>, grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+        hipLaunchKernelGGL((roi_align_fwd_kernel<4, false>), grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv, none, nullptr);
     else if (cc == 3)
-        hipLaunchKernelGGL(roi_align_fwd_kernel<3>, grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+        hipLaunchKernelGGL((roi_align_fwd_kernel<3, false>), grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv, none, nullptr);
     else
-        hipLaunchKernelGGL(roi_align_fwd_kernel<1>, grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv);
+        hipLaunchKernelGGL((roi_align_fwd_kernel<1, false>), grid, block, 0, s, input, rois, out, K, C, H, W, PH, PW, spatial_scale, sampling_ratio, mean, stdv, none, nullptr);
+    return (int)hipGetLastError();
+}
+
+int drc_roi_align_fpn_fwd(const drc_fpn_pyramid* pyr, const float* rois, const int32_t* levels, float* out, int K, int C, int PH, int PW,
+                          int sampling_ratio, void* stream) {
+    if (!pyr) return -1;
+    if (K < 0 || C <= 0 || PH <= 0 || PW <= 0 || sampling_ratio < 0 || pyr->n_levels < 1 || pyr->n_levels > DRC_FPN_MAX_LEVELS) return -2;
+    for (int i = 0; i < pyr->n_levels; ++i)
+        if (!pyr->feat[i] || pyr->H[i] <= 0 || pyr->W[i] <= 0) return -2;
+    if (K == 0) return 0;
+    if (!rois || !levels || !out) return -1;
+    const int cc = C % 4 == 0 ? 4 : 1;
+    const long total = (long)K * (C / cc) * PH * PW;
+    const dim3 grid(grid_for(total)), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (cc == 4)
+        hipLaunchKernelGGL((roi_align_fwd_kernel<4, true>), grid, block, 0, s, nullptr, rois, out, K, C, 0, 0, PH, PW, 0.f, sampling_ratio, nullptr, nullptr, *pyr, levels);
+    else
+        hipLaunchKernelGGL((roi_align_fwd_kernel<1, true>), grid, block, 0, s, nullptr, rois, out, K, C, 0, 0, PH, PW, 0.f, sampling_ratio, nullptr, nullptr, *pyr, levels);
     return (int)hipGetLastError();
 }
 

@@ -3,11 +3,14 @@
 Fork behaviour kept: the level of a box is round(4 + ln(sqrt(area) / 224)) (natural log, no epsilon), clamped to the configured
 levels; the extra top level (P6) is never pooled from; the ROIAlign scale of a level is feature height / image height, not the
 configured constant.  ROIAlign itself is the bit-exact HIP kernel behind layers.ROIAlign (drc_roi_align_fwd)."""
+import ctypes as C
 import math
 
 import torch
 from torch import nn
 
+from .. import _lib
+from .. import engine as E
 from ..layers.roi_align import ROIAlign
 
 
@@ -27,6 +30,7 @@ class Pooler(nn.Module):
         self.poolers = nn.ModuleList([ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio) for s in scales])
         self.output_size = tuple(output_size)
         self.map_levels = LevelMapper(-math.log2(scales[0]), -math.log2(scales[-1]))
+        self.single_launch = True        # all levels in one drc_roi_align_fpn_fwd launch (False: the reference's per-level loop)
 
     @staticmethod
     def convert_to_roi_format(boxes):
@@ -44,6 +48,22 @@ class Pooler(nn.Module):
         if len(rois) == 0:
             return out
         levels = self.map_levels(boxes)
+        feats = [f.contiguous() for f in x[: len(self.poolers)]]
+        needs_grad = torch.is_grad_enabled() and any(f.requires_grad for f in feats)
+        if not needs_grad and self.single_launch and all(f.is_cuda and f.dtype == torch.float32 and f.shape[1] == c for f in feats) and len(feats) <= 8:
+            # one launch over the pyramid (drc_roi_align_fpn_fwd): every roi reads its level's map and scale; no per-level host sync
+            pyr = _lib.DrcFpnPyramid()
+            pyr.n_levels = len(feats)
+            for i, f in enumerate(feats):
+                pyr.feat[i], pyr.H[i], pyr.W[i] = f.data_ptr(), f.shape[2], f.shape[3]
+                pyr.scale[i] = f.shape[2] / boxes[0].height                     # (fork quirk: feature height / image height)
+            lv32 = levels.to(torch.int32).contiguous()
+            rois = rois.contiguous()
+            out = torch.empty(len(rois), c, *self.output_size, dtype=torch.float32, device=rois.device)
+            st = _lib.lib().drc_roi_align_fpn_fwd(C.byref(pyr), E._ptr(rois), E._ptr(lv32), E._ptr(out), len(rois), c, self.output_size[0],
+                                                  self.output_size[1], int(self.poolers[0].sampling_ratio), E._stream_ptr(rois.device))
+            _lib.check(st, "drc_roi_align_fpn_fwd")
+            return out
         for level, (feat, pooler) in enumerate(zip(x[: len(self.poolers)], self.poolers)):
             idx = torch.nonzero(levels == level).reshape(-1)
             if idx.numel() == 0:

@@ -279,6 +279,18 @@ int drc_copy_blocks(const float* x, float* y, int N, int CB, int64_t vox_per_cb,
  * Backward accumulates with atomicAdd into grad_in, which the caller zero-fills. */
 int drc_roi_align_fwd(const float* input, const float* rois, float* out, int K, int C, int H, int W, int PH, int PW,
                       float spatial_scale, int sampling_ratio, const float* mean, const float* stdv, void* stream);
+/* The same operator over an FPN pyramid in ONE launch (round 3): roi k is pooled from level levels[k] (its [N,C,H,W] map, size and
+ * scale in `pyr`), which replaces the per-level nonzero / index_select / roi_align / index_copy loop of modeling/poolers.py:118-149;
+ * per-sample arithmetic identical to drc_roi_align_fwd. */
+#define DRC_FPN_MAX_LEVELS 8
+typedef struct {
+    const float* feat[DRC_FPN_MAX_LEVELS];
+    int32_t H[DRC_FPN_MAX_LEVELS], W[DRC_FPN_MAX_LEVELS];
+    float scale[DRC_FPN_MAX_LEVELS];
+    int32_t n_levels;
+} drc_fpn_pyramid;
+int drc_roi_align_fpn_fwd(const drc_fpn_pyramid* pyr, const float* rois, const int32_t* levels, float* out, int K, int C, int PH, int PW,
+                          int sampling_ratio, void* stream);
 int drc_roi_align_bwd(const float* grad_out, const float* rois, float* grad_in, int K, int C, int H, int W, int PH, int PW,
                       float spatial_scale, int sampling_ratio, void* stream);
 

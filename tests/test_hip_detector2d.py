@@ -223,6 +223,34 @@ def test_stereo_rpn_blocked_head_matches_dense_head(dev, n, h, w):
         assert d.shape == b.shape and (d - b).abs().max().item() <= 1e-5 * max(1.0, d.abs().max().item())
 
 
+def test_pooler_single_launch_equals_per_level_loop(dev):
+    """drc_roi_align_fpn_fwd (one launch over the pyramid, round 3) against the per-level nonzero / index_select / ROIAlign / index_copy
+    loop of the reference's Pooler (poolers.py:118-149): bit-identical, for both pooler shapes of the 2D stage, incl. empty levels."""
+    from disprcnn_amd.modeling.poolers import Pooler
+    from disprcnn_amd.structures.bounding_box import BoxList
+    fl, _ = synth.synth_pyramid(2, 160, 256, tag="poolfpn")
+    feats = [f.to(dev) for f in fl]
+    g = torch.Generator().manual_seed(5)
+    boxes = []
+    for i, r in enumerate((37, 0 + 5)):
+        xy = torch.rand(r, 2, generator=g) * torch.tensor([200.0, 120.0])
+        wh = torch.rand(r, 2, generator=g) ** 2 * torch.tensor([250.0, 150.0]) + 2.0
+        b = torch.cat((xy, (xy + wh).clamp(max=255.0)), 1)
+        b[:, 3] = b[:, 3].clamp(max=159.0)
+        boxes.append(BoxList(b.to(dev), (256, 160)))
+    for res, ratio in ((7, 2), (14, 2)):
+        p = Pooler((res, res), (0.25, 0.125, 0.0625, 0.03125), ratio)
+        one = p(feats, boxes)
+        p.single_launch = False
+        ref = p(feats, boxes)
+        assert one.shape == ref.shape == (42, 256, res, res) and torch.equal(one, ref)
+    small = [BoxList(torch.tensor([[3.0, 4.0, 20.0, 18.0]], device=dev), (256, 160)), BoxList(torch.zeros(0, 4, device=dev), (256, 160))]
+    p.single_launch = True
+    a = p(feats, small)
+    p.single_launch = False
+    assert torch.equal(a, p(feats, small))
+
+
 def test_full_pipeline_images_to_disparity_maps(dev):
     """test_net.py's data flow on the HIP path: stereo pair -> DispRCNN (2D stage) -> DispRCNN3D (instance disparity on the detections)
     -> DisparityMapProcessor (full-image maps).  The 2D stage's output IS the disparity stage's lr_result; each stage has its own parity
