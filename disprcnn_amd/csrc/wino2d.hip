@@ -41,8 +41,13 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
     const int g = lane >> 4;
 
     const drc_tap_class cls = p.cls[0];
-    const int TH = (p.OH + 1) >> 1, TW = (p.OW + 1) >> 1;    // odd maps: the last tile row / column is half used (see unit_end)
-    const int tiles = p.N * TH * TW;
+    // Dilation d (round 3; the feature CNN's layer4, d = 2): a dilated 3x3 convolution is d*d independent undilated ones on the
+    // sub-grids (a, b) + d*(i, j), so a tile is (n, a, b, ht, wt): patch rows / columns d apart, the 2x2 outputs d apart.  The host
+    // admits d > 1 only when 2d divides OH and OW (every sub-grid has whole tiles).
+    const int dil = cls.sh;
+    const int TH = dil > 1 ? p.OH / (2 * dil) : (p.OH + 1) >> 1;   // d = 1, odd maps: the last tile row / column is half used (see unit_end)
+    const int TW = dil > 1 ? p.OW / (2 * dil) : (p.OW + 1) >> 1;
+    const int tiles = p.N * dil * dil * TH * TW;
     const int groups = (tiles + 15) >> 4;
     // block -> (cout group, position), rounds of four tile groups: see wino3d.hip
     const int n_cg = p.cout_pad / 16 / CT;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
     const int w_xi = w_cb * p.cb_in;               // floats per frequency point
 
     // lane geometry of a round: byte offset of the 4x4 patch origin (logical voxel 2t-1 = padded 2t + first), channels 4g..4g+3
-    struct Geo { unsigned xo; int n, ht, wt; bool valid; };
+    struct Geo { unsigned xo; int n, ht, wt; bool valid; };      // ht, wt: first output row / column of the tile, in units of 2 rows (d = 1)
     auto geo_of = [&](int round) __attribute__((always_inline)) {
         Geo q;
         int grp = (round * nbk + pos) * W2_WAVES + wave;
@@ -73,18 +78,22 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
         int tile = grp * 16 + j;
         q.valid = active && tile < tiles;
         if (tile >= tiles) tile = tiles - 1;
-        q.wt = tile % TW; tile /= TW;
-        q.ht = tile % TH;
-        q.n = tile / TH;
-        q.xo = (unsigned)((q.n * p.x_n_stride + (int64_t)cls.dd0 * p.x_d_stride + (2 * q.ht + cls.dh0) * p.x_h_stride +
-                           (int64_t)(2 * q.wt + cls.dw0) * 16 + g * 4) * 4);
+        const int wt = tile % TW; tile /= TW;
+        const int ht = tile % TH; tile /= TH;
+        const int sub = tile % (dil * dil);                 // sub-grid (a, b) = (sub / dil, sub % dil); 0 for d = 1
+        q.n = tile / (dil * dil);
+        const int a = sub / dil, b = sub - a * dil;
+        q.ht = 2 * dil * ht + a;                            // first output row / column of the tile
+        q.wt = 2 * dil * wt + b;
+        q.xo = (unsigned)((q.n * p.x_n_stride + (int64_t)cls.dd0 * p.x_d_stride + (q.ht + cls.dh0) * p.x_h_stride +
+                           (int64_t)(q.wt + cls.dw0) * 16 + g * 4) * 4);
         return q;
     };
 
     // one h-row of a step's patch (4 float4) and its w butterfly
     auto load_row = [&](f32x4 (&r)[4], const char* s, int h, unsigned xo) __attribute__((always_inline)) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) r[w] = *(const f32x4*)(s + ((int64_t)h * p.x_h_stride + w * 16) * 4 + xo);
+        for (int w = 0; w < 4; ++w) r[w] = *(const f32x4*)(s + ((int64_t)(h * dil) * p.x_h_stride + w * dil * 16) * 4 + xo);
     };
     auto bfly_row = [&](f32x4 (&t)[4], const f32x4 (&d)[4]) __attribute__((always_inline)) {
         t[0] = d[0] - d[2]; t[1] = d[1] + d[2]; t[2] = d[2] - d[1]; t[3] = d[1] - d[3];
@@ -219,8 +228,8 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
     // end of a tile group: A^T . A (4x4 -> 2x2) of its accumulators, then the epilogue
     auto unit_end = [&](const Geo& geo) __attribute__((always_inline)) {
         if (!geo.valid) return;
-        const int64_t yo = p.y_off0 + (int64_t)geo.n * p.y_n_stride + (int64_t)(2 * geo.ht) * p.y_h_stride + (int64_t)(2 * geo.wt) * 16 + g * 4;
-        const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)(2 * geo.ht) * p.r_h_stride + (int64_t)(2 * geo.wt) * 16 + g * 4;
+        const int64_t yo = p.y_off0 + (int64_t)geo.n * p.y_n_stride + (int64_t)geo.ht * p.y_h_stride + (int64_t)geo.wt * 16 + g * 4;
+        const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)geo.ht * p.r_h_stride + (int64_t)geo.wt * 16 + g * 4;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const f32x4 bn_sc = *(const f32x4*)(p.scale + (ct0 + ct) * 16 + g * 4);
@@ -235,11 +244,11 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
             for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
                 for (int ow = 0; ow < 2; ++ow) {
-                    if (2 * geo.ht + oh >= p.OH || 2 * geo.wt + ow >= p.OW) continue;   // the unused half of an odd map's last tiles
+                    if (geo.ht + oh * dil >= p.OH || geo.wt + ow * dil >= p.OW) continue;   // the unused half of an odd map's last tiles
                     f32x4 v_ = (ow == 0 ? hh[oh][0] + hh[oh][1] + hh[oh][2] : hh[oh][1] - hh[oh][2] - hh[oh][3]) * bn_sc + bn_sh;
-                    if (p.res) v_ += *(const f32x4*)(p.res + ro + oh * p.r_h_stride + ow * 16 + (int64_t)(ct0 + ct) * p.r_cb_stride);
+                    if (p.res) v_ += *(const f32x4*)(p.res + ro + (oh * dil) * p.r_h_stride + ow * dil * 16 + (int64_t)(ct0 + ct) * p.r_cb_stride);
                     if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
-                    *(f32x4*)(p.y + yo + oh * p.y_h_stride + ow * 16 + (int64_t)(ct0 + ct) * p.y_cb_stride) = v_;
+                    *(f32x4*)(p.y + yo + (oh * dil) * p.y_h_stride + ow * dil * 16 + (int64_t)(ct0 + ct) * p.y_cb_stride) = v_;
                 }
         }
     };
@@ -256,7 +265,8 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
 
 template <int CT>
 int launch(const drc_tapconv_params& p, hipStream_t stream) {
-    const long tiles = (long)p.N * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
+    const int dil = p.cls[0].sh;
+    const long tiles = dil > 1 ? (long)p.N * (p.OH / 2) * (p.OW / 2) : (long)p.N * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long groups = (tiles + 15) / 16;
     const int n_cg = p.cout_pad / 16 / CT;
     // one block per CU; every cout group gets the same number of blocks
@@ -311,7 +321,8 @@ extern "C" int drc_conv2d_k3_wino_fwd(const drc_tapconv_params* pp, int cout_til
     if (p.N == 0) return 0;
     if (p.cout_pad <= 0 || (p.cout_pad & 15) || p.cb_in <= 0) return -2;
     const drc_tap_class& k = p.cls[0];
-    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 1 || k.nh != 3 || k.nw != 3 || k.sh != 1 || k.sw != 1) return -4;
+    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || k.nd != 1 || k.nh != 3 || k.nw != 3 || k.sh < 1 || k.sh != k.sw) return -4;
+    if (k.sh > 1 && (p.OH % (2 * k.sh) || p.OW % (2 * k.sh))) return -4;      // dilated: whole tiles on every sub-grid
     if (((int64_t)p.N * p.x_n_stride + 2 * p.x_h_stride) * 4 >= (1LL << 32)) return -5;   // 32-bit lane offsets over the whole batch
     if ((int64_t)p.N * ((p.OH + 1) / 2) * ((p.OW + 1) / 2) >= (1LL << 31) - 16 || (int64_t)16 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
     const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;

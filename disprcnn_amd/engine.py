@@ -660,6 +660,7 @@ WINO = {"enabled": True,      # stride-1 3x3x3 layers with even output dims as W
 WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
           "rb": False, "rb_min_chunks": 256,  # the row-brick kernel's 2D form (widths 14 or multiples of 28): bit-identical, measured equal
                                               # (32 crops: 70.7 vs 77.2 us at 32ch@112^2, 198 vs 201 at 128ch@56^2, 442 vs 404 at 320->128) -> off
+          "dilated": True,    # dilated layers whose maps divide by 2*dilation: d*d interleaved sub-grids (feature CNN layer4; round 3)
           "odd": True,        # odd maps too (the trunk's 47 x 155 level: 256 -> 256 186 -> ? us); False: direct kernel as in rounds 1-2
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
@@ -833,13 +834,14 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
         wct = 2 if ct % 2 == 0 else 1
         # (odd maps: the last tile row / column is half used, wino2d.hip; their patch row 3 lies in the slack behind the tensor)
         wtiles = x.N * ((y.H + 1) // 2) * ((y.W + 1) // 2)
-        if (WINO2D["enabled"] and stride == 1 and dilation == 1 and pad == 1 and (WINO2D["odd"] or not (y.H | y.W) & 1) and
+        dil_ok = dilation == 1 or (WINO2D["dilated"] and y.H % (2 * dilation) == 0 and y.W % (2 * dilation) == 0)
+        if (WINO2D["enabled"] and stride == 1 and dil_ok and pad == dilation and (WINO2D["odd"] or not (y.H | y.W) & 1) and
                 (x.N * x.n_stride + 2 * x.h_stride) * 4 < 2 ** 32 and wtiles // 64 >= WINO2D["min_chunks"]):
             pl.wino = True
             pl.slide_ct = wct
             pl.kname = "wino2d_kernel<%d>" % wct
             chunks = wtiles // 64
-            if (WINO2D.get("rb") and not (y.H | y.W) & 1 and chunks * (pl.p.cout_pad // 32) >= WINO2D["rb_min_chunks"]
+            if (WINO2D.get("rb") and dilation == 1 and not (y.H | y.W) & 1 and chunks * (pl.p.cout_pad // 32) >= WINO2D["rb_min_chunks"]
                     and _lib.lib().drc_conv2d_k3_wino_rb_supported(pl.p.cout_pad, y.H, y.W)):
                 pl.rb = True
                 pl.kname = "wino2d_rb_kernel<%d>" % (7 if y.W == 14 else 14)

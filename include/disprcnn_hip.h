@@ -197,7 +197,8 @@ int drc_conv3d_k3_wino_costvol_fwd(const drc_tapconv_params* p, const drc_costvo
 int drc_conv3d_k3_wino_rb_costvol_fwd(const drc_tapconv_params* p, const drc_costvol_src* cv, void* stream);
 
 /* Conv2d 3x3, stride 1, dilation 1, pad 1 (same parameter block as drc_conv2d_k3_direct_fwd; R, WT ignored) as Winograd
- * F(2x2, 3x3): 16 instead of 36 multiplies per (cin, cout) pair and 2x2 output tile.  Odd OH / OW: the last tile row / column
+ * F(2x2, 3x3): 16 instead of 36 multiplies per (cin, cout) pair and 2x2 output tile.  Dilation d = cls[0].sh = sw > 1 (pad = d) is taken
+ * when 2d divides OH and OW (d*d interleaved sub-grids).  Odd OH / OW (d = 1): the last tile row / column
  * keeps one output row / column and its input patch reaches one row past the zero halo (into the next plane; values there do not
  * reach a stored output), so the tensor must be followed by (W + 2 * pad + 2) * 64 readable bytes.  Needs
  * (N * x_n_stride + 2 * x_h_stride) * 4 < 2^32; weights from drc_pack_weights_wino2d ([16 = xh*4+xw][ceil(Cin/16)][cout_pad][16]). */

@@ -110,7 +110,7 @@ def test_config_b_golden_replicated_to_16_crops(dev):
     for name in WINO_LAYERS:
         assert ws3["p"][name].wino, name
     ws2 = m._rt._ws[("2d", 32, 224, 224)]
-    assert ws2["p"]["fe.firstconv.2"].wino and ws2["p"]["fe.lastconv.0"].wino and ws2["p"]["fe.layer4.0.conv1"].kname.startswith("conv2ddirect")
+    assert ws2["p"]["fe.firstconv.2"].wino and ws2["p"]["fe.lastconv.0"].wino and ws2["p"]["fe.layer4.0.conv1"].wino and ws2["p"]["fe.layer2.0.conv1"].kname.startswith("conv2ddirect")
     ref = torch.from_numpy(z["B_pred"])
     err = (pred.view(8, 2, 224, 224) - ref[None]).abs()
     print("B x8 mean/max err px", err.mean().item(), err.max().item())

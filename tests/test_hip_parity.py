@@ -313,6 +313,32 @@ def test_conv2d_winograd_kernel_vs_oracle(dev, n, cin, cout, hw, with_res):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("n,cin,cout,hw,dil,with_res", [(3, 128, 128, (56, 56), 2, True), (2, 32, 48, (16, 24), 2, False), (2, 20, 16, (16, 8), 4, True),
+                                                         (5, 64, 32, (4, 12), 2, True)])
+def test_conv2d_winograd_dilated_vs_oracle(dev, n, cin, cout, hw, dil, with_res):
+    """Round 3: dilated 3x3 layers (pad = dilation; feature CNN layer4, submodule.py:71) on the 2D Winograd kernel as d*d interleaved
+    sub-grids, against the direct dilated convolution; maps that 2d does not divide stay on the direct kernel."""
+    from disprcnn_amd import ops, engine as E
+    x = synth.hash_uniform(f"W2d{cin}{cout}{hw}:x", (n, cin) + hw)
+    w = synth.hash_uniform(f"W2d{cin}{cout}:w", (cout, cin, 3, 3), -0.1, 0.1)
+    scale = synth.hash_uniform("W2d:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("W2d:b", (cout,), -0.5, 0.5)
+    res = synth.hash_uniform(f"W2d{cout}{hw}:r", (n, cout) + hw) if with_res else None
+    ref = F.conv2d(x, w, None, 1, dil, dil) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref + res) if with_res else ref
+    saved = (E.WINO2D["enabled"], E.WINO2D["min_chunks"])
+    E.WINO2D["enabled"], E.WINO2D["min_chunks"] = True, 0
+    try:
+        xb = E.Blocked(n, cin, 1, *hw, 0, dil, dil, dev)
+        plan = E.plan_conv2d(xb, E.Blocked(n, cout, 1, *hw, 0, 1, 1, dev), 3, 1, dil, dil, cout, True)
+        odd = E.plan_conv2d(E.Blocked(n, cin, 1, hw[0] + 2, hw[1], 0, dil, dil, dev), E.Blocked(n, cout, 1, hw[0] + 2, hw[1], 0, 1, 1, dev), 3, 1, dil, dil, cout, True)
+        got = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, dil, dil, with_res, res.to(dev) if with_res else None)
+    finally:
+        E.WINO2D["enabled"], E.WINO2D["min_chunks"] = saved
+    assert plan.wino and plan.c2d and not odd.wino
+    _close(got, ref)
+
+
 @pytest.mark.parametrize("n,cin,cout,hw,with_res,expect_rb", [
     (3, 32, 32, (112, 112), True, True),         # firstconv / layer1 of the PSMNet feature CNN: four strips of 14 tile columns
     (2, 64, 64, (56, 56), False, True),          # layer2: two strips, two cout groups

@@ -159,7 +159,14 @@ def test_conv2d_3x3_kernel_selection():
     assert plan(2, 256, (24, 78)).wino                # a deep backbone stage: few tile groups, still ahead of the direct kernel
     assert not plan(2, 512, (12, 38)).wino            # too few tile groups per cout group
     assert not plan(32, 32, (112, 112), stride=2).wino
-    assert not plan(32, 128, (56, 56), dil=2).wino
+    assert plan(32, 128, (56, 56), dil=2).wino            # dilated, 2d | H, W: d*d interleaved sub-grids on the Winograd kernel (round 3)
+    assert not plan(32, 128, (54, 56), dil=2).wino        # ... otherwise the direct kernel
+    saved_dil = E.WINO2D["dilated"]
+    E.WINO2D["dilated"] = False
+    try:
+        assert not plan(32, 128, (56, 56), dil=2).wino
+    finally:
+        E.WINO2D["dilated"] = saved_dil
     saved = E.WINO2D["enabled"]
     E.WINO2D["enabled"] = False
     try:
