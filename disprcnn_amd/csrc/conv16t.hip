@@ -184,6 +184,16 @@ void conv16t_kernel(const drc_tapconv_params p) {
                 const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)q.n * p.r_n_stride : nullptr;
                 const int row0 = q.r0 + wave * RW;
                 const int yl = q.od * yd_ + row0 * yh + col * 32 + g * 4, rl = q.od * rd_ + row0 * rh + col * 32 + g * 4;
+                // the residual tile as one batch of loads, then the arithmetic and the stores (not a load -> wait -> store chain per output)
+                f16x4 rv[RW][CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        const int cot = q.cg * CT + ct;
+                        rv[r][ct] = (f16x4){0, 0, 0, 0};
+                        if (res && col_ok && row0 + r < p.OH) rv[r][ct] = *(const f16x4*)(res + rl + (cot >> 1) * rc + r * rh + (cot & 1) * 16);
+                    }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const int cot = q.cg * CT + ct;
@@ -191,20 +201,12 @@ void conv16t_kernel(const drc_tapconv_params p) {
                     const f32x4 sh = *(const f32x4*)(p.shift + cot * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < RW; ++r) {
-                        const int row = q.r0 + wave * RW + r;
-                        if (col_ok && row < p.OH) {
-                            const int yo = yl + (cot >> 1) * yc + r * yh + (cot & 1) * 16;
-                            f32x4 v = acc[r][ct] * sc + sh;
-                            if (res) {
-                                const int ro = rl + (cot >> 1) * rc + r * rh + (cot & 1) * 16;
-                                const f16x4 rv = *(const f16x4*)(res + ro);
-                                v.x += (float)rv.x; v.y += (float)rv.y; v.z += (float)rv.z; v.w += (float)rv.w;
-                            }
-                            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                            f16x4 hv;
-                            hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
-                            *(f16x4*)(y + yo) = hv;
-                        }
+                        f32x4 v = acc[r][ct] * sc + sh;
+                        v.x += (float)rv[r][ct].x; v.y += (float)rv[r][ct].y; v.z += (float)rv[r][ct].z; v.w += (float)rv[r][ct].w;
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        f16x4 hv;
+                        hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
+                        if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + (cot >> 1) * yc + r * yh + (cot & 1) * 16) = hv;
                     }
                 }
             }
@@ -217,6 +219,174 @@ void conv16t_kernel(const drc_tapconv_params p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16s_kernel<RW,CT>: the 3x3x3 layers with ONE 32-channel input block and <= 32 couts (dres0[1], dres1, classif[0], the 32 -> 1
+// heads: six of the seven full-resolution layers) as a DEPTH-SLIDING walk.  conv16t re-stages three depth slices per output slice
+// (3.7x the input through the DMA path) and cannot overlap that DMA with its MFMAs because its weights share the in-order vmcnt queue.
+// Here the layer's whole weight set (27 x CT fragments) is loaded into each wave's REGISTERS once, a block owns a (n, row tile, column tile) COLUMN
+// and walks od = 0..OD-1 with a ring of four slice slots: slices od-1, od, od+1 resident, slice od+2 landing while the 27 taps of od
+// run -- the MFMA phase issues no vector-memory instruction, so one `vmcnt(0)` + barrier per output slice is all the synchronisation.
+// Per (kd, kw) the RW+2 distinct input rows are read once and serve all three kh (6 ds_read_b128 per 24 MFMAs at RW=4, CT=2).
+template <int RW, int CT>
+__global__ __launch_bounds__(64 * T16_WAVES) void conv16s_kernel(const drc_tapconv_params p) {
+    constexpr int TR = RW * T16_WAVES;
+    constexpr int SLOT = (TR + 2) * 1024;              // bytes of one staged slice
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef const __attribute__((address_space(3))) volatile f16x8 lds_frag;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const _Float16* x = (const _Float16*)p.x;
+    const drc_tap_class cls = p.cls[0];
+    const bool dense1 = p.reserved == 1;
+    const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride;
+    const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
+    const int rh = (int)p.r_h_stride, rd_ = (int)p.r_d_stride, rc = (int)p.r_cb_stride;
+    const int n_ct = (p.OW + T16_COLS - 1) / T16_COLS, n_rt = (p.OH + TR - 1) / TR;
+    const unsigned columns = (unsigned)p.N * n_rt * n_ct;
+
+    // ---- weights -> REGISTERS, once per wave: 27 x CT fragments (216 VGPRs at CT = 2; the kernel runs one wave per SIMD, 512 are
+    // there).  Through LDS they doubled the ds_read_b128 traffic of a (kd, kw) group (12 KiB per wave for 24 MFMAs), and LDS -- not the
+    // matrix cores -- bounded the step.
+    f16x8 wreg[27][CT];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            wreg[tap][ct] = *(const f16x8*)((const _Float16*)p.w + ((long)tap * p.cout_pad + ct * 16 + j) * 32 + g * 8);
+    const __attribute__((address_space(3))) char* ring = (const __attribute__((address_space(3))) char*)lds;
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 1024);
+    f32x4 sc_[CT], sh_[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        sc_[ct] = dense1 ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(p.scale + ct * 16 + g * 4);
+        sh_[ct] = dense1 ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(p.shift + ct * 16 + g * 4);
+    }
+
+    f32x4 acc[RW][CT];
+    for (unsigned col = blockIdx.x; col < columns; col += gridDim.x) {
+        unsigned t = col;
+        unsigned u = t / (unsigned)n_ct; const int c0 = (int)(t - u * (unsigned)n_ct) * T16_COLS; t = u;
+        u = t / (unsigned)n_rt; const int r0 = (int)(t - u * (unsigned)n_rt) * TR;
+        const int n = (int)u;
+        const _Float16* src0 = x + (long)n * p.x_n_stride + (cls.dd0 * xd + (r0 + cls.dh0) * xh + (c0 + cls.dw0 + j) * 32 + g * 8);
+        auto stage = [&](int ps) __attribute__((always_inline)) {           // padded slice ps -> ring slot ps & 3
+            char* dst = lds + (ps & 3) * SLOT;
+#pragma unroll
+            for (int i0 = 0; i0 < TR + 2; i0 += T16_WAVES) {
+                const int rr = i0 + wave;
+                if (rr < TR + 2) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src0 + (ps * xd + rr * xh)), LDS_PTR(dst + rr * 1024), 16, 0, 0);
+            }
+        };
+        // every wave is done with the previous column's slots before they are overwritten
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stage(0); stage(1); stage(2);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int od = 0; od < p.OD; ++od) {
+            // slices od .. od+2 are resident and slot (od+3)&3 is free (the barrier that ended the previous step)
+            if (od + 1 < p.OD) stage(od + 3);
+            // this slice's residual tile is requested now and consumed after the 27 taps (one load -> wait -> store chain per output
+            // made the epilogue the longest phase of a step)
+            const int col_ = c0 + j;
+            const bool col_ok = j < T16_COLS && col_ < p.OW;
+            const int row0 = r0 + wave * RW;
+            const _Float16* res = (p.res && !dense1) ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride : nullptr;
+            const int rl = od * rd_ + row0 * rh + col_ * 32 + g * 4;
+            f16x4 rv[RW][CT];
+            float rdv[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                rdv[r] = 0.f;
+                if (dense1 && p.res && g == 0 && col_ok && row0 + r < p.OH)
+                    rdv[r] = ((const float*)p.res)[(((long)n * p.OD + od) * p.OH + row0 + r) * p.OW + col_];
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    rv[r][ct] = (f16x4){0, 0, 0, 0};
+                    if (res && col_ok && row0 + r < p.OH) rv[r][ct] = *(const f16x4*)(res + rl + (ct >> 1) * rc + r * rh + (ct & 1) * 16);
+                }
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // (kd, kw) groups, one ahead: the RW+2 rows of column shift kw in slice od+kd, and the 3 x CT weight fragments of (kd, *, kw)
+            f16x8 rowA[RW + 2], rowB[RW + 2];
+            auto gfetch = [&](f16x8 (&rows)[RW + 2], int grp) __attribute__((always_inline)) {
+                const int kd = grp / 3, kw = grp - kd * 3;
+                const __attribute__((address_space(3))) char* sb = ring + ((od + kd) & 3) * SLOT + lane_b + kw * 16;
+#pragma unroll
+                for (int rr = 0; rr < RW + 2; ++rr) rows[rr] = *(lds_frag*)(sb + rr * 1024);
+            };
+            auto gmfma = [&](const f16x8 (&rows)[RW + 2], int grp) __attribute__((always_inline)) {
+                const int kd = grp / 3, kw = grp - kd * 3;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[(kd * 3 + kh) * 3 + kw][ct], rows[r + kh], acc[r][ct], 0, 0, 0);
+            };
+            gfetch(rowA, 0);
+#pragma unroll
+            for (int grp = 0; grp < 9; ++grp) {
+                if (grp + 1 < 9) { if (grp & 1) gfetch(rowA, grp + 1); else gfetch(rowB, grp + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp & 1) gmfma(rowB, grp); else gmfma(rowA, grp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the loads of this step (next slice's rows, residuals) are waited for HERE, before the stores are issued: the stores then
+            // stay in flight through the barrier and the next step's MFMAs (vmcnt counts them too; waiting at the top of the next step
+            // exposed their write latency once per output slice)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- epilogue of output slice od
+            if (dense1) {
+                float* yd = (float*)p.y;
+                if (g == 0 && col_ok) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        if (row0 + r < p.OH) yd[(((long)n * p.OD + od) * p.OH + row0 + r) * p.OW + col_] = acc[r][0].x + rdv[r];
+                }
+            } else {
+                _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride;
+                const int yl = od * yd_ + row0 * yh + col_ * 32 + g * 4;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        f32x4 v = acc[r][ct] * sc_[ct] + sh_[ct];
+                        v.x += (float)rv[r][ct].x; v.y += (float)rv[r][ct].y; v.z += (float)rv[r][ct].z; v.w += (float)rv[r][ct].w;
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        f16x4 hv;
+                        hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
+                        if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + (ct >> 1) * yc + r * yh + (ct & 1) * 16) = hv;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave's rows landed; everyone is done reading slice od-1's slot
+        }
+    }
+}
+
+template <int RW, int CT>
+int launch_slide(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int TR = RW * T16_WAVES;
+    constexpr size_t lds = 4 * (size_t)(TR + 2) * 1024 + 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv16s_kernel<RW, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long columns = (long)p.N * ((p.OH + TR - 1) / TR) * ((p.OW + T16_COLS - 1) / T16_COLS);
+    if (columns >= (1L << 31)) return -5;
+    long blocks = 256;                                   // one block per CU: the weights take the wave's register file
+    if (blocks > columns) blocks = columns;
+    hipLaunchKernelGGL((conv16s_kernel<RW, CT>), dim3((unsigned)blocks), dim3(64 * T16_WAVES), lds, stream, p);
+    return (int)hipGetLastError();
 }
 
 template <int RW, int CT, int ND>
@@ -275,5 +445,13 @@ extern "C" int drc_conv16_k3_tile_fwd(const drc_tapconv_params* pp, void* stream
         (p.res && p.reserved != 1 && p.r_n_stride * 2 >= (1LL << 31)))
         return -5;                                                                       // ... and inside one unit of x / y / res
     hipStream_t s = (hipStream_t)stream;
+#ifndef T16_SLIDE
+#define T16_SLIDE 1
+#endif
+    if (T16_SLIDE && p.cls[0].nd == 3 && p.cb_in == 1 && p.cout_pad <= 32 && p.OD >= 4) {      // one input block, <= 32 couts: depth-sliding walk
+        const bool tall = p.OH % 16 == 0 || p.OH >= 48;
+        if (p.cout_pad == 32) return tall ? launch_slide<4, 2>(p, s) : launch_slide<2, 2>(p, s);
+        return tall ? launch_slide<4, 1>(p, s) : launch_slide<2, 1>(p, s);
+    }
     return p.cls[0].nd == 3 ? pick<3>(p, s) : pick<1>(p, s);
 }

@@ -1143,8 +1143,10 @@ class ConvPlan16:
         self.tile = bool(C16_TILE["enabled"] and _lib.lib().drc_conv16_k3_tile_supported(C.byref(p)))
         if self.tile:
             ct = p.cout_pad // 16
-            self.kname = "conv16t_kernel<%d,%d,%d>" % (4 if (OH % 16 == 0 or OH >= 48) else 2, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1),
-                                                        classes[0]["n"][0])
+            rw = 4 if (OH % 16 == 0 or OH >= 48) else 2
+            self.kname = "conv16t_kernel<%d,%d,%d>" % (rw, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1), classes[0]["n"][0])
+            if classes[0]["n"][0] == 3 and x.cb == 1 and p.cout_pad <= 32 and OD >= 4:      # conv16t.hip: the depth-sliding walk
+                self.kname = "conv16s_kernel<%d,%d>" % (rw, p.cout_pad // 16)
 
     def run(self, x, w16, scale, shift, y, res=None):
         p = self.p

@@ -310,7 +310,8 @@ int drc_align_roi_pairs(const float* left_boxes, const float* right_boxes, const
  * classifier conv with the cumulative head add (stackhourglass.py:78-88,142-144).  No reference counterpart (fp32-only). */
 int drc_conv16_fwd(const drc_tapconv_params* p, void* stream);
 /* The stride-1 3x3x3 / 3x3 (pad 1, one tap class) layers of the same parameter block with the input tile staged in LDS
- * (conv16t.hip): 16- or 8-row x 14-column output tiles of one slice per block, all taps read their voxel fragments from LDS.
+ * (conv16t.hip): 16- or 8-row x 14-column output tiles of one slice per block, all taps read their voxel fragments from LDS; 3x3x3 layers
+ * with one 32-channel input block, <= 32 couts and OD >= 4 take the depth-sliding form (weights in registers, each input slice staged once).
  * R, WT are ignored.  Reads up to 15 voxel lines past a plane's last padded row / column on ragged maps (values there do not reach a
  * stored output): the tensor must be followed by that much readable memory (engine.Blocked16's slack).  _supported: 1 if the
  * parameter block describes such a layer. */

@@ -32,7 +32,10 @@ def _h(t):
     (64, 32, 1, False, (4, 12, 28), True), (32, 32, 1, False, (3, 28, 28), False), (32, 64, 2, False, (12, 28, 28), False),
     (64, 64, 2, False, (6, 14, 14), True), (64, 64, 1, False, (3, 7, 7), True), (64, 64, 1, True, (3, 7, 7), True),
     (64, 32, 1, True, (6, 14, 14), False), (24, 40, 1, False, (2, 5, 9), True), (24, 16, 1, True, (3, 9, 30), True),
-    (40, 48, 2, False, (6, 10, 18), False), (32, 32, 1, False, (2, 56, 56), True)])
+    (40, 48, 2, False, (6, 10, 18), False), (32, 32, 1, False, (2, 56, 56), True),
+    # one input block, <= 32 couts, depth >= 4: the depth-sliding walk (conv16s_kernel), incl. ragged rows / columns and 16 couts
+    (32, 32, 1, False, (6, 28, 28), True), (32, 32, 1, False, (5, 20, 17), False), (24, 16, 1, False, (4, 9, 30), True),
+    (32, 32, 1, False, (9, 56, 56), True)])
 def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, transposed, dims, with_res):
     from disprcnn_amd import engine as E
     n = 2
@@ -53,6 +56,7 @@ def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, t
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale.to(dev); sh[:cout] = shift.to(dev)
     assert plan.tile == (stride == 1 and not transposed)            # stride-1 layers: the LDS-tiled kernel (conv16t.hip)
+    assert plan.kname.startswith("conv16s") == (plan.tile and cin <= 32 and cout <= 32 and dims[0] >= 4)
     plan.run(xb, E.pack_weight16(w.to(dev), transposed), sc, sh, yb, rb)
     got = yb.to_dense().cpu()
     assert got.shape == ref.shape
