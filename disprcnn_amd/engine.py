@@ -654,6 +654,7 @@ class ConvPlan:
 
 # Kernel-selection switches (defaults = the fastest measured path; the tests flip them to keep every variant covered)
 WINO = {"enabled": True,      # stride-1 3x3x3 layers with even output dims as Winograd F(2x2x2,3x3x3) (wino3d.hip)
+        "small": 48,          # ... also below the sliding kernel's unit threshold, from this many 64-tile chunks (0: never); fewer: tapdirect<.,1>
         "fuse_costvol": True, # eval: dres0[0] reads the feature maps directly, the cost volume is never written (wino3d_cv_kernel)
         "rb": True,           # 28- and 14-wide maps: the two-waves-per-SIMD row-brick kernel (wino3d_rb.hip) ...
         "rb_min_chunks": 256} # ... when every CU gets at least one (64-tile chunk, 32-cout group) unit
@@ -707,11 +708,19 @@ def plan_conv3d(x, y, stride, cout, relu):
                     and _lib.lib().drc_conv3d_k3_wino_rb_supported(pl.p.cout_pad, y.D, y.H, y.W)):
                 pl.rb = True
                 pl.kname = "wino3d_rb_kernel<%d>" % (7 if y.W == 14 else 14)
-    elif (not pl.slide and stride == 1 and SLIDE["enabled"] and DIRECT["enabled"] and getattr(pl, "slide_small_ok", False)
-          and (y.D | y.H | y.W) & 1):
-        # odd maps (no Winograd) at small batch: the direct kernel with one cout tile per wave
-        pl.slide, pl.direct, pl.slide_ct = True, True, 1
-        pl.kname = "tapdirect_kernel<%d,1>" % (-(-(pl.p.R * pl.p.WT) // 16))
+    elif not pl.slide and stride == 1 and SLIDE["enabled"] and DIRECT["enabled"] and getattr(pl, "slide_small_ok", False):
+        wchunks = x.N * (y.D // 2) * (y.H // 2) * (y.W // 2) // 64
+        if WINO["enabled"] and wchunks >= WINO["small"] > 0 and not (y.D | y.H | y.W) & 1 and x.N * x.n_stride * 4 < 2 ** 32:
+            # even maps at small batch (Config B's quarter-resolution hourglass layers, 16 ROIs: 6 x 14 x 14): Winograd still halves
+            # the generic kernel's time (4 ROIs at 12 x 28 x 28: 74 vs 119 us direct; round 3 -- rounds 1-2 sent these to tapconv);
+            # below ~48 chunks every kernel sits at its ~65 us latency floor and the direct one is marginally ahead
+            pl.slide, pl.direct, pl.wino = True, True, True
+            pl.slide_ct = SLIDE["ct"] if (pl.p.cout_pad // 16) % SLIDE["ct"] == 0 else 1
+            pl.kname = "wino3d_kernel<%d>" % pl.slide_ct
+        else:
+            # odd maps (no Winograd) at small batch: the direct kernel with one cout tile per wave
+            pl.slide, pl.direct, pl.slide_ct = True, True, 1
+            pl.kname = "tapdirect_kernel<%d,1>" % (-(-(pl.p.R * pl.p.WT) // 16))
     elif pl.slide and (pl.p.R + 2) * (-(-(2 * (pl.p.WT + 2)) // 64)) > 18:
         pl.slide = False                     # the LDS-staged kernel stages at most two pieces per tap step: tall narrow tiles go generic
         pl.kname = pl.kname.replace("tapslide", "tapconv")

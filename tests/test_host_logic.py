@@ -126,7 +126,11 @@ def test_stride1_conv3d_kernel_selection():
         assert not plan(256, 32, (12, 28, 28)).wino
     finally:
         E.WINO["enabled"] = saved
-    pl = plan(2, 32, (12, 28, 28))                      # too few work units for the sliding kernels
+    pl = plan(2, 32, (12, 28, 28))                      # below the sliding kernels' unit threshold, 36 Winograd chunks (< 48):
+    assert not pl.wino and pl.direct and pl.kname == "tapdirect_kernel<7,1>"            # the direct kernel, one cout tile per wave (round 3)
+    pl = plan(4, 64, (12, 28, 28))                      # ... 73 chunks: Winograd (rounds 1-2: the generic kernel)
+    assert pl.wino and pl.kname == "wino3d_kernel<2>"
+    pl = plan(1, 32, (2, 4, 4))                         # a handful of voxels: the generic kernel
     assert not pl.wino and not pl.direct
     # a Winograd plan wants the 64-point packing, not the 27-tap one
     pl = plan(256, 32, (12, 28, 28))
