@@ -451,7 +451,7 @@ def rank0_extras(dev, extra):
                      "note": ("whole stereo-pair pipeline, direct-convolution-equivalent conv flops (SURVEY 8a/8d: backbone 250.3 G + 16 x "
                               "(2 x 22.19 G 2D CNN + 48.51 G regressor)) / wall time; an upper bound on the executed MFMA fraction because the "
                               "Winograd layers execute 64/216 (3D) and 16/36 (2D) of their share; per-kernel MFMA-busy and HBM bytes: "
-                              "profiles/r2_pair_*.md")},
+                              "profiles/r3_pair_backbone_*.md, r3_configB_*.md")},
         "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
     del bb, det, mB
     # ---- the 2D stage in front of the path: DispRCNN = R-50-FPN trunk + Stereo RPN + stereo box head + mask head on the pair

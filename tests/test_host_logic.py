@@ -242,3 +242,51 @@ def test_graphed_step_needs_the_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         GraphedStep(lambda: torch.zeros(1))
+
+
+def test_stem_space_to_depth_weight_is_the_same_convolution():
+    """backbone/runtime.py: the 7x7 stride-2 pad-3 stem as a 4x4 stride-1 convolution over the 2x2 pixel-unshuffled image (round 3) --
+    exact re-indexing of the weights (float64, even and odd image sizes)."""
+    from disprcnn_amd.modeling.backbone.runtime import _stem_s2d_weight
+    g = torch.Generator().manual_seed(3)
+    for H, W in ((10, 14), (11, 13), (7, 8)):
+        x = torch.randn(2, 3, H, W, dtype=torch.float64, generator=g)
+        w = torch.randn(5, 3, 7, 7, dtype=torch.float64, generator=g)
+        ref = torch.nn.functional.conv2d(x, w, stride=2, padding=3)
+        xs = torch.nn.functional.pixel_unshuffle(torch.nn.functional.pad(x, (0, W & 1, 0, H & 1)), 2)
+        got = torch.nn.functional.conv2d(torch.nn.functional.pad(xs, (2, 1, 2, 1)), _stem_s2d_weight(w))
+        assert got.shape[2] >= ref.shape[2] and got.shape[3] >= ref.shape[3]
+        assert (got[:, :, :ref.shape[2], :ref.shape[3]] - ref).abs().max().item() < 1e-12
+
+
+def test_fp16_kernel_selection():
+    """Which fp16 kernel a layer takes (engine.ConvPlan16): the depth-sliding walk for one input block / <= 32 couts / depth >= 4, the
+    LDS-tiled kernel for the other stride-1 3x3x3 and 3x3 layers, conv16.hip's generic tap walk for strides, transposed, dilated and 1x1."""
+    from disprcnn_amd import engine as E
+    dev = torch.device("cpu")
+
+    def geo(n, c, d, h, w, pad=1, pd=1):
+        b = E.Blocked16.__new__(E.Blocked16)
+        b.N, b.C, b.D, b.H, b.W, b.pd, b.ph, b.pw = n, c, d, h, w, pd, pad, pad
+        b.cb = (c + 31) // 32
+        b.Dp, b.Hp, b.Wp = d + 2 * pd, h + 2 * pad, w + 2 * pad
+        b.h_stride = b.Wp * 32; b.d_stride = b.Hp * b.h_stride; b.cb_stride = b.Dp * b.d_stride; b.n_stride = b.cb * b.cb_stride
+        b.device = dev
+        return b
+
+    assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16s_kernel<4,2>"
+    assert E.plan_conv3d16(geo(4, 64, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16t_kernel<4,2,3>"      # two input blocks
+    assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16t_kernel<2,4,3>"
+    assert E.plan_conv3d16(geo(4, 32, 3, 28, 28), geo(4, 32, 3, 28, 28), 1, 32, True).kname == "conv16t_kernel<2,2,3>"        # depth < 4
+    assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 64, 12, 28, 28), 2, 64, True).kname.startswith("conv16_kernel")
+    assert E.plan_conv3d16_cout1(geo(4, 32, 24, 56, 56)).kname == "conv16s_kernel<4,1>"
+    x2 = geo(8, 64, 1, 56, 56, pad=1, pd=0)
+    assert E.plan_conv2d16(x2, geo(8, 64, 1, 56, 56, pd=0), 3, 1, 1, 1, 64, True).kname == "conv16t_kernel<4,4,1>"
+    assert E.plan_conv2d16(geo(8, 128, 1, 56, 56, pad=2, pd=0), geo(8, 128, 1, 56, 56, pd=0), 3, 1, 2, 2, 128, True).kname.startswith("conv16_kernel")
+    assert E.plan_conv2d16(x2, geo(8, 64, 1, 56, 56, pd=0), 1, 1, 0, 1, 64, False).kname.startswith("conv16_kernel")
+    saved = E.C16_TILE["enabled"]
+    E.C16_TILE["enabled"] = False
+    try:
+        assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname.startswith("conv16_kernel")
+    finally:
+        E.C16_TILE["enabled"] = saved
