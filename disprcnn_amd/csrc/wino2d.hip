@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-template <int CT>
+template <int CT, int DIL>      // DIL: dilation as a compile-time constant (as a run-time scalar it cost the undilated layers 36 spilled SGPRs, 5-10 %)
 __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv_params p) {
     // transformed weights of a half step (8 frequency points x CT*16 couts x 16 channels), ring of three, shared by the block
     __shared__ __attribute__((aligned(16))) float w_ring[3][8][CT][256];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
     // Dilation d (round 3; the feature CNN's layer4, d = 2): a dilated 3x3 convolution is d*d independent undilated ones on the
     // sub-grids (a, b) + d*(i, j), so a tile is (n, a, b, ht, wt): patch rows / columns d apart, the 2x2 outputs d apart.  The host
     // admits d > 1 only when 2d divides OH and OW (every sub-grid has whole tiles).
-    const int dil = cls.sh;
+    constexpr int dil = DIL;
     const int TH = dil > 1 ? p.OH / (2 * dil) : (p.OH + 1) >> 1;   // d = 1, odd maps: the last tile row / column is half used (see unit_end)
     const int TW = dil > 1 ? p.OW / (2 * dil) : (p.OW + 1) >> 1;
     const int tiles = p.N * dil * dil * TH * TW;
@@ -263,9 +263,9 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
 #undef W2_MFMA_ROW
 }
 
-template <int CT>
+template <int CT, int DIL>
 int launch(const drc_tapconv_params& p, hipStream_t stream) {
-    const int dil = p.cls[0].sh;
+    constexpr int dil = DIL;
     const long tiles = dil > 1 ? (long)p.N * (p.OH / 2) * (p.OW / 2) : (long)p.N * ((p.OH + 1) / 2) * ((p.OW + 1) / 2);
     const long groups = (tiles + 15) / 16;
     const int n_cg = p.cout_pad / 16 / CT;
@@ -275,7 +275,7 @@ int launch(const drc_tapconv_params& p, hipStream_t stream) {
     if (per_cg > need) per_cg = need;
     if (per_cg < 1) per_cg = 1;
     dim3 grid((unsigned)(per_cg * n_cg), 1, 1);
-    hipLaunchKernelGGL((wino2d_kernel<CT>), grid, dim3(64 * W2_WAVES), 0, stream, p);
+    hipLaunchKernelGGL((wino2d_kernel<CT, DIL>), grid, dim3(64 * W2_WAVES), 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -328,7 +328,10 @@ extern "C" int drc_conv2d_k3_wino_fwd(const drc_tapconv_params* pp, int cout_til
     const int ct = p.cout_pad / 16, CT = cout_tiles_per_wave;
     if ((CT != 1 && CT != 2) || ct % CT) return -2;
     hipStream_t s = (hipStream_t)stream;
-    return CT == 2 ? launch<2>(p, s) : launch<1>(p, s);
+    if (k.sh == 1) return CT == 2 ? launch<2, 1>(p, s) : launch<1, 1>(p, s);
+    if (k.sh == 2) return CT == 2 ? launch<2, 2>(p, s) : launch<1, 2>(p, s);
+    if (k.sh == 4) return CT == 2 ? launch<2, 4>(p, s) : launch<1, 4>(p, s);
+    return -4;
 }
 
 extern "C" int drc_pack_weights_wino2d(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream) {

@@ -659,8 +659,10 @@ WINO = {"enabled": True,      # stride-1 3x3x3 layers with even output dims as W
         "rb": True,           # 28- and 14-wide maps: the two-waves-per-SIMD row-brick kernel (wino3d_rb.hip) ...
         "rb_min_chunks": 256} # ... when every CU gets at least one (64-tile chunk, 32-cout group) unit
 WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (wino2d.hip) ...
-          "rb": False, "rb_min_chunks": 256,  # the row-brick kernel's 2D form (widths 14 or multiples of 28): bit-identical, measured equal
-                                              # (32 crops: 70.7 vs 77.2 us at 32ch@112^2, 198 vs 201 at 128ch@56^2, 442 vs 404 at 320->128) -> off
+          "rb": True, "rb_min_chunks": 256, "rb_max_cb": 8,
+          # the row-brick kernel's 2D form (widths 14 or multiples of 28; bit-identical) for layers of <= 128 input channels: after the
+          # round-3 fix of wino2d's spilled scalars still 70 vs 82 us at 32ch@112^2, 68 vs 75 at 64ch@56^2, 194 vs 201 at 128ch@56^2
+          # (32 crops; 265 vs 350 / 218 vs 266 / 693 vs 754 at 128 crops); 320 -> 128 loses (443 vs 405) and stays on wino2d
           "dilated": True,    # dilated layers whose maps divide by 2*dilation: d*d interleaved sub-grids (feature CNN layer4; round 3)
           "odd": True,        # odd maps too (the trunk's 47 x 155 level: 256 -> 256 186 -> ? us); False: direct kernel as in rounds 1-2
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
@@ -850,7 +852,7 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
             pl.slide_ct = wct
             pl.kname = "wino2d_kernel<%d>" % wct
             chunks = wtiles // 64
-            if (WINO2D.get("rb") and dilation == 1 and not (y.H | y.W) & 1 and chunks * (pl.p.cout_pad // 32) >= WINO2D["rb_min_chunks"]
+            if (WINO2D.get("rb") and dilation == 1 and x.cb <= WINO2D["rb_max_cb"] and not (y.H | y.W) & 1 and chunks * (pl.p.cout_pad // 32) >= WINO2D["rb_min_chunks"]
                     and _lib.lib().drc_conv2d_k3_wino_rb_supported(pl.p.cout_pad, y.H, y.W)):
                 pl.rb = True
                 pl.kname = "wino2d_rb_kernel<%d>" % (7 if y.W == 14 else 14)

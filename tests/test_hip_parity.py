@@ -357,17 +357,17 @@ def test_conv2d_winograd_rowbrick_kernel(dev, n, cin, cout, hw, with_res, expect
     res = synth.hash_uniform(f"RB2{cout}{hw}:r", (n, cout) + hw) if with_res else None
     ref = F.conv2d(x, w, None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     ref = F.relu(ref + res) if with_res else ref
-    saved = (E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"])
+    saved = (E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"], E.WINO2D["rb_max_cb"])
     got = {}
     try:
         for rb in (True, False):
-            E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"] = True, 0, rb, 0
+            E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"], E.WINO2D["rb_max_cb"] = True, 0, rb, 0, 1 << 20
             xb = E.Blocked(n, cin, 1, *hw, 0, 1, 1, dev)
             plan = E.plan_conv2d(xb, E.Blocked(n, cout, 1, *hw, 0, 1, 1, dev), 3, 1, 1, 1, cout, True)
             assert plan.wino and plan.c2d and plan.rb == (rb and expect_rb), (plan.kname, rb)
             got[rb] = ops.conv2d_bn(x.to(dev), w.to(dev), scale.to(dev), shift.to(dev), 1, 1, 1, with_res, res.to(dev) if with_res else None)
     finally:
-        E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"] = saved
+        E.WINO2D["enabled"], E.WINO2D["min_chunks"], E.WINO2D["rb"], E.WINO2D["rb_min_chunks"], E.WINO2D["rb_max_cb"] = saved
     _close(got[True], ref)
     assert torch.equal(got[True], got[False]), (got[True] - got[False]).abs().max().item()
 

@@ -151,7 +151,8 @@ def test_conv2d_3x3_kernel_selection():
         oh, ow = (hw[0] - 1) // stride + 1, (hw[1] - 1) // stride + 1
         return E.plan_conv2d(x, E.Blocked(n, c, 1, oh, ow, 0, 1, 1, dev), 3, stride, dil, dil, c, True)
 
-    assert plan(32, 32, (112, 112)).kname == "wino2d_kernel<2>"
+    assert plan(32, 32, (112, 112)).kname == "wino2d_rb_kernel<14>"      # <= 128 input channels on a 28-multiple width: the row-brick form (round 3)
+    assert plan(2, 256, (56, 56)).kname == "wino2d_kernel<2>"            # more input channels (or too few chunks): wino2d.hip
     assert plan(32, 128, (56, 56)).wino
     assert plan(2, 64, (94, 311)).wino                # odd width: half-used last tile column (round 3)
     saved_odd = E.WINO2D["odd"]
