@@ -10,6 +10,9 @@
 // a 16-channel block as one coalesced float4), writes P to LDS as [tap][row][col] with zero pad columns, and gathers the 27
 // shifted values per output voxel in a fixed order (no atomics: results do not depend on the batch or the schedule).
 // Three partial output slices (depth taps 0,1,2 -> od = d+1, d, d-1) live in registers.
+// Round 3: with few ROIs (16 crops at 24x56x56: 448 columns for 1024 SIMDs, each walking 24 slices: 257 us for 179 MB) the depth is cut into
+// `segs` segments (grid.y): a wave emits the output slices [o0, o1) of its segment from the input slices o0-1 .. o1 (two extra slices
+// per segment, no atomics, the same fixed summation order per output).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,7 +27,7 @@ namespace {
 // x: blocked [N][2][D+2][H+2][W+2][16] (halo 1); w: [27][32]; res/out: dense [N][D][H][W]
 __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                     const float* __restrict__ res, float* __restrict__ out, int N, int D, int H,
-                                                                    int W, int R) {
+                                                                    int W, int R, int segs) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -33,6 +36,9 @@ __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float*
     const int col = blockIdx.x * C1M_WAVES + wave;       // (n, row tile)
     if (col >= N * n_rt) return;                         // wave-uniform; no workgroup barrier
     const int n = col / n_rt, oh0 = (col - n * n_rt) * R;
+    const int o0 = (int)((long)blockIdx.y * D / segs), o1 = (int)((long)(blockIdx.y + 1) * D / segs);   // output slices of this segment
+    const int d_begin = o0 > 0 ? o0 - 1 : 0, d_end = o1 < D ? o1 : D - 1;                              // input slices it reads
+    if (o0 >= o1) return;
     const int Wp = W + 2, Hp = H + 2, Dp = D + 2;
     const int prow = W + 2;                              // P row stride (zero pad column each side)
     const int rows_p = R + 2;
@@ -85,10 +91,10 @@ __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float*
         return xn + ((int64_t)(d + 1) * Hp + row) * Wp * 16 + (int64_t)(c + 1) * 16 + g * 4;
     };
     bool vin_n; int r_n, c_n;
-    const float* xp_n = tile_ptr(0, 0, vin_n, r_n, c_n);
+    const float* xp_n = tile_ptr(d_begin, 0, vin_n, r_n, c_n);
     f32x4 nb0 = *(const f32x4*)xp_n, nb1 = *(const f32x4*)(xp_n + cbs);
 
-    for (int d = 0; d < D; ++d) {
+    for (int d = d_begin; d <= d_end; ++d) {
         // ---- P = W x X over the tile's voxels
         for (int vt = 0; vt < ntile; ++vt) {
             const f32x4 b0 = nb0, b1 = nb1;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float*
             const int r = r_n, c = c_n;
             {   // next tile (of this slice, or the first of the next slice; past the end: a harmless reload)
                 const bool last = vt + 1 == ntile;
-                const int dn = last ? (d + 1 < D ? d + 1 : d) : d;
+                const int dn = last ? (d + 1 <= d_end ? d + 1 : d) : d;
                 xp_n = tile_ptr(dn, last ? 0 : vt + 1, vin_n, r_n, c_n);
                 nb0 = *(const f32x4*)xp_n; nb1 = *(const f32x4*)(xp_n + cbs);
             }
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float*
                 }
             a0[u] += s0; a1[u] += s1; a2[u] += s2;
         }
-        // output slice d-1 is complete
-        if (d >= 1) {
+        // output slice d-1 is complete (emitted when it belongs to this segment)
+        if (d - 1 >= o0 && d - 1 < o1) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (ov[u]) {
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float*
         for (int u = 0; u < 2; ++u) { a2[u] = a1[u]; a1[u] = a0[u]; a0[u] = 0.f; }
     }
     // last slice: od = D-1 has no contribution from a slice D (zero halo)
+    if (o1 == D)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
         if (ov[u]) {
@@ -174,8 +181,12 @@ extern "C" int drc_conv3d_cout1_mfma_try(const float* x, const float* w, const f
         attr_done = true;
     }
     const long cols = (long)N * ((H + R - 1) / R);
-    hipLaunchKernelGGL(cout1_mfma_kernel, dim3((unsigned)((cols + C1M_WAVES - 1) / C1M_WAVES)), dim3(64 * C1M_WAVES), lds, (hipStream_t)stream, x, w,
-                       res, out, N, D, H, W, R);
+    // depth segments: enough waves for two per SIMD, at least four output slices each (two extra input slices per segment)
+    long segs = (2048 + cols - 1) / cols;
+    if (segs > D / 4) segs = D / 4;
+    if (segs < 1) segs = 1;
+    hipLaunchKernelGGL(cout1_mfma_kernel, dim3((unsigned)((cols + C1M_WAVES - 1) / C1M_WAVES), (unsigned)segs), dim3(64 * C1M_WAVES), lds,
+                       (hipStream_t)stream, x, w, res, out, N, D, H, W, R, (int)segs);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -481,7 +481,8 @@ def test_conv2d_layer_vs_oracle(dev, cin, cout, k, stride, pad, dil, hw):
     _close(got, F.relu(ref + res))
 
 
-@pytest.mark.parametrize("n,dims", [(3, (12, 28, 28)), (2, (6, 56, 56)), (2, (5, 9, 13)), (1, (1, 3, 112)), (2, (3, 30, 7))])
+@pytest.mark.parametrize("n,dims", [(3, (12, 28, 28)), (2, (6, 56, 56)), (2, (5, 9, 13)), (1, (1, 3, 112)), (2, (3, 30, 7)),
+                                    (2, (24, 56, 56)), (1, (13, 28, 28)), (1, (9, 16, 20))])      # few columns: depth segments (round 3)
 def test_classifier_conv_cout1_vs_oracle(dev, n, dims):
     """Conv3d(32->1, k3, p1, bias=False) + cumulative head add (stackhourglass.py:78-88,142-144): the MFMA 1x1x1-GEMM +
     shifted-sum kernel (and its scalar fallback shapes) vs F.conv3d; 2e-5 * max|ref| + 1e-5."""
