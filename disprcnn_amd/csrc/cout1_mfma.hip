@@ -181,8 +181,9 @@ extern "C" int drc_conv3d_cout1_mfma_try(const float* x, const float* w, const f
         attr_done = true;
     }
     const long cols = (long)N * ((H + R - 1) / R);
-    // depth segments: enough waves for two per SIMD, at least four output slices each (two extra input slices per segment)
-    long segs = (2048 + cols - 1) / cols;
+    // depth segments when the columns alone leave SIMDs idle: enough waves for two per SIMD, at least four output slices each (two extra
+    // input slices per segment)
+    long segs = cols >= 1024 ? 1 : (2048 + cols - 1) / cols;          // (one wave per SIMD or more: the extra slices cost more than they fill)
     if (segs > D / 4) segs = D / 4;
     if (segs < 1) segs = 1;
     hipLaunchKernelGGL(cout1_mfma_kernel, dim3((unsigned)((cols + C1M_WAVES - 1) / C1M_WAVES), (unsigned)segs), dim3(64 * C1M_WAVES), lds,
