@@ -36,6 +36,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RB_PAIR 0              // 1: staging items of one column pair, the neighbour's pair fetched with ds_bpermute (half the loads;
                                //    bit-identical, measured 3-6 % slower: the exchange puts an LDS round trip into every item)
 #endif
+#ifndef RB_PP
+#define RB_PP 1                // 1: the two waves of a SIMD run ONE barrier interval apart ("ping-pong"): while one multiplies (32 MFMAs) its partner
+                               //    reads operands, stages the next brick and runs the phase ends; 0: both in lock step (round 3)
+#endif
 #ifdef RB_ABL_NOBARRIER
 #define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
@@ -46,16 +50,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef RB_TRACE
 // development only: s_memtime stamps of block RB_TRACE_BLOCK, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps
 __device__ unsigned long long rb_trace_buf[2][64][16];
+#if RB_PP
+// the stamps of a step are collected in one VGPR (lane k = mark k) and stored once per step, so that no trace store sits in front of the
+// kernel's own vmcnt waits
+#define RB_MARK(k) do { if (rb_traced) { const unsigned t_ = __builtin_amdgcn_readfirstlane((unsigned)__builtin_readcyclecounter()); \
+                             asm volatile("v_writelane_b32 %0, %1, " #k : "+v"(rb_marks) : "s"(t_)); } } while (0)
+#define RB_FLUSH_MARKS() do { if (rb_traced && stepno > 8 && stepno <= 72 && lane < 16) rb_trace_buf[wave >> 2][stepno - 9][lane] = rb_marks; } while (0)
+#else
 #define RB_MARK(k)                                                                                              \
     do {                                                                                                        \
         if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && stepno >= 8 && stepno < 72)                      \
             rb_trace_buf[wave >> 2][stepno - 8][k] = __builtin_readcyclecounter();                              \
     } while (0)
+#endif
 extern "C" int drc_rb_trace_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_trace_buf), sizeof(rb_trace_buf));
 }
 #else
 #define RB_MARK(k)
+#define RB_FLUSH_MARKS()
 #endif
 
 namespace {
@@ -83,6 +96,10 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     const int g = lane >> 4;
     const int tg = wave & 3;                       // tile group of the chunk
     const int ctl = wave >> 2;                     // cout tile within the block's 32 couts (waves w and w+4 share a SIMD)
+#if defined(RB_TRACE) && RB_PP
+    const bool rb_traced = blockIdx.x == 8 && (wave & 3) == 0;
+    unsigned rb_marks = 0;
+#endif
 
     const drc_tap_class cls = p.cls[0];
     // Maps wider than 2 TW columns (Config B's 56-wide volume at TW = 14) are walked as WS side-by-side strips of TW tile columns: a
@@ -204,8 +221,9 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     struct Raw { f32x4 a[kCols], b[kCols]; };
     // (all uniform offsets are 32-bit: the launcher checks N * x_n_stride * 4 < 2^32 and the packed weights < 2^31 floats)
     const unsigned xcb4 = (unsigned)p.x_cb_stride * 4u, xd4 = (unsigned)p.x_d_stride * 4u;
-    auto stage_issue = [&](const Item& it, int xd, int cb, Raw& r) __attribute__((always_inline)) {
-#ifdef RB_ABL_NOSTAGE
+    // the loads of column w of an item (slice a, slice b); stage_issue = all columns
+    auto stage_issue_w = [&](const Item& it, int xd, int cb, Raw& r, int w) __attribute__((always_inline)) {
+#if defined(RB_ABL_NOSTAGE) || defined(RB_ABL_NOISS)
         return;
 #endif
         if (kPair ? !it.live : !it.valid) return;
@@ -217,27 +235,25 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                 const int d = it.d0 + (ab == 0 ? slice_a(xd) : slice_b(xd));
                 const bool ind = (unsigned)d < (unsigned)p.OD;
                 const int sh = right ? cv.lo4 + d : 0;                              // the right map is read at x - i
-#pragma unroll
-                for (int w = 0; w < kCols; ++w) {
-                    const int x = it.x0 + w;
-                    const bool ok = ind && (unsigned)x < (unsigned)cv.Wp && (unsigned)(x - cv.lo4 - d) < (unsigned)cv.Wp;
-                    const unsigned off = it.goff + (ok ? (unsigned)((x - sh + cv.pad) * 64) : 0u);
-                    (ab == 0 ? r.a[w] : r.b[w]) = *(const f32x4*)(base + off);
-                }
+                const int x = it.x0 + w;
+                const bool ok = ind && (unsigned)x < (unsigned)cv.Wp && (unsigned)(x - cv.lo4 - d) < (unsigned)cv.Wp;
+                const unsigned off = it.goff + (ok ? (unsigned)((x - sh + cv.pad) * 64) : 0u);
+                (ab == 0 ? r.a[w] : r.b[w]) = *(const f32x4*)(base + off);
             }
         } else {
             const char* sa = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_a(xd) * xd4);
             const char* sb = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_b(xd) * xd4);
-#pragma unroll
-            for (int w = 0; w < kCols; ++w) {
-                r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
-                if constexpr (!D2) r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
-            }
+            r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
+            if constexpr (!D2) r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
         }
+    };
+    auto stage_issue = [&](const Item& it, int xd, int cb, Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int w = 0; w < kCols; ++w) stage_issue_w(it, xd, cb, r, w);
     };
     // depth butterfly, w butterfly, four w-frequencies into brick buffer `bb`
     auto stage_finish = [&](const Item& it, int xd, char* bb, const Raw& r) __attribute__((always_inline)) {
-#ifdef RB_ABL_NOSTAGE
+#if defined(RB_ABL_NOSTAGE) || defined(RB_ABL_NOFIN)
         return;
 #endif
         if (kPair ? !it.live : !it.valid) return;
@@ -446,6 +462,197 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                 }
     };
 
+#if RB_PP
+    // ================= ping-pong pipeline =================
+    // Waves 0-3 (group A, one per SIMD) and waves 4-7 (group B, their SIMD partners) execute the same instruction stream, B one barrier
+    // interval ("slot") behind A.  The stream alternates an L segment (LDS side, no MFMA: the previous phase's inverse transform +
+    // epilogue if one ended, the operand reads + h butterflies of the coming half step, the transform + LDS write of the staging item
+    // whose loads were issued during the previous M) with an M segment (the half step's 32 MFMAs with the vector-memory issue spread
+    // between them: two LDS-DMA ring copies and the eight loads of the next staging item), so in every slot each SIMD has one wave
+    // in M and one in L:
+    //     slot   2i    2i+1   2i+2   2i+3
+    //     A      L_i   M_i    L_i+1  M_i+1
+    //     B      M_i-1 L_i    M_i    L_i+1
+    // LDS hand-offs (half step i = 2 * step + hf, brick buffer = step & 1, ring slab = hf):
+    //   * brick of step s+1: item A (loads issued in M_2s-1) written in L_2s, item B (issued in M_2s) written in L_2s+1 -- slots 4s..4s+3;
+    //     first read in slot 4s+4 (A's L_2s+2); that buffer's previous readers (step s-1) finished in slot 4s-1.
+    //   * ring slab of half step h: A's waves copy their 8 units at the start of M_h-1 (slot 2h-1), B's theirs at the start of M_h-2
+    //     (slot 2h-2), both wait for them (vmcnt(0)) before the barrier that ends that slot; first read in slot 2h; the slab's
+    //     previous readers (half step h-2) finished in slot 2h-3.
+    struct Cursor { int round, xd, cb; };
+    auto advance = [&](Cursor c) __attribute__((always_inline)) {
+        if (++c.cb == p.cb_in) { c.cb = 0; if (D2 || ++c.xd == 4) { c.xd = 0; ++c.round; } }
+        return c;
+    };
+    const int grp = ctl;                            // 0: group A, 1: group B
+    // wave's two units (w, w + 8) of half step (xd, cb, hf) -> slab hf
+    auto ring_fill_pp = [&](int xd, int cb, int hf) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOFILL
+        return;
+#endif
+        const char* src = wlane + ((unsigned)(xd * 16 + hf * 8) * wxi4 + (unsigned)cb * wcb4);
+        char* dst = ring + hf * 16384 + wave * 1024;
+        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src), RB_LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src + 4 * wxi4), RB_LDS_PTR(dst + 8192), 16, 0, 0);
+    };
+    f32x4 wf0[4], wf1[4], v0[4], v1[4];           // the operands of the coming M segment
+    // L: operand reads + h butterflies of half step HALF of the step whose brick rows start at tb
+    auto load_ops = [&](auto half_tag, const char* tb, const char* rs) __attribute__((always_inline)) {
+        constexpr int HALF = decltype(half_tag)::value;
+        f32x4 ta[4], tb_[4], tc[4];
+#ifdef RB_ABL_NOLDSR
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) {
+            const f32x4 c_ = {(float)lane, (float)(lane + xw), 1.f, 2.f};
+            wf0[xw] = c_; wf1[xw] = c_ * 2.f; ta[xw] = c_ * 3.f; tb_[xw] = c_ * 4.f; tc[xw] = c_ * 5.f;
+            asm volatile("" : "+v"(wf0[xw]), "+v"(wf1[xw]), "+v"(ta[xw]), "+v"(tb_[xw]), "+v"(tc[xw]));
+        }
+        if (false)
+#endif
+        {
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) ta[xw] = *(const f32x4*)(tb + (HALF == 0 ? 0 : 1) * SB + xw * XWS);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb + 2 * SB + xw * XWS);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) tc[xw] = *(const f32x4*)(tb + (HALF == 0 ? 1 : 3) * SB + xw * XWS);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) wf0[xw] = *(const f32x4*)(rs + (0 * 4 + xw) * 2048);
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) wf1[xw] = *(const f32x4*)(rs + (1 * 4 + xw) * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF == 0) {                 // xh 0: t0 - t2, xh 1: t1 + t2      (ta = t0, tb_ = t2, tc = t1)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) { v0[xw] = ta[xw] - tb_[xw]; v1[xw] = tc[xw] + tb_[xw]; }
+        } else {                                   // xh 2: t2 - t1, xh 3: t1 - t3      (ta = t1, tb_ = t2, tc = t3)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) { v0[xw] = tb_[xw] - ta[xw]; v1[xw] = ta[xw] - tc[xw]; }
+        }
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) asm volatile("" : "+v"(v0[xw]), "+v"(v1[xw]), "+v"(wf0[xw]), "+v"(wf1[xw]));
+    };
+#define RB_MFMA_S(XH, WF, V, S)                                                                       \
+    _Pragma("unroll") for (int xw = 0; xw < 4; ++xw) {                                                \
+        const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                       \
+        acc[XH][xw] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[xw][S], V[xw][S], FIRST && S == 0 ? z4_ : acc[XH][xw], 0, 0, 0); \
+    }
+#define RB_SB() __builtin_amdgcn_sched_barrier(0)
+    // M: the 32 MFMAs of half step HALF in eight groups of four; vm(k) = the vector-memory work issued behind group k
+    auto mfma_seg = [&](auto first_tag, auto half_tag, auto&& vm) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int HALF = decltype(half_tag)::value;
+#ifdef RB_ABL_NOMFMA
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) { acc[2 * HALF][xw] += wf0[xw] * v0[xw]; acc[2 * HALF + 1][xw] += wf1[xw] * v1[xw]; }
+        for (int k = 0; k < 8; ++k) vm(k);
+#else
+        RB_MFMA_S(2 * HALF, wf0, v0, 0)     RB_SB(); vm(0); RB_SB();
+        RB_MFMA_S(2 * HALF, wf0, v0, 1)     RB_SB(); vm(1); RB_SB();
+        RB_MFMA_S(2 * HALF, wf0, v0, 2)     RB_SB(); vm(2); RB_SB();
+        RB_MFMA_S(2 * HALF, wf0, v0, 3)     RB_SB(); vm(3); RB_SB();
+        RB_MFMA_S(2 * HALF + 1, wf1, v1, 0) RB_SB(); vm(4); RB_SB();
+        RB_MFMA_S(2 * HALF + 1, wf1, v1, 1) RB_SB(); vm(5); RB_SB();
+        RB_MFMA_S(2 * HALF + 1, wf1, v1, 2) RB_SB(); vm(6); RB_SB();
+        RB_MFMA_S(2 * HALF + 1, wf1, v1, 3) RB_SB(); vm(7); RB_SB();
+#endif
+    };
+#define RB_WAIT_L() do { RB_SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RB_SB(); } while (0)
+#define RB_WAIT_M() do { RB_SB(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RB_SB(); } while (0)
+#define RB_BAR() do { RB_SB(); asm volatile("s_barrier" ::: "memory"); RB_SB(); } while (0)
+
+    Cursor c0 = {0, 0, 0};
+    Cursor c1 = advance(c0);
+    Cursor c2 = advance(c1);
+    Geo geo = geo_of(0);
+    Item itA = item_of(0, 0), itB = item_of(0, 1);
+    Raw r;
+    // ---- prologue: brick of step 0 into buffer 0, weights of half step 0 (all waves) and B's share of half step 1, loads of item A of step 1
+    ring_fill_pp(0, 0, 0);
+    stage_issue(itA, 0, 0, r); stage_finish(itA, 0, brick, r);
+    stage_issue(itB, 0, 0, r); stage_finish(itB, 0, brick, r);
+    if (c1.round < rounds) {
+        if (c1.round != c0.round) itA = item_of(c1.round, 0);
+        stage_issue(itA, c1.xd, c1.cb, r);
+    }
+    if (grp == 1) ring_fill_pp(0, 0, 1);
+    RB_BARRIER();
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");       // B starts one slot late
+    RB_SB();
+
+    const char* const rs_lane = ring + ctl * 1024 + lane * 16;
+    int stepno = 0;
+    auto do_step = [&](auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const bool v1ok = c1.round < rounds, v2ok = c2.round < rounds;
+        // ---- L of half 0
+        RB_MARK(0);
+        if constexpr (FIRST) {
+            if (stepno > 0) {                      // the phase that ended with the previous step
+                phase_end(D2 ? 0 : (c0.xd + 3) & 3, geo);
+                if (D2 || c0.xd == 0) geo = geo_of(c0.round);
+            }
+        }
+        char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
+        const char* tb = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds;
+        load_ops(std::integral_constant<int, 0>{}, tb, rs_lane);
+        if (v1ok) stage_finish(itA, c1.xd, nb, r);                  // item A of step s+1 (loads issued during the previous M)
+        RB_WAIT_L();
+        RB_MARK(1);
+        RB_BAR();
+        // ---- M of half 0: A copies its units of (this step, half 1), B its units of (next step, half 0); loads of item B of step s+1
+        RB_MARK(2);
+        if (v1ok && c1.round != c0.round) itB = item_of(c1.round, 1);
+        mfma_seg(first_tag, std::integral_constant<int, 0>{}, [&](int k) __attribute__((always_inline)) {
+            if (k == 0) {
+                if (grp == 0) ring_fill_pp(c0.xd, c0.cb, 1);
+                else if (v1ok) ring_fill_pp(c1.xd, c1.cb, 0);
+            } else if (k <= 4) {
+                if (v1ok) stage_issue_w(itB, c1.xd, c1.cb, r, k - 1);
+            }
+        });
+        RB_MARK(3);
+        RB_WAIT_M();
+        RB_MARK(4);
+        RB_BAR();
+        // ---- L of half 1
+        RB_MARK(5);
+        load_ops(std::integral_constant<int, 1>{}, tb, rs_lane + 16384);
+        if (v1ok) stage_finish(itB, c1.xd, nb, r);
+        RB_WAIT_L();
+        RB_MARK(6);
+        RB_BAR();
+        // ---- M of half 1: A copies (next step, half 0), B (next step, half 1); loads of item A of step s+2
+        RB_MARK(7);
+        if (v2ok && c2.round != c1.round) itA = item_of(c2.round, 0);
+        mfma_seg(first_tag, std::integral_constant<int, 1>{}, [&](int k) __attribute__((always_inline)) {
+            if (k == 0) {
+                if (v1ok) ring_fill_pp(c1.xd, c1.cb, grp);
+            } else if (k <= 4) {
+                if (v2ok) stage_issue_w(itA, c2.xd, c2.cb, r, k - 1);
+            }
+        });
+        c0 = c1; c1 = c2; c2 = advance(c2);
+        ++stepno;
+        RB_MARK(8);
+        RB_WAIT_M();
+        RB_MARK(9);
+        RB_BAR();
+        RB_MARK(10);
+        RB_FLUSH_MARKS();
+    };
+#pragma unroll 1
+    for (int ph = 0; ph < rounds * (D2 ? 1 : 4); ++ph) {
+        do_step(std::true_type{});
+#pragma unroll 1
+        for (int c = 1; c < p.cb_in; ++c) do_step(std::false_type{});
+    }
+    phase_end(D2 ? 0 : 3, geo);                    // the last phase of the last round
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");       // A's count of barriers = B's
+#undef RB_MFMA_S
+#undef RB_MFMA_ROW
+#else
+
     struct Cursor { int round, xd, cb; };
     auto advance = [&](Cursor c) __attribute__((always_inline)) {
         if (++c.cb == p.cb_in) { c.cb = 0; if (D2 || ++c.xd == 4) { c.xd = 0; ++c.round; } }
@@ -512,6 +719,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         for (int c = 1; c < p.cb_in; ++c) do_step(std::false_type{});
     }
 #undef RB_MFMA_ROW
+#endif
 }
 
 template <int TW>
