@@ -40,8 +40,18 @@ for wv in range(2):
     f = d[0::cb].mean(axis=0); o = d[1::cb].mean(axis=0) if cb > 1 else f * 0
     fmt = lambda v: " ".join(f"{n}={x:5.0f}" for n, x in zip(names, v))
     print(f" wave {wv*4}: step {step.mean():6.0f} | PE steps: {fmt(f)} | others: {fmt(o)}")
+    m0 = t[wv, :, [2, 11, 12, 13, 14, 15, 3]].T
+    dm = np.diff(m0, axis=1) % (1 << 32)
+    print("   inside M0: MFMA 0-3 (fma pieces) | 4-9 (w butterfly + LDS writes) | 10-13 (ring copies) | 14-21 (4 loads) | 22-29 (4 loads) | 30-31:", np.round(dm.mean(axis=0)).astype(int).tolist())
 if os.environ.get("RAW"):
     base = t[0, 0, 0]
     for s_ in range(int(os.environ["RAW"])):
         for wv in range(2):
             print(f"step {s_} wave {wv*4}: " + " ".join(f"{int((t[wv, s_, k] - base) % (1 << 32)):6d}" for k in range(11)))
+per = 4 * cb
+for wv in range(2):
+    d = np.diff(t[wv, :, :11], axis=1) % (1 << 32)
+    # stepno of row k = 8 + k
+    for ph in range(per):
+        rows = [k for k in range(64) if (8 + k) % per == ph]
+        print(f"   wave {wv*4} step%{per}={ph}: L0={d[rows, 0].mean():6.0f} M0={d[rows, 2].mean():6.0f} L1={d[rows, 5].mean():6.0f} M1={d[rows, 7].mean():6.0f}")
