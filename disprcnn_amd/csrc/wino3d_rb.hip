@@ -1,31 +1,24 @@
 // wino3d_rb.hip -- stride-1 3x3x3 convolution (+BN, +residual, +ReLU) as Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores,
-// TWO waves per SIMD running one barrier interval apart ("ping-pong"), input staged per BLOCK as depth- and w-transformed ROWS
-// ("row brick") in LDS (gfx950 / CDNA4; row brick: round 3, ping-pong: round 4).
+// TWO waves per SIMD, input staged per BLOCK as depth- and w-transformed ROWS ("row brick") in LDS (gfx950 / CDNA4, round 3).
 //
 //   reference: dres0/dres1, classifN[0], hourglass conv2 (stackhourglass.py:63-88, :14-20)
 //
+// wino3d.hip (rounds 1-2) gives every lane its tile's 4x4x4 patch: 32 float4 global loads per step into 128 landing registers,
+// every input voxel fetched ~8x per CU (5-9x from L2), 450 registers -> ONE wave per SIMD, so every barrier, operand read and
+// phase end is exposed (MFMA busy 39 %).  Here
 //   * a block of 8 waves (2 per SIMD, <= 256 registers each) owns 64 consecutive tiles: waves (tg, ct) -- tile group tg of 16
-//     tiles (the N dimension of the 16x16x4 MFMA) x cout tile ct of 16 couts; waves w and w + 4 share a SIMD and a tile group;
+//     tiles (the N dimension of the 16x16x4 MFMA) x cout tile ct of 16 couts; the two waves of a SIMD share their tile group;
 //   * per step (depth frequency xd, channel block cb) the block stages the input ROWS its tiles touch ONCE: work item
 //     (row slot, tile column wt, channel quad g) loads the row's four columns 2wt..2wt+3 of the two slices of xd (8 float4),
 //     applies the depth butterfly (slice a +/- slice b) and the w butterfly and writes the four w-frequencies to LDS --
 //     rows are shared by the two tile rows that overlap them, so these two butterflies run once per ROW instead of once
-//     per tile, and each input voxel is loaded ~2.3x per CU and step instead of 8x;
-//   * a step is two half steps of 32 MFMAs per wave: half hf covers the w-frequencies xw = 2hf, 2hf+1 of all four h-frequencies.
-//     Its operands are read from LDS in an L segment (8 transformed-row reads + h butterfly, 8 weight reads from a two-slab ring
-//     the block fills by LDS-DMA), its MFMAs run in the following M segment;
-//   * PING-PONG: waves 0-3 (group A) and their SIMD partners 4-7 (group B) execute the same stream, B one barrier interval
-//     ("slot") behind A, so in every slot each SIMD has one wave in M (matrix pipe) and one in L (LDS pipe + VALU):
-//         slot   2i    2i+1   2i+2   2i+3
-//         A      L_i   M_i    L_i+1  M_i+1
-//         B      M_i-1 L_i    M_i    L_i+1
-//     Everything that is not an operand read rides in the issue slots between the MFMAs of an M segment: the ring's LDS-DMA, the
-//     transform + LDS write of the staging item whose loads were issued one M earlier (two slots of flight), the next item's loads;
-//   * the phase end (in-plane inverse 4x4 -> 2x2 of the 16 accumulators of a depth frequency) is split over the two L segments of
-//     the next phase's first step: columns xw 0,1 before the first M overwrites them, columns 2,3 + the depth sums before the second;
-//     the partial depth inverses are two running sums in registers.
+//     per tile (2x and 4x fewer), and each input voxel is loaded ~2.3x per CU instead of 8x;
+//   * a wave reads its tiles' four transformed rows from LDS (12 + 4 ds_read_b128 per step), applies the h butterfly (64 VALU)
+//     and runs 64 MFMAs against the transformed weights, which the block shares through a two-slab LDS ring filled by LDS-DMA
+//     (no registers) half a step ahead;
+//   * the partial depth inverses are two running sums in registers (no LDS parking).
 // The arithmetic and its order are exactly wino3d.hip's: results are BIT-IDENTICAL to drc_conv3d_k3_wino_fwd.
-// LDS: ring 2 x 16 KB + brick 2 x (NS + 1) slots x (256 * TW) B; NS = 16 for 28x28 maps (151 KB), 28 for 14x14 maps (134 KB).
+// LDS: ring 2 x 16 KB + brick 2 x NS slots x (256 * TW) B; NS = 16 for 28x28 maps (144 KB), 28 for 14x14 maps (130 KB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,25 +27,45 @@
 #include "../../include/disprcnn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// a - b as two packed instructions: hipcc lowers a float4 subtraction to four v_sub_f32, but an fma with an (opaque) -1 becomes two
+// v_pk_fma_f32.  The fp32 MFMA shares the SIMD's vector ALUs with the ordinary vector instructions -- measured: every vector instruction
+// of either wave costs ~8 cycles of matrix time, in the gaps between MFMAs too -- so the instruction COUNT is what matters.  The result
+// is bit-identical: fma(b, -1, a) rounds a - b once.  (An inline-asm v_pk_add_f32 with neg modifiers is correct as well but invisible to
+// hipcc's hazard recognizer: an MFMA reading its result one instruction later got stale data.)
+__device__ __forceinline__ f32x4 rb_sub(const f32x4 a, const f32x4 b, const f32x4 neg1) {
+    return __builtin_elementwise_fma(b, neg1, a);
+}
 
 #define RB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define RB_WAVES 8
 #define RB_RING_BYTES 32768
+#ifndef RB_PAIR
+#define RB_PAIR 0              // 1: staging items of one column pair, the neighbour's pair fetched with ds_bpermute (half the loads;
+                               //    bit-identical, measured 3-6 % slower: the exchange puts an LDS round trip into every item)
+#endif
+#ifdef RB_ABL_NOBARRIER
+#define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 
 #ifdef RB_TRACE
-// development only: s_memtime stamps of block 8, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps.  The stamps of a
-// step are collected in one VGPR (lane k = mark k) and stored once per step, so that no trace store sits in front of the kernel's own waits.
+// development only: s_memtime stamps of block RB_TRACE_BLOCK, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps
 __device__ unsigned long long rb_trace_buf[2][64][16];
-#define RB_MARK(k) do { if (rb_traced) { const unsigned t_ = __builtin_amdgcn_readfirstlane((unsigned)__builtin_readcyclecounter()); \
-                             asm volatile("v_writelane_b32 %0, %1, " #k : "+v"(rb_marks) : "s"(t_)); } } while (0)
-#define RB_FLUSH_MARKS() do { if (rb_traced && stepno > 8 && stepno <= 72 && lane < 16) rb_trace_buf[wave >> 2][stepno - 9][lane] = rb_marks; } while (0)
+#define RB_MARK(k)                                                                                              \
+    do {                                                                                                        \
+        if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && stepno >= 8 && stepno < 72)                      \
+            rb_trace_buf[wave >> 2][stepno - 8][k] = __builtin_readcyclecounter();                              \
+    } while (0)
 extern "C" int drc_rb_trace_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_trace_buf), sizeof(rb_trace_buf));
 }
 #else
 #define RB_MARK(k)
-#define RB_FLUSH_MARKS()
 #endif
 
 namespace {
@@ -73,17 +86,16 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     constexpr int GS = 16 * TW;                    // bytes per channel quad
     char* const ring = smem;                       // [slab 2][unit = i * 2 + ct_local : 16][g 4][j 16] float4
     char* const brick = smem + RB_RING_BYTES;      // [buffer 2][NS][SB]
-    const unsigned buf_bytes = (unsigned)(NS + 1) * SB;     // NS row slots + one scratch slot (item_of)
+    const unsigned buf_bytes = (unsigned)NS * SB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
     const int g = lane >> 4;
     const int tg = wave & 3;                       // tile group of the chunk
     const int ctl = wave >> 2;                     // cout tile within the block's 32 couts (waves w and w+4 share a SIMD)
-#ifdef RB_TRACE
-    const bool rb_traced = blockIdx.x == 8 && (wave & 3) == 0;
-    unsigned rb_marks = 0;
-#endif
+    f32x4 neg1 = {-1.f, -1.f, -1.f, -1.f};
+    asm volatile("" : "+v"(neg1));               // opaque: fma(b, -1, a) must stay an fma (rb_sub)
+#define RB_SUB(a, b) rb_sub(a, b, neg1)
 
     const drc_tap_class cls = p.cls[0];
     // Maps wider than 2 TW columns (Config B's 56-wide volume at TW = 14) are walked as WS side-by-side strips of TW tile columns: a
@@ -113,7 +125,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 
     // ---- geometry of a round.  Lane: its tile, the LDS offset of its rows inside a brick buffer.  Thread: its (at most two)
     // staging items (row slot, tile column, channel quad): global byte offset of the row's first column, LDS byte offset.
-    struct Geo { int tile; bool valid; unsigned lds; };        // the lane's tile of the round (clamped), the LDS offset of its first row
+    struct Geo { int n, dt, ht, wt; bool valid; unsigned lds; };
     auto geo_of = [&](int round) __attribute__((always_inline)) {
         Geo q;
         const int chunk = round * nbk + pos;
@@ -121,27 +133,29 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         int tile = chunk * 64 + tg * 16 + j;
         q.valid = tile < tiles;
         if (tile >= tiles) tile = tiles - 1;
-        q.tile = tile;
         const int R0 = t0 / TW, R = tile / TW;
+        q.wt = tile - R * TW;
+        int t = R;
+        q.ht = t % TH; t /= TH;
+        q.wt += (t % WS) * TW; t /= WS;             // the tile's column in the whole map
+        q.dt = t % TD;
+        q.n = t / TD;
         int slot = 2 * (R - R0) + 2 * (R / TH - R0 / TH);
         slot = slot > NS - 4 ? NS - 4 : slot;
         q.lds = (unsigned)(slot * SB + g * GS + (tile - R * TW) * 16);
         return q;
     };
-    // tile -> (n, depth tile, tile row, tile column in the whole map); only the epilogue needs them (once per round)
-    auto tile_coords = [&](int tile, int& n, int& dt, int& ht, int& wt) __attribute__((always_inline)) {
-        const int R = tile / TW;
-        wt = tile - R * TW;
-        int t = R;
-        ht = t % TH; t /= TH;
-        wt += (t % WS) * TW; t /= WS;
-        dt = t % TD;
-        n = t / TD;
-    };
     // A staging item = (row slot, tile column wt, channel quad gq), thread t takes items t and t + 512: it loads the row's columns
     // 2wt..2wt+3 in the two slices of the step (8 float4; lanes of a quad group share a 64-byte line), applies the depth butterfly and the
-    // w butterfly and writes the four w-frequencies of tile column wt to LDS.
-    struct Item { unsigned goff, loff; bool valid; int x0, d0; };   // x0, d0 (CV): volume column / slice of the patch origin
+    // w butterfly and writes the four w-frequencies of tile column wt to LDS.  (Tried and dropped, s_memtime-traced on the GPU: items of
+    // one column PAIR with the neighbour's pair fetched by ds_bpermute / DPP -- half the loads, the same time; loads issued a half step
+    // ahead or right before the barriers -- the wait is the LDS-DMA ring fill, not the loads; L2-warming touches -- slower: every extra
+    // vector-memory instruction costs its issue slot behind the other seven waves' requests.)
+    constexpr bool kPair = RB_PAIR != 0;
+    constexpr int kCols = kPair ? 2 : 4;           // columns an item loads
+    constexpr int PPS = TW + 1 <= 8 ? 8 : 16;      // pair mode: column pairs per slot (padded), slots per wave item
+    constexpr int SPW = 16 / PPS;
+    struct Item { unsigned goff, loff; bool valid, live; int x0, d0; };   // x0, d0 (CV): volume column / slice of the patch origin; live: wave-uniform
     auto item_of = [&](int round, int k) __attribute__((always_inline)) {
         Item it;
         const int chunk = round * nbk + pos;
@@ -150,11 +164,24 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         const int R0 = t0 / TW, R1 = t1 / TW;
         int nslots = 2 * (R1 - R0) + 2 * (R1 / TH - R0 / TH) + 4;
         nslots = nslots > NS ? NS : nslots;
-        const int q = (int)threadIdx.x + 512 * k;
-        it.valid = q < nslots * TW * 4;
-        const int s0 = q / (4 * TW);
-        const int rem = q - s0 * (4 * TW);
-        const int wt = rem >> 2, gq = rem & 3;
+        int s0, wt, gq;
+        if constexpr (kPair) {
+            // a wave item (wave + 8k) = one slot of 16 column pairs (TW = 14) or two slots of 8 (TW = 7); lane = pair * 4 + quad, so lane + 4
+            // is the next pair of the same slot; pair TW only feeds its neighbour; every lane of a live wave item loads
+            s0 = (wave + 8 * k) * SPW + (SPW == 2 ? lane >> 5 : 0);
+            const int cp = (lane >> 2) & (PPS - 1);
+            gq = lane & 3;
+            it.valid = s0 < nslots && cp < TW;
+            it.live = __builtin_amdgcn_readfirstlane((wave + 8 * k) * SPW < nslots);
+            wt = cp < TW ? cp : TW;
+        } else {
+            const int q = (int)threadIdx.x + 512 * k;
+            it.valid = q < nslots * TW * 4;
+            it.live = true;
+            s0 = q / (4 * TW);
+            const int rem = q - s0 * (4 * TW);
+            wt = rem >> 2; gq = rem & 3;
+        }
         // slot -> (tile row relative to R0, patch row h): two slots per tile row plus two per slab touched
         int s = s0 < nslots ? s0 : nslots - 1;
         int left = TH - R0 % TH, base = 0, rel = 0, h = 0;
@@ -184,273 +211,191 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                                   (int64_t)(2 * wg + cls.dw0) * 16 + gq * 4) * 4);
             it.x0 = it.d0 = 0;
         }
-        // a lane without an item transforms a (clamped, in-bounds) row like the others and writes it to the scratch slot NS of the
-        // brick buffer: no exec-mask branch inside the M segments, which stay one basic block each
-        it.loff = (unsigned)((it.valid ? s0 : NS) * SB + gq * GS + wt * 16);
+        it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + (wt < TW ? wt : 0) * 16);
         return it;
     };
-    struct Raw { f32x4 a[4], b[4]; };
+    struct Raw { f32x4 a[kCols], b[kCols]; };
     // (all uniform offsets are 32-bit: the launcher checks N * x_n_stride * 4 < 2^32 and the packed weights < 2^31 floats)
     const unsigned xcb4 = (unsigned)p.x_cb_stride * 4u, xd4 = (unsigned)p.x_d_stride * 4u;
-    // one load of an item: column w of slice a (ab = 0) or slice b (ab = 1).  Issued by EVERY lane -- the offsets of a lane without an item
-    // are those of a clamped slot, in bounds -- so that an M segment always ends with exactly eight vector-memory instructions (RB_WAIT_M).
-    auto stage_issue_1 = [&](const Item& it, int xd, int cb, Raw& r, int w, int ab) __attribute__((always_inline)) {
-#if defined(RB_ABL_NOSTAGE) || defined(RB_ABL_NOISS)
+    auto stage_issue = [&](const Item& it, int xd, int cb, Raw& r) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOSTAGE
         return;
 #endif
+        if (kPair ? !it.live : !it.valid) return;
         if constexpr (CV) {
             const bool right = cb >= cv.cbi;                                      // wave-uniform
             const char* base = (const char*)((right ? cv.right : cv.left) + (int64_t)(right ? cb - cv.cbi : cb) * cv.cb_stride);
-            const int d = it.d0 + (ab == 0 ? slice_a(xd) : slice_b(xd));
-            const bool ind = (unsigned)d < (unsigned)p.OD;
-            const int sh = right ? cv.lo4 + d : 0;                              // the right map is read at x - i
-            const int x = it.x0 + w;
-            const bool ok = ind && (unsigned)x < (unsigned)cv.Wp && (unsigned)(x - cv.lo4 - d) < (unsigned)cv.Wp;
-            const unsigned off = it.goff + (ok ? (unsigned)((x - sh + cv.pad) * 64) : 0u);
-            (ab == 0 ? r.a[w] : r.b[w]) = *(const f32x4*)(base + off);
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab) {
+                const int d = it.d0 + (ab == 0 ? slice_a(xd) : slice_b(xd));
+                const bool ind = (unsigned)d < (unsigned)p.OD;
+                const int sh = right ? cv.lo4 + d : 0;                              // the right map is read at x - i
+#pragma unroll
+                for (int w = 0; w < kCols; ++w) {
+                    const int x = it.x0 + w;
+                    const bool ok = ind && (unsigned)x < (unsigned)cv.Wp && (unsigned)(x - cv.lo4 - d) < (unsigned)cv.Wp;
+                    const unsigned off = it.goff + (ok ? (unsigned)((x - sh + cv.pad) * 64) : 0u);
+                    (ab == 0 ? r.a[w] : r.b[w]) = *(const f32x4*)(base + off);
+                }
+            }
         } else {
-            const char* sl = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)(ab == 0 || D2 ? slice_a(xd) : slice_b(xd)) * xd4);
-            (ab == 0 ? r.a[w] : r.b[w]) = *(const f32x4*)(sl + w * 64 + it.goff);      // (2D: one slice; its second load keeps the count at eight)
+            const char* sa = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_a(xd) * xd4);
+            const char* sb = (const char*)p.x + ((unsigned)cb * xcb4 + (unsigned)slice_b(xd) * xd4);
+#pragma unroll
+            for (int w = 0; w < kCols; ++w) {
+                r.a[w] = *(const f32x4*)(sa + w * 64 + it.goff);
+                if constexpr (!D2) r.b[w] = *(const f32x4*)(sb + w * 64 + it.goff);
+            }
         }
     };
-    auto stage_issue_w = [&](const Item& it, int xd, int cb, Raw& r, int w) __attribute__((always_inline)) {
-        stage_issue_1(it, xd, cb, r, w, 0);
-        stage_issue_1(it, xd, cb, r, w, 1);
-    };
-    // depth butterfly, w butterfly, four w-frequencies into brick buffer `bb` -- in nine pieces (pc 0..8) so that an M segment can spread
-    // them over the gaps between its MFMAs (dd = the depth-butterflied columns, fdst = the item's LDS address; both live across the pieces)
-    f32x4 dd[4];
-    char* fdst = nullptr;
-    auto stage_finish_pc = [&](int pc, const Item& it, int xd, char* bb, const Raw& r) __attribute__((always_inline)) {
-#if defined(RB_ABL_NOSTAGE) || defined(RB_ABL_NOFIN)
+    // depth butterfly, w butterfly, four w-frequencies into brick buffer `bb`
+    auto stage_finish = [&](const Item& it, int xd, char* bb, const Raw& r) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOSTAGE
         return;
 #endif
-        if (pc == 0) {
-            fdst = bb + it.loff;
-        } else if (pc <= 4) {
-            const int w = pc - 1;
-            if constexpr (D2) {
-                dd[w] = r.a[w];
-            } else {
-                const float sgn = xd == 1 ? 1.f : -1.f;
-                dd[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); dd[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
-                dd[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); dd[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
-            }
-        } else if (pc == 5) {
-            *(f32x4*)(fdst + 0 * XWS) = dd[0] - dd[2];
-        } else if (pc == 6) {
-            *(f32x4*)(fdst + 1 * XWS) = dd[1] + dd[2];
-        } else if (pc == 7) {
-            *(f32x4*)(fdst + 2 * XWS) = dd[2] - dd[1];
-        } else if (pc == 8) {
-            *(f32x4*)(fdst + 3 * XWS) = dd[1] - dd[3];
-        }
-    };
-    auto stage_finish = [&](const Item& it, int xd, char* bb, const Raw& r) __attribute__((always_inline)) {
+        if (kPair ? !it.live : !it.valid) return;
+        const float sgn = xd == 1 ? 1.f : -1.f;
+        f32x4 d[4];
 #pragma unroll
-        for (int pc = 0; pc < 9; ++pc) stage_finish_pc(pc, it, xd, bb, r);
+        for (int w = 0; w < kCols; ++w) {
+            if constexpr (D2) {
+                d[w] = r.a[w];
+            } else {
+                d[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); d[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
+                d[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); d[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
+            }
+        }
+        if constexpr (kPair) {          // the next pair's columns from lane + 4 (scalars by value: __builtin_bit_cast on a vector-ELEMENT
+            auto nl = [&](float v) __attribute__((always_inline)) {            // lvalue reads element 0 with this hipcc)
+                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 4) & 63) * 4, __builtin_bit_cast(int, v)));
+            };
+#pragma unroll
+            for (int w = 0; w < 2; ++w) { d[2 + w].x = nl(d[w].x); d[2 + w].y = nl(d[w].y); d[2 + w].z = nl(d[w].z); d[2 + w].w = nl(d[w].w); }
+            if (!it.valid) return;
+        }
+        char* dst = bb + it.loff;
+        *(f32x4*)(dst + 0 * XWS) = RB_SUB(d[0], d[2]);
+        *(f32x4*)(dst + 1 * XWS) = d[1] + d[2];
+        *(f32x4*)(dst + 2 * XWS) = RB_SUB(d[2], d[1]);
+        *(f32x4*)(dst + 3 * XWS) = RB_SUB(d[1], d[3]);
     };
 
-    // ---- weight ring: half step (xd, cb, hf) uses the eight frequency points (xh, xw = 2 hf + xwl) of block cb for the block's two cout
-    // tiles = 16 units of 1 KiB [g][j] float4 in the rb packing (drc_pack_weights_wino_rb: [xi = (xd*4 + xh)*4 + xw][cb][cout tile]);
-    // unit u = (xh * 2 + xwl) * 2 + cout tile; wave w copies units w and w + 8 by LDS-DMA (lane l -> byte l*16 of the unit): xh = w >> 2
-    // (+ 2 for the second unit), xwl = (w >> 1) & 1, cout tile w & 1; the per-wave part of the source offset is constant
+    // ---- weight ring: half step (xd, cb, hf) uses frequency points xd*16 + hf*8 + 0..7 of block cb for the block's two cout
+    // tiles = 16 units of 1 KiB [g][j] float4 in the rb packing (drc_pack_weights_wino_rb); wave w copies units w and w + 8 by
+    // LDS-DMA (lane l -> byte l*16 of the unit)
+    // unit u = wave + 8k: frequency point i = u >> 1 (k = 1: + 4), cout tile u & 1; the per-wave part of the source offset is constant
+    const char* const wlane = (const char*)(p.w + (int64_t)ct0 * 256 + lane * 4) + (unsigned)(((wave >> 1) * p.cb_in * n_ct + (wave & 1)) * 1024);
     const unsigned wxi4 = (unsigned)(p.cb_in * n_ct) * 1024u;         // bytes per frequency point
     const unsigned wcb4 = (unsigned)n_ct * 1024u;                     // bytes per channel block
-    const char* const wlane = (const char*)(p.w + (int64_t)ct0 * 256 + lane * 4) + ((unsigned)((wave >> 2) * 4 + ((wave >> 1) & 1)) * wxi4 + (unsigned)(wave & 1) * 1024u);
-    auto ring_fill = [&](int xd, int cb, int hf) __attribute__((always_inline)) {
+    auto ring_fill = [&](int slab, int xd, int cb, int hf) __attribute__((always_inline)) {
 #ifdef RB_ABL_NOFILL
         return;
 #endif
-        const char* src = wlane + ((unsigned)(xd * 16 + hf * 2) * wxi4 + (unsigned)cb * wcb4);
-        char* dst = ring + hf * 16384 + wave * 1024;
+        const char* src = wlane + ((unsigned)(xd * 16 + hf * 8) * wxi4 + (unsigned)cb * wcb4);
+        char* dst = ring + slab * 16384 + wave * 1024;
         __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src), RB_LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src + 8 * wxi4), RB_LDS_PTR(dst + 8192), 16, 0, 0);
-    };
-    // in the pipeline the four waves of group A copy all 16 units of the NEXT half step from their L segment (four each: unit w + 4m =
-    // (xh = m, xwl = w >> 1, cout tile w & 1)); an L segment has issue slots to spare, an M segment does not
-    const char* const wlaneA = (const char*)(p.w + (int64_t)ct0 * 256 + lane * 4) + ((unsigned)((wave >> 1) & 1) * wxi4 + (unsigned)(wave & 1) * 1024u);
-    auto ring_fill_A = [&](int xd, int cb, int hf) __attribute__((always_inline)) {
-#ifdef RB_ABL_NOFILL
-        return;
-#endif
-        const char* src = wlaneA + ((unsigned)(xd * 16 + hf * 2) * wxi4 + (unsigned)cb * wcb4);
-        char* dst = ring + hf * 16384 + (wave & 3) * 1024;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src + (unsigned)(4 * m) * wxi4), RB_LDS_PTR(dst + m * 4096), 16, 0, 0);
-    };
-    auto ring_fill_1 = [&](int xd, int cb, int hf, int second) __attribute__((always_inline)) {      // one of the two copies
-#ifdef RB_ABL_NOFILL
-        return;
-#endif
-        const char* src = wlane + ((unsigned)(xd * 16 + hf * 2 + second * 8) * wxi4 + (unsigned)cb * wcb4);
-        char* dst = ring + hf * 16384 + wave * 1024 + second * 8192;
-        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src), RB_LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src + 4 * wxi4), RB_LDS_PTR(dst + 8192), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];                               // [xh][xw]
+    f32x4 acc[4][4];
     f32x4 o0[4], o1[4];                            // running depth sums of the in-plane inverses: [oh * 2 + ow]
-    f32x4 q0[2], q1[2];                            // phase end, part 1: q0[oh] = hh[oh][0] + hh[oh][1], q1[oh] = hh[oh][1]
-    f32x4 wf[4][2], v[4][2];                       // the operands of the coming M segment: [xh][xwl]
-#if defined(RB_ABL_EXTRA_M) || defined(RB_ABL_EXTRA_L)
-    float rb_dummy = (float)lane;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    float rb_d4[8] = {(float)lane, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f};
-    f32x2 rb_p4[8];
-    for (int i_ = 0; i_ < 8; ++i_) { rb_p4[i_].x = (float)(lane + i_); rb_p4[i_].y = 1.f; }
-#ifndef RB_ABL_KIND
-#define RB_ABL_KIND 0
-#endif
-#if RB_ABL_KIND == 0
-#define RB_DUMMY_OP(e) asm volatile("v_add_f32 %0, %0, %0" : "+v"(rb_dummy))
-#elif RB_ABL_KIND == 1
-#define RB_DUMMY_OP(e) asm volatile("v_add_f32 %0, %0, %0" : "+v"(rb_d4[(e) & 7]))
-#else
-#define RB_DUMMY_OP(e) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(rb_p4[(e) & 7]))
-#endif
-#endif
-
-    // L: operand reads + h butterflies of half step HALF of the step whose brick rows start at tb; rs = the half step's ring slab +
-    // the wave's cout tile + lane
-    auto load_ops = [&](auto half_tag, const char* tb, const char* rs) __attribute__((always_inline)) {
+#define RB_MFMA_ROW(XH, WF, V)                                                                        \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                     \
+        _Pragma("unroll") for (int xw = 0; xw < 4; ++xw) {                                            \
+            const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                   \
+            acc[XH][xw] = __builtin_amdgcn_mfma_f32_16x16x4f32(WF[xw][s], V[xw][s], FIRST && s == 0 ? z4_ : acc[XH][xw], 0, 0, 0); \
+        }
+    // the MFMAs of one half step: frequency rows xh = 2*HALF, 2*HALF+1; tb = the lane's rows in the step's brick buffer,
+    // rs = the half step's ring slab + the wave's cout tile + lane
+    auto consume = [&](auto first_tag, auto half_tag, const char* tb, const char* rs, auto&& between) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int HALF = decltype(half_tag)::value;
-        f32x4 t[4][2];
+        f32x4 wf0[4], wf1[4], ta[4], tb_[4], tc[4], v0[4], v1[4];
 #ifdef RB_ABL_NOLDSR
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int xwl = 0; xwl < 2; ++xwl) {
-                const f32x4 c_ = {(float)lane, (float)(lane + xwl), 1.f, (float)h};
-                wf[h][xwl] = c_; t[h][xwl] = c_ * 3.f;
-                asm volatile("" : "+v"(wf[h][xwl]), "+v"(t[h][xwl]));
-            }
+        for (int xw = 0; xw < 4; ++xw) {
+            const f32x4 c_ = {(float)lane, (float)(lane + xw), 1.f, 2.f};
+            wf0[xw] = c_; wf1[xw] = c_ * 2.f; ta[xw] = c_ * 3.f; tb_[xw] = c_ * 4.f; tc[xw] = c_ * 5.f;
+            asm volatile("" : "+v"(wf0[xw]), "+v"(wf1[xw]), "+v"(ta[xw]), "+v"(tb_[xw]), "+v"(tc[xw]));
+        }
         if (false)
 #endif
         {
+        // first row's operands: weights of frequency row 2*HALF, the two transformed rows its h butterfly combines
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
+        for (int xw = 0; xw < 4; ++xw) wf0[xw] = *(const f32x4*)(rs + (0 * 4 + xw) * 2048);
 #pragma unroll
-            for (int xwl = 0; xwl < 2; ++xwl) t[h][xwl] = *(const f32x4*)(tb + h * SB + (2 * HALF + xwl) * XWS);
+        for (int xw = 0; xw < 4; ++xw) ta[xw] = *(const f32x4*)(tb + (HALF == 0 ? 0 : 1) * SB + xw * XWS);
 #pragma unroll
-        for (int xh = 0; xh < 4; ++xh)
-#pragma unroll
-            for (int xwl = 0; xwl < 2; ++xwl) wf[xh][xwl] = *(const f32x4*)(rs + (xh * 2 + xwl) * 2048);
+        for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb + 2 * SB + xw * XWS);
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef RB_ABL_EXTRA_L
+        // the staging loads of this half step (8 vector-memory instructions, ~100 issue cycles each behind the other waves' requests) are
+        // issued while the LDS reads above are in flight.  (SIMD partners issuing theirs between their two MFMA rows instead, so that one
+        // wave's load issue sits beside the other's MFMAs: 3 % slower.)
+        between();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF == 0) {                 // xh 0: t0 - t2      (ta = t0, tb_ = t2)
 #pragma unroll
-        for (int e_ = 0; e_ < RB_ABL_EXTRA_L; ++e_) RB_DUMMY_OP(e_);
-#endif
+            for (int xw = 0; xw < 4; ++xw) v0[xw] = RB_SUB(ta[xw], tb_[xw]);
+        } else {                                   // xh 2: t2 - t1      (ta = t1, tb_ = t2)
 #pragma unroll
-        for (int xwl = 0; xwl < 2; ++xwl) {        // h butterfly: t0 - t2, t1 + t2, t2 - t1, t1 - t3
-            v[0][xwl] = t[0][xwl] - t[2][xwl];
-            v[1][xwl] = t[1][xwl] + t[2][xwl];
-            v[2][xwl] = t[2][xwl] - t[1][xwl];
-            v[3][xwl] = t[1][xwl] - t[3][xwl];
+            for (int xw = 0; xw < 4; ++xw) v0[xw] = RB_SUB(tb_[xw], ta[xw]);
         }
 #pragma unroll
-        for (int xh = 0; xh < 4; ++xh)
+        for (int xw = 0; xw < 4; ++xw) asm volatile("" : "+v"(v0[xw]));
+#ifdef RB_ABL_NOLDSR
+        if (false)
+#endif
+        {
+        // second row's operands, requested before the first row's MFMAs so that they arrive in their shadow
 #pragma unroll
-            for (int xwl = 0; xwl < 2; ++xwl) asm volatile("" : "+v"(v[xh][xwl]), "+v"(wf[xh][xwl]));
-    };
-#define RB_SB() __builtin_amdgcn_sched_barrier(0)
-    // M: the 32 MFMAs of half step HALF; fill(i) = the few instructions that ride in the gap behind MFMA i (an MFMA occupies the matrix pipe
-    // for 32 cycles, the wave can issue about five other instructions meanwhile -- a longer filler delays the next MFMA)
-    auto mfma_seg = [&](auto first_tag, auto half_tag, auto&& fill) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr int HALF = decltype(half_tag)::value;
+        for (int xw = 0; xw < 4; ++xw) tc[xw] = *(const f32x4*)(tb + (HALF == 0 ? 1 : 3) * SB + xw * XWS);
 #pragma unroll
-        for (int S = 0; S < 4; ++S)
-#pragma unroll
-            for (int xwl = 0; xwl < 2; ++xwl)
-#pragma unroll
-                for (int xh = 0; xh < 4; ++xh) {
+        for (int xw = 0; xw < 4; ++xw) wf1[xw] = *(const f32x4*)(rs + (1 * 4 + xw) * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef RB_ABL_NOMFMA
-                    acc[xh][2 * HALF + xwl] += wf[xh][xwl] * v[xh][xwl];
-#else
-                    const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};
-                    acc[xh][2 * HALF + xwl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[xh][xwl][S], v[xh][xwl][S], FIRST && S == 0 ? z4_ : acc[xh][2 * HALF + xwl], 0, 0, 0);
-#endif
-                    RB_SB(); fill((S * 2 + xwl) * 4 + xh);
-#ifdef RB_ABL_EXTRA_M
 #pragma unroll
-                    for (int e_ = 0; e_ < RB_ABL_EXTRA_M; ++e_) RB_DUMMY_OP(e_);
-#endif
-                    RB_SB();
-                }
-    };
-    // end of L: the operands have arrived.  End of M: the brick writes of this segment are done (lgkmcnt) and every vector-memory
-    // instruction but the youngest eight -- the item loads, which every M issues last -- has completed, i.e. the ring copies have landed.
-#define RB_WAIT_L() do { RB_SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RB_SB(); } while (0)
-#if defined(RB_ABL_NOSTAGE) || defined(RB_ABL_NOISS)
-#define RB_WAIT_M() do { RB_SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); RB_SB(); } while (0)
+        for (int xw = 0; xw < 4; ++xw) acc[2 * HALF][xw] += wf0[xw] * v0[xw];
 #else
-#define RB_WAIT_M() do { RB_SB(); asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); RB_SB(); } while (0)
+        RB_MFMA_ROW(2 * HALF, wf0, v0)
 #endif
-#define RB_BAR() do { RB_SB(); asm volatile("s_barrier" ::: "memory"); RB_SB(); } while (0)
-#ifndef RB_PRIO_M
-#define RB_PRIO_M 0
-#endif
-#ifndef RB_PRIO_L
-#define RB_PRIO_L 0
-#endif
-#define RB_STR2(x) #x
-#define RB_STR(x) RB_STR2(x)
-#ifndef RB_SKEW
-#define RB_SKEW 0
-#endif
-#if RB_SKEW == 1
-// the four M waves of a CU (one per SIMD) leave the barrier together and would hit the vector-memory and LDS-write paths in the same cycles
-// all segment long: delay wave w by (w & 3) * 16 cycles
-#define RB_ENTER_M() do { if (wave & 1) asm volatile("s_nop 15" ::: "memory"); if (wave & 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); RB_SB(); } while (0)
-#define RB_ENTER_L()
-#elif RB_SKEW == 2
-#define RB_ENTER_M() do { if (wave & 1) asm volatile("s_nop 15" ::: "memory"); RB_SB(); } while (0)
-#define RB_ENTER_L()
-#elif RB_PRIO_M != RB_PRIO_L
-#define RB_ENTER_M() asm volatile("s_setprio " RB_STR(RB_PRIO_M) ::: "memory")
-#define RB_ENTER_L() asm volatile("s_setprio " RB_STR(RB_PRIO_L) ::: "memory")
-#else
-#define RB_ENTER_M()
-#define RB_ENTER_L()
-#endif
-
-    // ---- phase end of a depth frequency: in-plane inverse (A^T . A, 4x4 -> 2x2), folded into the running depth sums (A^T columns
-    // [1 1 1 0] for od 0, [0 1 -1 -1] for od 1); the last frequency runs the epilogue.  Part 1 (columns xw 0, 1) runs before the
-    // next phase's first M overwrites them, part 2 (columns 2, 3) before its second M.
-    auto pe_part1 = [&]() __attribute__((always_inline)) {
-#ifdef RB_ABL_NOPE
-        return;
-#endif
-        f32x4 h0[2], h1[2];
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF == 0) {                 // xh 1: t1 + t2      (tc = t1)
 #pragma unroll
-        for (int xw = 0; xw < 2; ++xw) {
-            h0[xw] = acc[0][xw] + acc[1][xw] + acc[2][xw];
-            h1[xw] = acc[1][xw] - acc[2][xw] - acc[3][xw];
+            for (int xw = 0; xw < 4; ++xw) v1[xw] = tc[xw] + tb_[xw];
+        } else {                                   // xh 3: t1 - t3      (tc = t3)
+#pragma unroll
+            for (int xw = 0; xw < 4; ++xw) v1[xw] = RB_SUB(ta[xw], tc[xw]);
         }
-        q0[0] = h0[0] + h0[1]; q1[0] = h0[1];
-        q0[1] = h1[0] + h1[1]; q1[1] = h1[1];
+#ifdef RB_ABL_NOMFMA
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) acc[2 * HALF + 1][xw] += wf1[xw] * v1[xw];
+#else
+        RB_MFMA_ROW(2 * HALF + 1, wf1, v1)
+#endif
     };
-    auto pe_part2 = [&](int xd_, const Geo& eg) __attribute__((always_inline)) {
+
+    // end of a depth frequency: in-plane inverse (A^T . A, 4x4 -> 2x2), folded into the running depth sums (A^T columns
+    // [1 1 1 0] for od 0, [0 1 -1 -1] for od 1); the last frequency runs the epilogue
+    auto phase_end = [&](int xd_, const Geo& geo) __attribute__((always_inline)) {
 #ifdef RB_ABL_NOPE
         if (xd_ < 3) return;
-        if (eg.valid && lane == 0 && acc[0][2].x + acc[1][3].y + acc[2][2].z + acc[3][3].w == 1.2345e-30f) p.y[0] = 1.f;
+        if (geo.valid && lane == 0 && acc[0][0].x + acc[1][1].y + acc[2][2].z + acc[3][3].w == 1.2345e-30f) p.y[0] = 1.f;
         return;
 #endif
         // the last frequency: the residual's eight float4 are requested first, so that they travel under the inverse transform
-        const bool last = (D2 || xd_ == 3) && eg.valid;
+        const bool last = (D2 || xd_ == 3) && geo.valid;
         const int ct = ct0 + ctl;
         f32x4 rv[8];
         int64_t yo = 0;
         if (last) {
-            int en, edt, eht, ewt;
-            tile_coords(eg.tile, en, edt, eht, ewt);
-            yo = p.y_off0 + (int64_t)en * p.y_n_stride + (int64_t)(2 * edt) * p.y_d_stride + (int64_t)(2 * eht) * p.y_h_stride +
-                 (int64_t)(2 * ewt) * 16 + g * 4 + (int64_t)ct * p.y_cb_stride;
+            yo = p.y_off0 + (int64_t)geo.n * p.y_n_stride + (int64_t)(2 * geo.dt) * p.y_d_stride + (int64_t)(2 * geo.ht) * p.y_h_stride +
+                 (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.y_cb_stride;
             if (p.res) {
-                const int64_t ro = p.r_off0 + (int64_t)en * p.r_n_stride + (int64_t)(2 * edt) * p.r_d_stride + (int64_t)(2 * eht) * p.r_h_stride +
-                                   (int64_t)(2 * ewt) * 16 + g * 4 + (int64_t)ct * p.r_cb_stride;
+                const int64_t ro = p.r_off0 + (int64_t)geo.n * p.r_n_stride + (int64_t)(2 * geo.dt) * p.r_d_stride + (int64_t)(2 * geo.ht) * p.r_h_stride +
+                                   (int64_t)(2 * geo.wt) * 16 + g * 4 + (int64_t)ct * p.r_cb_stride;
 #pragma unroll
                 for (int i = 0; i < (D2 ? 4 : 8); ++i)
                     rv[i] = *(const f32x4*)(p.res + ro + (i >> 2) * p.r_d_stride + ((i >> 1) & 1) * p.r_h_stride + (i & 1) * 16);
@@ -458,14 +403,14 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         }
         f32x4 inv[4];
         {
-            f32x4 h0[2], h1[2];
+            f32x4 hh[2][4];
 #pragma unroll
-            for (int xw = 0; xw < 2; ++xw) {
-                h0[xw] = acc[0][2 + xw] + acc[1][2 + xw] + acc[2][2 + xw];
-                h1[xw] = acc[1][2 + xw] - acc[2][2 + xw] - acc[3][2 + xw];
+            for (int xw = 0; xw < 4; ++xw) {
+                hh[0][xw] = acc[0][xw] + acc[1][xw] + acc[2][xw];
+                hh[1][xw] = RB_SUB(RB_SUB(acc[1][xw], acc[2][xw]), acc[3][xw]);
             }
-            inv[0] = q0[0] + h0[0]; inv[1] = q1[0] - h0[0] - h0[1];
-            inv[2] = q0[1] + h1[0]; inv[3] = q1[1] - h1[0] - h1[1];
+            inv[0] = hh[0][0] + hh[0][1] + hh[0][2]; inv[1] = RB_SUB(RB_SUB(hh[0][1], hh[0][2]), hh[0][3]);
+            inv[2] = hh[1][0] + hh[1][1] + hh[1][2]; inv[3] = RB_SUB(RB_SUB(hh[1][1], hh[1][2]), hh[1][3]);
         }
         if constexpr (D2) {
             if (!last) return;
@@ -494,7 +439,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         }
         if (xd_ == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { o0[i] += inv[i]; o1[i] -= inv[i]; }
+            for (int i = 0; i < 4; ++i) { o0[i] += inv[i]; o1[i] = RB_SUB(o1[i], inv[i]); }
             return;
         }
         if (!last) return;
@@ -507,166 +452,71 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #pragma unroll
                 for (int ow = 0; ow < 2; ++ow) {
                     const int i = oh * 2 + ow;
-                    f32x4 v_ = (od == 0 ? o0[i] : o1[i] - inv[i]) * bn_sc + bn_sh;
+                    f32x4 v_ = (od == 0 ? o0[i] : RB_SUB(o1[i], inv[i])) * bn_sc + bn_sh;
                     if (p.res) v_ += rv[od * 4 + i];
                     if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
                     *(f32x4*)(p.y + yo + od * p.y_d_stride + oh * p.y_h_stride + ow * 16) = v_;
                 }
     };
 
-    // ---- the pipeline.  Half step i = 2 * step + hf; brick buffer = step & 1, ring slab = hf.  LDS hand-offs:
-    //   * ring slab of half step h: A's four waves copy its 16 units at the start of L_h-1 (slot 2h-2) and wait for them before the barrier
-    //     that ends M_h-1 (slot 2h-1); first read in slot 2h; the slab's previous readers (half step h-2) finished in slot 2h-3.
-    //   * brick of step s+1 (buffer (s+1) & 1) must be written in slots 4s..4s+3: its first read is in slot 4s+4 (A's L_2s+2) and that
-    //     buffer's previous readers (step s-1) finish in slot 4s-1.  A thread has two items per brick, held in two geometry sets P, Q:
-    //         M(hf 0) of step s: finish Q -> brick s+1            | issue loads of P for brick s+1 (A) / s+2 (B)
-    //         M(hf 1) of step s: finish P -> brick s+1 (A) / s+2 (B) | issue loads of Q for brick s+2
-    //     A writes in slots 4s+1, 4s+3; B in 4s+2 (brick s+1) and 4s+4 (brick s+2: slots 4(s+1)..): B stages half a step ahead of A.
-    //     An item's loads fly for two slots (one M to the next).
     struct Cursor { int round, xd, cb; };
     auto advance = [&](Cursor c) __attribute__((always_inline)) {
         if (++c.cb == p.cb_in) { c.cb = 0; if (D2 || ++c.xd == 4) { c.xd = 0; ++c.round; } }
         return c;
     };
-    auto clampc = [&](Cursor c) __attribute__((always_inline)) {        // steps past the end: stage the last round's rows again (never read)
-        if (c.round >= rounds) { c.round = rounds - 1; c.xd = 0; c.cb = 0; }
-        return c;
-    };
-    const int grp = ctl;                            // 0: group A, 1: group B
-    const int kP = 1 - grp, kQ = grp;               // which of the thread's two items the sets P and Q hold
 
+    // ---- prologue: brick of step 0 into buffer 0, weights of half step 0 into slab 0
     Cursor c0 = {0, 0, 0};
-    Cursor c1 = advance(c0);
-    Cursor c2 = advance(c1);
-    Geo geo = geo_of(0), ego = geo;
-    Raw r;
-    Item itP, itQ;
-    int rndP, rndQ;
-    // the fillers of an M segment: gaps 0..8: the nine pieces of the item finished here (its loads are two slots old; hipcc waits for ALL
-    // vector memory before the first piece, so nothing younger may be in flight yet); 10, 12: the two ring copies; 14, 16, .., 28: the eight
-    // loads of the item issued here (always the segment's last eight vector-memory instructions)
-    auto m_fill = [&](int i, int dxd, int dcb, int dhf, const Item& fi, int fxd, char* fbuf, const Item& ii, const Cursor& ic) __attribute__((always_inline)) {
-#ifndef RB_SCHED
-#define RB_SCHED 1
-#endif
-#if RB_SCHED == 0
-        if (i <= 8) stage_finish_pc(i, fi, fxd, fbuf, r);
-        else if (i >= 14 && i <= 28 && !(i & 1)) stage_issue_1(ii, ic.xd, ic.cb, r, (i - 14) >> 2, ((i - 14) >> 1) & 1);
-#elif RB_SCHED == 1
-        // LDS writes eight MFMAs apart (the four M waves of a CU write at the same moment; back to back they queue behind each other)
-        if (i <= 4) stage_finish_pc(i, fi, fxd, fbuf, r);
-        else if (i == 7) stage_finish_pc(5, fi, fxd, fbuf, r);
-        else if (i == 15) stage_finish_pc(6, fi, fxd, fbuf, r);
-        else if (i == 23) stage_finish_pc(7, fi, fxd, fbuf, r);
-        else if (i == 31) stage_finish_pc(8, fi, fxd, fbuf, r);
-        else if (i >= 9 && i <= 29 && !(i & 1) ) { }
-        else if (i == 9 || i == 11 || i == 13 || i == 17 || i == 19 || i == 21 || i == 25 || i == 27) {
-            const int m = i == 9 ? 0 : i == 11 ? 1 : i == 13 ? 2 : i == 17 ? 3 : i == 19 ? 4 : i == 21 ? 5 : i == 25 ? 6 : 7;
-            stage_issue_1(ii, ic.xd, ic.cb, r, m >> 1, m & 1);
-        }
-#else
-        // LDS writes in the tail
-        if (i <= 4) stage_finish_pc(i, fi, fxd, fbuf, r);
-        else if (i >= 8 && i <= 22 && !(i & 1)) stage_issue_1(ii, ic.xd, ic.cb, r, (i - 8) >> 2, ((i - 8) >> 1) & 1);
-        else if (i >= 28) stage_finish_pc(i - 23, fi, fxd, fbuf, r);
-#endif
-    };
-    // ---- prologue: brick of step 0 into buffer 0; weights of half step 0 (all waves) and B's share of half step 1; B's item P of
-    // brick 1 (its M(hf 1) of "step -1"); the loads of item Q of brick 1
-    ring_fill(0, 0, 0);
+    Geo geo = geo_of(0);
+    Item itA = item_of(0, 0), itB = item_of(0, 1);
+    ring_fill(0, 0, 0, 0);
     {
-        const Item i0 = item_of(0, 0), i1 = item_of(0, 1);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) stage_issue_w(i0, 0, 0, r, w);
-        stage_finish(i0, 0, brick, r);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) stage_issue_w(i1, 0, 0, r, w);
-        stage_finish(i1, 0, brick, r);
+        Raw r;
+        stage_issue(itA, 0, 0, r); stage_finish(itA, 0, brick, r);
+        stage_issue(itB, 0, 0, r); stage_finish(itB, 0, brick, r);
     }
-    {
-        const Cursor cc1 = clampc(c1);
-        itP = item_of(grp ? cc1.round : 0, kP); rndP = grp ? cc1.round : 0;
-        if (grp == 1) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) stage_issue_w(itP, cc1.xd, cc1.cb, r, w);
-            stage_finish(itP, cc1.xd, brick + buf_bytes, r);
-        }
-        itQ = item_of(cc1.round, kQ); rndQ = cc1.round;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) stage_issue_w(itQ, cc1.xd, cc1.cb, r, w);
-    }
-    RB_SB();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (grp == 1) asm volatile("s_barrier" ::: "memory");       // B starts one slot late
-    RB_SB();
+    RB_BARRIER();
 
     const char* const rs_lane = ring + ctl * 1024 + lane * 16;
     int stepno = 0;
+    // Step s = (xd, cb) of c0 runs the MFMAs of its brick (buffer s & 1) while the brick of step s+1 is built in the other buffer:
+    //   half 0: ring slab 1 <- weights of half 1 (LDS-DMA) | loads of item A of step s+1 issued | MFMAs of frequency rows 0, 1 |
+    //           item A transformed and written | barrier
+    //   half 1: ring slab 0 <- weights of step s+1's half 0 | loads of item B issued | MFMAs of rows 2, 3 | item B | phase end after
+    //           the last channel block | barrier
+    // Every wave runs the same straight-line sequence: accumulators merged from two control-flow paths cost a copy each, and waves that
+    // alternate roles (one staging while its SIMD partner multiplies) measured no faster.
     auto do_step = [&](auto first_tag) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const Cursor cc1 = clampc(c1), cc2 = clampc(c2);
-        const Cursor cP = grp ? cc2 : cc1;          // the brick P is staged for
-        char* const buf1 = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;      // brick s+1
-        char* const buf2 = brick + (unsigned)(stepno & 1) * buf_bytes;            // brick s+2 (= this step's buffer, free after L(hf 1))
-        char* const bufP = grp ? buf2 : buf1;
-        // ---- L of half 0
-        RB_MARK(0);
-        if constexpr (FIRST) {
-            if (stepno > 0) {                      // the phase that ended with the previous step
-                pe_part1();
-                if (D2 || c0.xd == 0) { ego = geo; geo = geo_of(c0.round); }
-            }
-        }
-        if (rndP != cP.round) { itP = item_of(cP.round, kP); rndP = cP.round; }       // P: last used in the previous M(hf 1), next in M(hf 0)
-        if (grp == 0) ring_fill_A(c0.xd, c0.cb, 1);                                      // the ring slab of this step's second half
+        const Cursor c1 = advance(c0);
+        const bool next_round = c1.round != c0.round;
+        if (next_round && c1.round < rounds) { itA = item_of(c1.round, 0); itB = item_of(c1.round, 1); }
         const char* tb = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds;
-        load_ops(std::integral_constant<int, 0>{}, tb, rs_lane);
-        RB_WAIT_L();
+        char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
+        Raw r;
+        RB_MARK(0);
+        ring_fill(1, c0.xd, c0.cb, 1);
         RB_MARK(1);
-        RB_BAR();
-        RB_ENTER_M();
-        // ---- M of half 0: A copies its ring units of (this step, half 1), B of (next step, half 0)
+        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
         RB_MARK(2);
-        const Cursor cd0 = grp ? cc1 : c0;          // ring copies (past the end: a repeat into a slab nobody reads any more)
-        mfma_seg(first_tag, std::integral_constant<int, 0>{}, [&](int i) __attribute__((always_inline)) {
-            m_fill(i, cd0.xd, cd0.cb, 1 - grp, itQ, cc1.xd, buf1, itP, cP);
-            if (i == 3) RB_MARK(11);
-            if (i == 9) RB_MARK(12);
-            if (i == 13) RB_MARK(13);
-            if (i == 21) RB_MARK(14);
-            if (i == 29) RB_MARK(15);
-        });
+        stage_finish(itA, c1.xd, nb, r);
         RB_MARK(3);
-        RB_WAIT_M();
+        RB_BARRIER();
         RB_MARK(4);
-        RB_BAR();
-        RB_ENTER_L();
-        // ---- L of half 1
+        ring_fill(0, c1.xd, c1.cb, 0);
         RB_MARK(5);
-        if constexpr (FIRST) {
-            if (stepno > 0) pe_part2(D2 ? 0 : (c0.xd + 3) & 3, ego);
-        }
-        if (rndQ != cc2.round) { itQ = item_of(cc2.round, kQ); rndQ = cc2.round; }    // Q: last used in M(hf 0), next in M(hf 1)
-        if (grp == 0) ring_fill_A(cc1.xd, cc1.cb, 0);                                    // ... of the next step's first half
-        load_ops(std::integral_constant<int, 1>{}, tb, rs_lane + 16384);
-        RB_WAIT_L();
+        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
         RB_MARK(6);
-        RB_BAR();
-        RB_ENTER_M();
-        // ---- M of half 1: A copies (next step, half 0), B (next step, half 1)
+        stage_finish(itB, c1.xd, nb, r);
         RB_MARK(7);
-        mfma_seg(first_tag, std::integral_constant<int, 1>{}, [&](int i) __attribute__((always_inline)) {
-            m_fill(i, cc1.xd, cc1.cb, grp, itP, cP.xd, bufP, itQ, cc2);
-        });
-        c0 = c1; c1 = c2; c2 = advance(c2);
-        ++stepno;
+        if (c0.cb == p.cb_in - 1) {
+            phase_end(c0.xd, geo);
+            if (next_round && c1.round < rounds) geo = geo_of(c1.round);
+        }
         RB_MARK(8);
-        RB_WAIT_M();
+        RB_BARRIER();
         RB_MARK(9);
-        RB_BAR();
-        RB_ENTER_L();
-        RB_MARK(10);
-        RB_FLUSH_MARKS();
+        c0 = c1;
+        ++stepno;
     };
 #pragma unroll 1
     for (int ph = 0; ph < rounds * (D2 ? 1 : 4); ++ph) {
@@ -674,13 +524,8 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #pragma unroll 1
         for (int c = 1; c < p.cb_in; ++c) do_step(std::false_type{});
     }
-    pe_part1();                                    // the last phase of the last round
-    pe_part2(D2 ? 0 : 3, geo);
-    if (grp == 0) asm volatile("s_barrier" ::: "memory");       // A's count of barriers = B's
-#if defined(RB_ABL_EXTRA_M) || defined(RB_ABL_EXTRA_L)
-    { float t_ = rb_dummy; for (int i_ = 0; i_ < 8; ++i_) t_ += rb_d4[i_] + rb_p4[i_].x + rb_p4[i_].y; if (t_ == 1.2345e-30f) p.y[0] = t_; }
-#endif
-#undef RB_SB
+#undef RB_MFMA_ROW
+#undef RB_SUB
 }
 
 template <int TW>
@@ -709,7 +554,7 @@ inline int rb_slots(int TW, int TH) {
 template <int TW>
 int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_t stream, bool d2 = false) {
     const int NS = rb_slots(TW, p.OH / 2);
-    const size_t lds = RB_RING_BYTES + (size_t)2 * (NS + 1) * 256 * TW;
+    const size_t lds = RB_RING_BYTES + (size_t)2 * NS * 256 * TW;
     if (lds > 163840 || NS * TW * 4 > 1024) return -4;
     static bool attr_set = false;                  // idempotent: racing first calls set the same value
     if (!attr_set) {
@@ -819,7 +664,7 @@ extern "C" int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int
     if (OW != 14 && OW % 28) return 0;                      // 14-wide maps: TW = 7; multiples of 28: strips of TW = 14 tile columns
     const int TW = OW == 14 ? 7 : 14;
     const int NS = rb_slots(TW, OH / 2);
-    return RB_RING_BYTES + (size_t)2 * (NS + 1) * 256 * TW <= 163840 && NS * TW * 4 <= 1024;
+    return RB_RING_BYTES + (size_t)2 * NS * 256 * TW <= 163840 && NS * TW * 4 <= 1024;
 }
 
 static int rb_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void* stream) {

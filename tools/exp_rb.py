@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from disprcnn_amd import _lib
+if os.environ.get("DRC_LIB"):
+    _lib.LIB_PATH = os.environ["DRC_LIB"]
 from disprcnn_amd import engine as E
 
 
