@@ -102,6 +102,7 @@ _SIGS = {
     "drc_srpn_proposals_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_float, _P, _P, _P, _P]),
     "drc_conv3d_k3_wino_costvol_fwd": (_I, [C.POINTER(DrcTapconvParams), C.POINTER(DrcCostvolSrc), _I, _P]),
     "drc_disparity_paste_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "drc_disparity_resize_fwd": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
     "drc_roi_depth_maps_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "drc_conv2d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_pack_weights_wino2d": (_I, [_P, _I, _I, _I, _I, _P, _P]),

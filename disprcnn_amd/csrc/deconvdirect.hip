@@ -157,13 +157,11 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
             for (int i = 0; i < 27; ++i) {
                 constexpr int dummy_ = 0; (void)dummy_;
                 const Combo q = kTab.c[i];
-#ifndef DD_ABL_NOW      // (ablation, wrong results by design: the 27 x CT weight loads of a channel block issued only for its first taps)
                 if (i + DD_AHEAD < 27) {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         wq[(i + DD_AHEAD) % (DD_AHEAD + 1)][ct] = *(const f32x4*)(wb + (unsigned)(i + DD_AHEAD) * w_tap_b + ct * 1024 + wlane);
                 }
-#endif
                 if (LAST && p.res && (i == 0 || kTab.c[i > 0 ? i - 1 : 0].last_of_class)) {
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt)

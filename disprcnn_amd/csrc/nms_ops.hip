@@ -2,8 +2,8 @@
 //   reference: csrc/cuda/nms.cu:23-131 (IoU with the legacy +1 pixel convention, suppression when IoU > threshold),
 //              csrc/cpu/nms_cpu.cpp:5-75 (same greedy order; compares with >=).
 // The reference computes a 64x64-blocked suppression bitmask on the device, copies it to the HOST and walks it there.  Here the
-// bitmask kernel uses one 64-lane wavefront per (row block, column block) -- a mask word is exactly one lane's ballot-free
-// 64-bit accumulator -- and the greedy walk stays on the device: one wavefront keeps the running "removed" words in its lanes
+// bitmask kernel uses one 64-lane wavefront per (row block, column block) -- a mask word is exactly one wavefront ballot -- and the
+// greedy walk stays on the device: one wavefront keeps the running "removed" words in its lanes
 // (lane j owns column block j) and ORs a surviving row's words in one step.  No host round trip, no allocation here (the
 // caller passes the workspace).
 #include <hip/hip_runtime.h>
@@ -13,42 +13,42 @@
 
 namespace {
 
-__device__ __forceinline__ float iou_plus1(const float* a, const float* b) {
-    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-    const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
-    const float inter = width * height;
-    const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
-    const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
-    return inter / (sa + sb - inter);
-}
-
-// grid (col_blocks, row_blocks), 64 threads: lane r of row block R tests its box against the 64 boxes of column block C
+// Suppression bitmask, one wavefront per (row block R, column block C) of 64 x 64 boxes.  Lane i OWNS column box 64C+i (registers; no LDS,
+// no barrier); the row boxes are walked one at a time, row r's corners and area broadcast from lane r through scalar registers
+// (v_readlane), every lane tests it against its own column box, and the wavefront-wide ballot of the test IS the row's 64-bit mask word
+// (bit i = row suppresses column box 64C+i).  Lane r keeps word r, so the block ends with one coalesced 512-byte store.
+// IoU with the legacy +1 pixel convention, as inter / (area_row + area_col - inter) (reference csrc/cuda/nms.cu:13-21, csrc/cpu/nms_cpu.cpp:26-62:
+// the operation order is what index-exact parity with the reference's kept sets pins).
+// grid (col_blocks, row_blocks, box sets), 64 threads
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thresh, int strict, uint64_t* __restrict__ mask) {
     const int rb = blockIdx.y, cb = blockIdx.x;
     const int col_blocks = gridDim.x;
     boxes += (int64_t)blockIdx.z * n * 4;                  // batched launch: box set blockIdx.z
     mask += (int64_t)blockIdx.z * n * col_blocks;
-    __shared__ float cbox[64 * 4];
-    const int cn = min(n - cb * 64, 64), rn = min(n - rb * 64, 64);
-    if ((int)threadIdx.x < cn) {
-        const float4 v = *(const float4*)(boxes + (int64_t)(cb * 64 + threadIdx.x) * 4);
-        cbox[threadIdx.x * 4 + 0] = v.x; cbox[threadIdx.x * 4 + 1] = v.y; cbox[threadIdx.x * 4 + 2] = v.z; cbox[threadIdx.x * 4 + 3] = v.w;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x >= rn) return;
-    const int row = rb * 64 + threadIdx.x;
-    uint64_t t = 0;
-    if (cb >= rb) {                                        // only later boxes can be suppressed by this one
-        const float4 v = *(const float4*)(boxes + (int64_t)row * 4);
-        const float me[4] = {v.x, v.y, v.z, v.w};
-        const int start = cb == rb ? (int)threadIdx.x + 1 : 0;
-        for (int i = start; i < cn; ++i) {
-            const float o = iou_plus1(me, cbox + i * 4);
-            if (strict ? o > thresh : o >= thresh) t |= 1ULL << i;
+    const int lane = threadIdx.x;
+    const int rn = min(n - rb * 64, 64), cn = min(n - cb * 64, 64);
+    uint64_t word = 0;
+    if (cb >= rb) {                                        // a box only suppresses LATER boxes (the upper triangle; wave-uniform)
+        const float4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const float4 cq = lane < cn ? *(const float4*)(boxes + (int64_t)(cb * 64 + lane) * 4) : z4;
+        const float4 rq = lane < rn ? *(const float4*)(boxes + (int64_t)(rb * 64 + lane) * 4) : z4;
+        const float c_area = (cq.z - cq.x + 1.f) * (cq.w - cq.y + 1.f);
+        const float r_area = (rq.z - rq.x + 1.f) * (rq.w - rq.y + 1.f);
+        auto bcast = [](float v, int r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+        for (int r = 0; r < rn; ++r) {
+            const float x1 = bcast(rq.x, r), y1 = bcast(rq.y, r), x2 = bcast(rq.z, r), y2 = bcast(rq.w, r), sa = bcast(r_area, r);
+            const float left = fmaxf(x1, cq.x), right = fminf(x2, cq.z);
+            const float top = fmaxf(y1, cq.y), bottom = fminf(y2, cq.w);
+            const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+            const float inter = width * height;
+            const float o = inter / (sa + c_area - inter);
+            const bool hit = lane < cn && (strict ? o > thresh : o >= thresh);
+            uint64_t w = __ballot(hit);
+            if (cb == rb) w &= r < 63 ? ~0ULL << (r + 1) : 0ULL;     // the diagonal block: only the boxes after row r
+            if (lane == r) word = w;
         }
     }
-    mask[(int64_t)row * col_blocks + cb] = t;
+    if (lane < rn) mask[(int64_t)(rb * 64 + lane) * col_blocks + cb] = word;
 }
 
 // one wavefront: lane j holds the removed-bits of column blocks j, j+64, ...  The walk goes 64 rows (one column block) at a time:
@@ -216,6 +216,8 @@ __global__ __launch_bounds__(64) void nms_walk_big_kernel(const uint64_t* __rest
             const uint64_t* p = mask + (int64_t)(c * 64 + __builtin_ctzll(km)) * col_blocks;
             for (int j = c + 1 + lane; j < col_blocks; j += 64) remv_lds[j] |= p[j];
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the ORs above have landed before the next block's word is read
+        __builtin_amdgcn_wave_barrier();                   // (another lane wrote it: do not let the compiler move the read across)
     }
 }
 

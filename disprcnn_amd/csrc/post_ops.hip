@@ -84,6 +84,42 @@ __global__ __launch_bounds__(kThreads) void roi_depth_maps_kernel(const float* _
     }
 }
 
+// DisparityMap.resize (reference structures/disparity.py:39-62): a whole [IH,IW] map to [OH,OW], values times OW / IW (a disparity is a
+// horizontal pixel distance).  mode 0: upsample_bilinear2d(align_corners=True) -- source coordinate = dst * (in-1)/(out-1), the two rows
+// blended after the two columns; mode 1: the reference's signed max pooling -- adaptive_max_pool2d of the positive part minus
+// adaptive_max_pool2d of the negated negative part (window [floor(i*in/out), ceil((i+1)*in/out)) per axis).
+__global__ __launch_bounds__(kThreads) void disparity_resize_kernel(const float* __restrict__ src, int IH, int IW, float* __restrict__ dst, int OH,
+                                                                     int OW, int mode) {
+    const int64_t n = (int64_t)OH * OW;
+    const float sh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+    const float sw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    for (int64_t pix = (int64_t)blockIdx.x * kThreads + threadIdx.x; pix < n; pix += (int64_t)gridDim.x * kThreads) {
+        const int y = (int)(pix / OW), x = (int)(pix - (int64_t)y * OW);
+        float v;
+        if (mode == 0) {
+            const float fy = sh * (float)y, fx = sw * (float)x;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int yp = y0 < IH - 1 ? 1 : 0, xp = x0 < IW - 1 ? 1 : 0;
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float* r0 = src + (int64_t)y0 * IW + x0;
+            const float* r1 = r0 + (int64_t)yp * IW;
+            v = (1.f - ly) * ((1.f - lx) * r0[0] + lx * r0[xp]) + ly * ((1.f - lx) * r1[0] + lx * r1[xp]);
+        } else {
+            const int ys = (int)(((int64_t)y * IH) / OH), ye = (int)((((int64_t)y + 1) * IH + OH - 1) / OH);
+            const int xs = (int)(((int64_t)x * IW) / OW), xe = (int)((((int64_t)x + 1) * IW + OW - 1) / OW);
+            float mp = -INFINITY, mn = -INFINITY;
+            for (int yy = ys; yy < ye; ++yy)
+                for (int xx = xs; xx < xe; ++xx) {
+                    const float s = src[(int64_t)yy * IW + xx];
+                    mp = fmaxf(mp, s > 0.f ? s : 0.f);
+                    mn = fmaxf(mn, s < 0.f ? -s : 0.f);
+                }
+            v = mp - mn;
+        }
+        dst[pix] = v / (float)IW * (float)OW;
+    }
+}
+
 unsigned blocks_for(int64_t n) {
     int64_t b = (n + kThreads - 1) / kThreads;
     return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -108,5 +144,14 @@ extern "C" int drc_roi_depth_maps_fwd(const float* disp, int S, const int32_t* b
     if (!disp || !boxes || !fuxb || !out) return -1;
     hipLaunchKernelGGL(roi_depth_maps_kernel, dim3(blocks_for((int64_t)H * W), (unsigned)R), dim3(kThreads), 0, (hipStream_t)stream, disp, S,
                        boxes, fuxb, H, W, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int drc_disparity_resize_fwd(const float* src, int IH, int IW, float* dst, int OH, int OW, int mode, void* stream) {
+    if (IH <= 0 || IW <= 0 || OH < 0 || OW < 0 || (mode != 0 && mode != 1)) return -2;
+    if (OH == 0 || OW == 0) return 0;
+    if (!src || !dst) return -1;
+    hipLaunchKernelGGL(disparity_resize_kernel, dim3(blocks_for((int64_t)OH * OW)), dim3(kThreads), 0, (hipStream_t)stream, src, IH, IW, dst, OH, OW,
+                       mode);
     return (int)hipGetLastError();
 }

@@ -664,7 +664,8 @@ WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (w
           # round-3 fix of wino2d's spilled scalars still 70 vs 82 us at 32ch@112^2, 68 vs 75 at 64ch@56^2, 194 vs 201 at 128ch@56^2
           # (32 crops; 265 vs 350 / 218 vs 266 / 693 vs 754 at 128 crops); 320 -> 128 loses (443 vs 405) and stays on wino2d
           "dilated": True,    # dilated layers whose maps divide by 2*dilation: d*d interleaved sub-grids (feature CNN layer4; round 3)
-          "odd": True,        # odd maps too (the trunk's 47 x 155 level: 256 -> 256 186 -> ? us); False: direct kernel as in rounds 1-2
+          "odd": True,        # odd maps too (the trunk's 47 x 155 level; the trunk's 3x3 convolutions went 2.02 -> 1.76 ms per pair with the
+                              # Winograd layers incl. the odd ones, see "min_chunks"); False: direct kernel as in rounds 1-2
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
 CONV2D_FILL = {"enabled": True}   # 3x3 Conv2d tile choice: trade MFMA padding for waves when a layer cannot fill the 1024 SIMDs
@@ -845,7 +846,8 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
         wct = 2 if ct % 2 == 0 else 1
         # (odd maps: the last tile row / column is half used, wino2d.hip; their patch row 3 lies in the slack behind the tensor)
         wtiles = x.N * ((y.H + 1) // 2) * ((y.W + 1) // 2)
-        dil_ok = dilation == 1 or (WINO2D["dilated"] and y.H % (2 * dilation) == 0 and y.W % (2 * dilation) == 0)
+        # (drc_conv2d_k3_wino_fwd instantiates dilations 1, 2 and 4 only; any other 3x3 layer keeps the direct kernel)
+        dil_ok = dilation == 1 or (WINO2D["dilated"] and dilation in (2, 4) and y.H % (2 * dilation) == 0 and y.W % (2 * dilation) == 0)
         if (WINO2D["enabled"] and stride == 1 and dil_ok and pad == dilation and (WINO2D["odd"] or not (y.H | y.W) & 1) and
                 (x.N * x.n_stride + 2 * x.h_stride) * 4 < 2 ** 32 and wtiles // 64 >= WINO2D["min_chunks"]):
             pl.wino = True

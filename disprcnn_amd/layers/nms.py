@@ -11,6 +11,20 @@ from .. import _lib
 from .. import engine as E
 
 
+def _mask_workspace(views, n, device):
+    """The dense suppression mask: views * n * ceil(n / 64) words of 8 bytes (1.8 GB per view at 120k boxes, 34 GB at the 524,288-box limit).
+    Checked against the free device memory first, so that an oversized call fails with the reason instead of an allocator error."""
+    words = views * n * ((n + 63) // 64)
+    need = words * 8
+    free, _total = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    if need > free + cached:
+        raise RuntimeError(f"nms: the suppression mask of {n} boxes x {views} view(s) needs {need / 2**30:.1f} GiB "
+                           f"(n * ceil(n/64) * 8 bytes per view), {(free + cached) / 2**30:.1f} GiB are free; pre-select the top-scoring boxes "
+                           f"(the reference keeps PRE_NMS_TOP_N <= 12,000 per level)")
+    return torch.empty(words, dtype=torch.int64, device=device)
+
+
 def nms(dets, scores, threshold, strict=True):
     """strict=True: suppress when IoU > threshold (the reference's CUDA op); False: >= (its CPU op)."""
     E.require_gpu(dets, "nms")
@@ -21,7 +35,7 @@ def nms(dets, scores, threshold, strict=True):
         return torch.empty(0, dtype=torch.int64, device=dets.device)
     order = torch.sort(scores.float(), dim=0, descending=True, stable=True)[1]
     boxes = dets.float().index_select(0, order).contiguous()
-    mask = torch.empty(n * ((n + 63) // 64), dtype=torch.int64, device=dets.device)
+    mask = _mask_workspace(1, n, dets.device)
     keep = torch.empty(n, dtype=torch.uint8, device=dets.device)
     st = _lib.lib().drc_nms_sorted_fwd(E._ptr(boxes), n, float(threshold), int(bool(strict)), E._ptr(mask), E._ptr(keep), E._stream_ptr(dets.device))
     _lib.check(st, "drc_nms_sorted_fwd")
@@ -43,7 +57,7 @@ def nms_pair_sorted_joint(dets_a, dets_b, threshold, max_keep=-1, strict=True):
         k = nms_pair(dets_a, dets_b, s, threshold, strict, joint=True)
         return k[:max_keep] if max_keep > 0 else k
     boxes = torch.stack((dets_a.float(), dets_b.float())).contiguous()
-    mask = torch.empty(2 * n * ((n + 63) // 64), dtype=torch.int64, device=dets_a.device)
+    mask = _mask_workspace(2, n, dets_a.device)
     keep = torch.empty(n, dtype=torch.uint8, device=dets_a.device)
     st = _lib.lib().drc_nms_sorted_pair_joint_fwd(E._ptr(boxes), n, float(threshold), int(bool(strict)), int(max_keep), E._ptr(mask), E._ptr(keep),
                                                   E._stream_ptr(dets_a.device))
@@ -65,7 +79,7 @@ def nms_pair(dets_a, dets_b, scores, threshold, strict=True, joint=False):
         return e if joint else (e, e.clone())
     order = torch.sort(scores.float(), dim=0, descending=True, stable=True)[1]
     boxes = torch.stack((dets_a.float().index_select(0, order), dets_b.float().index_select(0, order))).contiguous()
-    mask = torch.empty(2 * n * ((n + 63) // 64), dtype=torch.int64, device=dets_a.device)
+    mask = _mask_workspace(2, n, dets_a.device)
     keep = torch.empty(2, n, dtype=torch.uint8, device=dets_a.device)
     st = _lib.lib().drc_nms_sorted_batch_fwd(E._ptr(boxes), 2, n, float(threshold), int(bool(strict)), E._ptr(mask), E._ptr(keep), E._stream_ptr(dets_a.device))
     _lib.check(st, "drc_nms_sorted_batch_fwd")

@@ -182,9 +182,18 @@ class BackboneRuntime:
         _lib.check(lib.drc_maxpool2d_blocked(E._ptr(t["in4"].storage), E._ptr(t["p6"].storage), N, 16, th, tw, t["in4"].ph, 1, 2,
                                              t["p6"].H, t["p6"].W, t["p6"].ph, sp), "drc_maxpool2d_blocked")
         self._levels = [t[o] for o in ws["outs"]]
-        return tuple(t[o].to_dense()[:, :, 0] for o in ws["outs"])
+        self._gen = getattr(self, "_gen", 0) + 1
+        outs = tuple(t[o].to_dense()[:, :, 0] for o in ws["outs"])
+        for o in outs:                                   # the dense maps carry the generation of the blocked workspace they were read from
+            o._drc_pyramid_gen = (id(self), self._gen)
+        return outs
 
-    def blocked_levels(self):
-        """The pyramid of the LAST forward in the engine's blocked layout (halo 1), for consumers that run on the engine themselves
-        (the Stereo-RPN head): valid until the next forward overwrites the workspace."""
-        return self._levels
+    def blocked_levels(self, dense_outputs=None):
+        """The pyramid in the engine's blocked layout (halo 1), for consumers that run on the engine themselves (the Stereo-RPN head).
+        Pass the tuple `forward` returned: the levels are handed out only if that call is still the LAST forward of this runtime (the next
+        one overwrites the workspace) -- otherwise None, and the caller uses the dense maps.  Without an argument: the last forward's levels,
+        unchecked."""
+        if dense_outputs is None:
+            return self._levels
+        stamp = getattr(dense_outputs[0], "_drc_pyramid_gen", None) if len(dense_outputs) else None
+        return self._levels if stamp == (id(self), getattr(self, "_gen", 0)) else None

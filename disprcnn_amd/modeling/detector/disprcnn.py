@@ -58,7 +58,8 @@ class DispRCNN(nn.Module):
         feats = self.backbone(torch.cat((left_images.tensors, right_images.tensors), dim=0))
         left_features, right_features = [f[:n] for f in feats], [f[n:] for f in feats]
         rt = getattr(self.backbone, "_rt", None)
-        levels = rt.blocked_levels() if rt is not None and hasattr(rt, "blocked_levels") else None
+        # the blocked pyramid behind THESE dense maps (None if another forward of the backbone has overwritten the workspace since)
+        levels = rt.blocked_levels(feats) if rt is not None and hasattr(rt, "blocked_levels") else None
         left_prop, right_prop, _ = self.rpn(left_images, right_images, left_features, right_features, blocked_levels=levels)
         _, left_result, right_result, _ = self.roi_heads(left_features, right_features, left_prop, right_prop)
         return {"left": left_result, "right": right_result}

@@ -139,7 +139,28 @@ class BlockedConv2d:
         return yb
 
 
-_PACKED_W = {}     # id(weight) -> (version key, packed tensor): the layer's weights in the GEMM's operand layout, rebuilt when they change
+_PACKED_W = {}     # id(parameter) -> (weakref to the parameter, {tag: (version key, packed tensor, 2D shape)}).  The weak reference is the
+                   # identity check (ids and allocator addresses are reused once a model is freed) and its callback drops the entry -- and the
+                   # packed GPU copies with it -- when the parameter dies; nothing is stored on the parameter, so pickling a model stays lean.
+
+
+def _packed_cache(prm):
+    import weakref
+    k = id(prm)
+    ent = _PACKED_W.get(k)
+    if ent is None or ent[0]() is not prm:
+        ent = _PACKED_W[k] = (weakref.ref(prm, lambda _r, k=k: _PACKED_W.pop(k, None)), {})
+    return ent[1]
+
+
+def clear_packed_weights(module):
+    """Drop the packed GEMM operands cached for the parameters of `module`.  They are rebuilt on the next call; needed only after an edit
+    the version counter cannot see (`param.data.copy_(...)`, `param.data[...] = ...`) -- `load_state_dict`, optimizers and every in-place
+    operation on the parameter itself bump `_version` and are picked up automatically."""
+    for prm in module.parameters():
+        ent = _PACKED_W.get(id(prm))
+        if ent is not None and ent[0]() is prm:
+            ent[1].clear()
 
 
 def _pack_rows(a):
@@ -154,18 +175,16 @@ def _pack_rows(a):
 
 def gemm_bias_act(x, weight_param, w2d_fn, bias, relu, tag=""):
     """act(x [M,K] @ W^T + bias) with W = w2d_fn(weight_param) [N,K] on drc_linear_fwd.  The packed form of W is cached per
-    (parameter, tag) and rebuilt when the parameter's version or storage changes."""
+    live parameter object (and tag) and rebuilt when the parameter's version, storage, device or shape changes (see clear_packed_weights)."""
     from .. import _lib
     E.require_gpu(x, "gemm_bias_act")
     dev = x.device
     key = (weight_param._version, weight_param.data_ptr(), dev, tuple(weight_param.shape))
-    ck = (id(weight_param), tag)
-    ent = _PACKED_W.get(ck)
+    cache = _packed_cache(weight_param)
+    ent = cache.get(tag)
     if ent is None or ent[0] != key:
         w2 = w2d_fn(weight_param.detach().to(device=dev, dtype=torch.float32)).contiguous()
-        ent = _PACKED_W[ck] = (key, _pack_rows(w2), tuple(w2.shape))
-        if len(_PACKED_W) > 64:                                       # parameters of discarded models
-            _PACKED_W.pop(next(iter(_PACKED_W)))
+        ent = cache[tag] = (key, _pack_rows(w2), tuple(w2.shape))
     wp, (N, Kw) = ent[1], ent[2]
     x = x.float().contiguous()
     M, K = x.shape

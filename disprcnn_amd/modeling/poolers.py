@@ -42,11 +42,10 @@ class Pooler(nn.Module):
         """x: per-level [N,C,H,W] maps (a trailing extra level is ignored); boxes: list[BoxList] -> [R,C,oh,ow] in box order."""
         rois = self.convert_to_roi_format(boxes)
         c = x[0].shape[1]
-        out = torch.zeros(len(rois), c, *self.output_size, dtype=torch.float32, device=x[0].device)
         if len(self.poolers) == 1:
             return self.poolers[0](x[0], rois)
         if len(rois) == 0:
-            return out
+            return torch.zeros(0, c, *self.output_size, dtype=torch.float32, device=x[0].device)
         levels = self.map_levels(boxes)
         feats = [f.contiguous() for f in x[: len(self.poolers)]]
         needs_grad = torch.is_grad_enabled() and any(f.requires_grad for f in feats)
@@ -64,6 +63,7 @@ class Pooler(nn.Module):
                                                   self.output_size[1], int(self.poolers[0].sampling_ratio), E._stream_ptr(rois.device))
             _lib.check(st, "drc_roi_align_fpn_fwd")
             return out
+        out = torch.zeros(len(rois), c, *self.output_size, dtype=torch.float32, device=x[0].device)       # (the per-level path only)
         for level, (feat, pooler) in enumerate(zip(x[: len(self.poolers)], self.poolers)):
             idx = torch.nonzero(levels == level).reshape(-1)
             if idx.numel() == 0:

@@ -1,5 +1,9 @@
-"""DisparityMap: the value holder the post-processing hands on (reference: disprcnn/structures/disparity.py:12-36; the
-resize / crop arithmetic of that class runs inside drc_disparity_paste_fwd on this path)."""
+"""DisparityMap: the value holder the post-processing hands on and the training-target code crops and resamples
+(reference: disprcnn/structures/disparity.py:12-83; callers modeling/detector/disprcnn3d.py:89-91,173-174 and
+tools/kitti_object/generate_psmnet_input_inf.py:99-104).  `resize` runs on the GPU (drc_disparity_resize_fwd, csrc/post_ops.hip);
+the batched forms of the same arithmetic live in drc_roi_train_targets_fwd / drc_disparity_paste_fwd."""
+import warnings
+
 import torch
 
 
@@ -26,3 +30,35 @@ class DisparityMap:
 
     def to(self, device):
         return DisparityMap(self.data.to(device))
+
+    def resize(self, dst_size, use_max_pooling=False):
+        """-> the map resampled to dst_size = (width, height), values scaled by dst_width / width (a disparity is a horizontal pixel
+        distance).  Bilinear with align_corners=True, or (use_max_pooling) the signed max pooling of the reference; a negative
+        size leaves the map unchanged with a warning, like the reference.  GPU tensors only (no CPU fallback on the product path)."""
+        from .. import _lib
+        from .. import engine as E
+        if any(s < 0 for s in dst_size):
+            warnings.warn("dst size < 0, size will not change.")
+            return self.clone()
+        ow, oh = (int(round(s)) for s in dst_size)
+        E.require_gpu(self.data, "DisparityMap.resize")
+        src = self.data.contiguous()
+        out = torch.empty(oh, ow, dtype=torch.float32, device=src.device)
+        st = _lib.lib().drc_disparity_resize_fwd(E._ptr(src), self.height, self.width, E._ptr(out), oh, ow, int(bool(use_max_pooling)),
+                                                 E._stream_ptr(src.device))
+        _lib.check(st, "drc_disparity_resize_fwd")
+        return DisparityMap(out)
+
+    def crop(self, box):
+        """box = (left, upper, right, lower), rounded to integers -> the [lower-upper, right-left] window; where the box reaches past the
+        bottom / right edge the window is zero-filled (reference :68-77).  Coordinates are expected non-negative (callers clamp first)."""
+        x1, y1, x2, y2 = (int(round(float(v))) for v in box)
+        if min(x1, y1) < 0 or x2 < x1 or y2 < y1:
+            raise ValueError(f"DisparityMap.crop: box {tuple(box)} is not a forward window of non-negative coordinates")
+        out = self.data.new_zeros((y2 - y1, x2 - x1))
+        part = self.data[y1:y2, x1:x2]
+        out[: part.shape[0], : part.shape[1]] = part
+        return DisparityMap(out)
+
+    def __sub__(self, other):
+        return DisparityMap(self.data - other)

@@ -394,6 +394,12 @@ int drc_disparity_paste_fwd(const float* disp, int S, const int32_t* boxes, cons
                             const float* mask, float* out, void* stream);
 int drc_roi_depth_maps_fwd(const float* disp, int S, const int32_t* boxes, const float* fuxb, int R, int H, int W, float* out, void* stream);
 
+/* DisparityMap.resize of a whole map (reference structures/disparity.py:39-62, called by disprcnn3d.py:89-91,173-174 and
+ * tools/kitti_object/generate_psmnet_input_inf.py:99-104): src [IH,IW] -> dst [OH,OW], values times OW / IW.
+ *   mode 0: bilinear, align_corners=True (F.interpolate);  mode 1: use_max_pooling=True -- adaptive max pooling of the positive part minus
+ *   adaptive max pooling of the negated negative part. */
+int drc_disparity_resize_fwd(const float* src, int IH, int IW, float* dst, int OH, int OW, int mode, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * f4. Fully connected layers of the 2D stage's heads (roi_heads/box_head/roi_box_feature_extractors.py:85-130: the 7x7/stride-7
  *   convolution on 7x7 ROI features = a 25088 -> 2048 FC, then 2048 -> 2048; roi_box_predictors.py; the mask predictor's 2x2/stride-2

@@ -291,3 +291,28 @@ def test_fp16_kernel_selection():
         assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname.startswith("conv16_kernel")
     finally:
         E.C16_TILE["enabled"] = saved
+
+
+def test_packed_weight_cache_is_tied_to_the_live_parameter():
+    """the GEMM operand cache must not be keyed by id() alone (ids and allocator addresses are reused once a model is freed)
+    and must not keep packed copies of dead models alive."""
+    import gc
+
+    import torch
+
+    from disprcnn_amd.modeling import head_ops as H
+    lin = torch.nn.Linear(8, 4)
+    cache = H._packed_cache(lin.weight)
+    cache["tag"] = ("key", "packed", (4, 8))
+    assert H._packed_cache(lin.weight) is cache
+    H.clear_packed_weights(lin)
+    assert H._packed_cache(lin.weight) == {}
+    k = id(lin.weight)
+    H._packed_cache(lin.weight)["tag"] = 1
+    # an impostor entry under a recycled id is not trusted: the weak reference has to point at THIS parameter
+    other = torch.nn.Parameter(torch.zeros(4, 8))
+    H._PACKED_W[id(other)] = H._PACKED_W[k]
+    assert H._packed_cache(other) == {}
+    del lin, cache, other
+    gc.collect()
+    assert k not in H._PACKED_W
