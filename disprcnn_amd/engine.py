@@ -494,7 +494,7 @@ class ConvPlan:
         if slide:
             # the sliding-window kernel gives every resident wave an equal share (>= 3 output slices) of the
             # (cout group, column, slice) units: use it only when that still yields enough waves to fill the 1024 SIMDs
-            # (measured cross-over, tools/exp_conv.py)
+            # (measured cross-over, tools/experiments/exp_conv.py)
             self.slide_ct = SLIDE["ct"] if ct % SLIDE["ct"] == 0 else 1
             cols = x.N * (-(-OH // R)) * (-(-OW // WT))
             # small batches: with ONE cout tile per wave the LDS-free direct kernel still beats the generic kernel down to ~150 units
@@ -670,13 +670,13 @@ WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (w
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
 CONV2D_FILL = {"enabled": True}   # 3x3 Conv2d tile choice: trade MFMA padding for waves when a layer cannot fill the 1024 SIMDs
 DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
-DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/exp_conv.py)
+DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/experiments/exp_conv.py)
         "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)
 
 
 def choose_tile_down(OH, OW):
     """Output tile (R, WT) of the stride-2 kernel: least MFMA padding, then the largest tile (more MFMAs per staged
-    byte and per weight load; measured on the 14x14 and 7x7 maps, tools/exp_conv.py), then the widest rows."""
+    byte and per weight load; measured on the 14x14 and 7x7 maps, tools/experiments/exp_conv.py), then the widest rows."""
     if DOWN["tile"]:
         return DOWN["tile"]
     best = None
@@ -746,14 +746,14 @@ def plan_conv3d(x, y, stride, cout, relu):
 
 FUSED_DECONV = {"enabled": True}
 DECONV_DIRECT = {"enabled": True,     # LDS-free fused transposed conv (deconvdirect.hip) instead of the LDS-staged tapdeconv.hip
-                 "ct": 2}             # cout tiles per wave when they pair up (development knob: tools/exp_conv.py DC_CT)
+                 "ct": 2}             # cout tiles per wave when they pair up (development knob: tools/experiments/exp_conv.py DC_CT)
 
 
-DECONV_TILE = None    # development override (tools/exp_conv.py)
+DECONV_TILE = None    # development override (tools/experiments/exp_conv.py)
 
 
 def choose_tile_deconv(H, W):
-    """Input tile (R, WT) of the fused transposed-conv kernel.  Measured on MI355X (tools/exp_conv.py, 14x14 and 7x7 maps):
+    """Input tile (R, WT) of the fused transposed-conv kernel.  Measured on MI355X (tools/experiments/exp_conv.py, 14x14 and 7x7 maps):
     tiles of 4 voxel-tiles (49..64 slots, one cout tile per wave) beat smaller ones even with more MFMA padding, because a
     tap step then carries 16 MFMAs; among those the least padding wins."""
     if DECONV_TILE:

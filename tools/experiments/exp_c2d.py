@@ -1,6 +1,6 @@
 """Development tool: 3x3 Conv2d tile choice on the trunk's small maps (engine.CONV2D_FILL on / off)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import engine as E
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Micro-benchmark of one tapconv layer (development tool; not part of the product or the tests)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import _lib
 if os.environ.get("DRC_LIB"):

@@ -1,6 +1,6 @@
 """Development tool: run the 2D stage several times on one input and report the detection counts (determinism check)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import engine as E
 from disprcnn_amd.modeling.detector import DispRCNN, default_cfg_2d

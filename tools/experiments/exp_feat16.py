@@ -1,12 +1,12 @@
 """Development tool: per-tensor error of the fp16-storage feature CNN against the fp32 HIP path."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import engine as E
 from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
 from disprcnn_amd.utils import synth
 dev = torch.device("cuda:0")
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
 from tests.helpers import state_for
 sd = state_for('B')
 def model(storage, feat):

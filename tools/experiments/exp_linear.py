@@ -1,6 +1,6 @@
 """Development tool: drc_linear_fwd vs torch.addmm (hipBLASLt) on the stereo box head's fully connected layers."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import _lib
 if os.environ.get("DRC_LIB"):

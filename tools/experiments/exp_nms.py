@@ -1,6 +1,6 @@
 """Development tool: time layers.nms / nms_pair on RPN-sized proposal sets."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd.layers import nms, nms_pair
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Development tool: the kernel each 2D-CNN site of Config B runs (plan names) and their TIMING."""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import engine as E
 from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet

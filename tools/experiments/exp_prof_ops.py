@@ -1,6 +1,6 @@
 """Development tool: torch.profiler view of the 2D stage: which python lines issue memcpys / syncing ops per pair."""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import importlib.util

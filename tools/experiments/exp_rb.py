@@ -1,6 +1,6 @@
 """Development tool: wino3d_rb (two waves per SIMD, row brick) vs wino3d -- bit-exactness and time per launch."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import _lib
 if os.environ.get("DRC_LIB"):

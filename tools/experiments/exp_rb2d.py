@@ -1,6 +1,6 @@
 """Development tool: the 2D row-brick Winograd kernel vs wino2d on the PSMNet feature CNN's layers."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import engine as E
 def one(N, cin, cout, hw, res, reps=20):

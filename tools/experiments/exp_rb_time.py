@@ -1,6 +1,6 @@
 """Development tool: time the rb kernel (default lib or DRC_LIB variant) on the three layer shapes; no checks."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import _lib
 if os.environ.get("DRC_LIB"):

@@ -1,6 +1,6 @@
 """Development tool: stride-1 3x3x3 layers at small unit counts (Config B's quarter-resolution hourglass layers): kernel choices."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import engine as E
 import tools.exp_conv as X

@@ -1,6 +1,6 @@
 """Development tool: time the head kernels (32->1 classifier conv, upsample + softmax + soft-argmin) at the bench batch."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from disprcnn_amd import ops, _lib, engine as E
 from oracle import psmnet_oracle as O

@@ -1,6 +1,6 @@
 """Development tool: per-step s_memtime timeline of the two waves of one SIMD in the ping-pong rb kernel (needs a -DRB_TRACE variant lib)."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from disprcnn_amd import _lib
 _lib.LIB_PATH = os.environ["DRC_LIB"]

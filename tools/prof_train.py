@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from disprcnn_amd import _lib
-if os.environ.get("DRC_LIB"):          # development: a variant library from tools/build_variant2.sh
+if os.environ.get("DRC_LIB"):          # development: a variant library from tools/experiments/build_variant2.sh
     _lib.LIB_PATH = os.environ["DRC_LIB"]
 from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
 from disprcnn_amd.utils import synth
