@@ -47,24 +47,32 @@ def build_model(dev, maxdisp, mindisp, bn_case):
     return model.to(dev).eval(), sd
 
 
-def cpu_baseline_config_a(sd, budget_s=12.0):
-    """The CPU oracle (torch-CPU restatement, verified against the reference's outputs) on a bounded sample."""
+def cpu_baseline_config_a(sd, batches=(1, 16, 64), warmups=2, runs=5):
+    """The CPU oracle (torch-CPU restatement, verified against the reference's outputs) timed as SURVEY 8d prescribes: fp32, no_grad,
+    every host thread torch has (stated), for N in {1, 16, 64} ROI pairs: 2 warm-ups, median of 5 runs.  `value` = the best batch's rate."""
+    import statistics
+
     from oracle import psmnet_oracle as O
     from disprcnn_amd.utils import synth
     threads = torch.get_num_threads()
-    fl, fr = synth.synth_features(4, 32, 28, 28, tag="cpu")
+    per, spent, total = {}, 0.0, 0
     with torch.no_grad():
-        O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)          # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)
-            n += 4
-            el = time.perf_counter() - t0
-            if el >= budget_s:
-                break
-    return {"value": n / el, "unit": "ROI cost-volumes/s", "cores": threads, "kind": "port",
-            "sample": f"{n} ROI pairs (batches of 4) of the same Config-A workload, {el:.1f} s wall, torch-CPU fp32 oracle"}
+        for nb in batches:
+            fl, fr = synth.synth_features(nb, 32, 28, 28, tag="cpu")
+            for _ in range(warmups if nb < 64 else 1):               # (64 pairs take seconds per run: one warm-up there)
+                O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)
+            ts = []
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)
+                ts.append(time.perf_counter() - t0)
+            med = statistics.median(ts)
+            per[str(nb)] = {"roi_pairs_per_s": round(nb / med, 2), "median_s": round(med, 4), "runs": runs}
+            spent += sum(ts); total += nb * runs
+    best = max(per, key=lambda k: per[k]["roi_pairs_per_s"])
+    return {"value": per[best]["roi_pairs_per_s"], "unit": "ROI cost-volumes/s", "cores": threads, "kind": "port", "per_batch": per,
+            "sample": (f"Config-A workload, torch-CPU fp32 oracle, batches of {', '.join(map(str, batches))} ROI pairs: 2 warm-ups (1 at 64), median of "
+                       f"{runs} runs each; value = the best batch ({best}); {total} ROI pairs in {spent:.1f} s of timed CPU work")}
 
 
 def timed_steps(step, steps, warmup, world, sync):
@@ -212,7 +220,7 @@ def main():
         # HBM bytes per launch of the same kernel from the committed PMC pass of this command (profiles/collect.sh):
         # FETCH_SIZE (x2: gfx950 128-B request correction) + WRITE_SIZE; null if that profile is absent
         traffic, traffic_src = None, "no committed PMC pass"
-        for prof in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for prof in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 key = [k for k in tj if k.replace(" ", "") == dom.replace(" ", "")]
@@ -245,12 +253,14 @@ def main():
         # tails amortise with the batch; 288 GB of HBM hold far more than 1024 ROIs' activations (1.6 GB)
         if not args.no_extra:
             bs = {}
-            for nb in (256, 512):
+            for nb in (16, 64, 256, 512):
                 if nb >= N:
                     continue
                 with torch.no_grad():
                     tb_ = _time(lambda: model.forward_from_features(fl[:nb], fr[:nb], (112, 112)), 2, 5)
-                bs[str(nb)] = {"roi_pairs_per_s": round(nb / tb_, 1), "ms_per_step": round(tb_ * 1e3, 3)}
+                plans = model._rt._ws[("3d", nb, 12, 28, 28)]["p"]          # the launch heuristics depend on the batch: name what ran
+                bs[str(nb)] = {"roi_pairs_per_s": round(nb / tb_, 1), "ms_per_step": round(tb_ * 1e3, 3),
+                               "kernels": {k: plans[k].kname for k in ("dres1.0", "hg1.conv1", "hg1.conv2", "hg1.conv4", "hg1.conv5")}}
             extra["batch_sensitivity_rois_per_step"] = bs
 
     # ---- extras.  The train step is the only one with a collective (one flat gradient all-reduce): EVERY rank enters it.
@@ -363,6 +373,7 @@ def train_step_extra(dev, model_a, world):
 
 
 def rank0_extras(dev, extra):
+    from disprcnn_amd import engine as E
     from disprcnn_amd.utils import synth
     # ---- Config B (224x224, D=96, full PSMNet incl. the 2D feature CNN), 16 ROI pairs per step
     mB, _ = build_model(dev, 48, -48, "B")
@@ -388,26 +399,17 @@ def rank0_extras(dev, extra):
     with torch.no_grad():
         out16 = mB((l64, r64))
         t16 = _time(lambda: mB((l64, r64)), 1, 3)
-    # ... and with the 2D feature CNN on fp16-storage tensors as well (PSMNet.feature_storage = "f16", opt-in: round 3)
-    mB.feature_storage = "f16"
-    with torch.no_grad():
-        out16f = mB((l64, r64))
-        t16f = _time(lambda: mB((l64, r64)), 1, 3)
-    mB.feature_storage = "f32"
     mB.regressor_storage = "f32"
     with torch.no_grad():
         ref64 = mB((l64, r64))
         err16 = (out16 - ref64).abs().mean().item()
-        err16f = (out16f - ref64).abs().mean().item()
-    del ref64, out16f
+    del ref64
     extra["stress_64roi_224x224x96_f16_storage"] = {"roi_pairs_per_s": round(64 / t16, 1), "ms_per_64_roi_image": round(t16 * 1e3, 2),
                                                     "regressor_direct_conv_equivalent_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / t16 / 1e12, 1),
                                                     "mean_abs_err_px_vs_f32_path": round(err16, 4),
                                                     "dtype": "f16 storage / f32 accumulate (v_mfma_f32_16x16x32_f16) for cost volume + 3D regressor; 2D CNN f32"}
-    extra["stress_64roi_224x224x96_f16_storage_all"] = {
-        "roi_pairs_per_s": round(64 / t16f, 1), "ms_per_64_roi_image": round(t16f * 1e3, 2), "mean_abs_err_px_vs_f32_path": round(err16f, 4),
-        "dtype": "f16 storage / f32 accumulate for the 2D feature CNN too (conv16t.hip LDS tiles + conv16.hip + ops16.hip); opt-in: the fp16 "
-                 "rounding of the 60-layer 2D CNN is amplified by the regressor (error above), the SURVEY 8c bound holds for the mode above only"}
+    # (the opt-in all-fp16 mode, PSMNet.feature_storage = "f16", is not reported here: its error vs the fp32 path -- 0.34 px, tests/test_hip_f16.py --
+    # is outside the bound a throughput figure may be quoted under)
     del l64, r64, out16
     # ---- BASELINE configs[1] -- one stereo pair 2x3x375x1242 through ResNet-50-FPN (2D stage trunk) plus the
     # disparity stage on 16 ROIs/image (device-side ROI pairing + ROIAlign crops + full PSMNet at 224^2 / D=96)
@@ -441,17 +443,28 @@ def rank0_extras(dev, extra):
     with torch.no_grad():
         tp = _time(pair_step, 2, 5)
         tbb = _time(lambda: bb(pair), 1, 5)
+        # flops the pair's launches EXECUTE on the matrix cores: each plan's algorithmic conv flops x its kernel's ratio (Winograd
+        # F(2x2x2,3x3x3) runs 64 multiplies where the direct form needs 216, F(2x2,3x3) 16 of 36)
+        E.TIMING = []
+        pair_step()
+        torch.cuda.synchronize()
+        fl_exec = sum(f * (64.0 / 216.0 if k.startswith("wino3d") else 16.0 / 36.0 if k.startswith("wino2d") else 1.0) for k, f, _, _ in E.TIMING)
+        fl_timed = sum(f for _, f, _, _ in E.TIMING)
+        E.TIMING = None
     fl_pair = FLOPS_BACKBONE_PAIR + fl_b
     extra["kitti_pair_r50fpn_plus_16roi"] = {
         "stereo_pairs_per_s": round(1.0 / tp, 2), "ms_per_pair": round(tp * 1e3, 2), "backbone_ms": round(tbb * 1e3, 2),
         "backbone_tflops": round(FLOPS_BACKBONE_PAIR / tbb / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(fl_pair / tp / 1e12, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(fl_pair / tp / 1e12 / PEAK_F32_TFLOPS, 4),
+                     "executed_frac": round(fl_exec / tp / 1e12 / PEAK_F32_TFLOPS, 4),
+                     "executed_flops_per_pair": fl_exec, "conv_flops_of_the_timed_launches": fl_timed,
                      "flops_per_pair": fl_pair,
                      "note": ("whole stereo-pair pipeline, direct-convolution-equivalent conv flops (SURVEY 8a/8d: backbone 250.3 G + 16 x "
-                              "(2 x 22.19 G 2D CNN + 48.51 G regressor)) / wall time; an upper bound on the executed MFMA fraction because the "
-                              "Winograd layers execute 64/216 (3D) and 16/36 (2D) of their share; per-kernel MFMA-busy and HBM bytes: "
-                              "profiles/r3_pair_backbone_*.md, r3_configB_*.md")},
+                              "(2 x 22.19 G 2D CNN + 48.51 G regressor)) / wall time = `frac`, NOT an executed fraction: the Winograd layers execute 64/216 "
+                              "(3D) and 16/36 (2D) of their share.  `executed_frac` = the flops the launches actually execute on the matrix cores "
+                              "(per-launch conv flops x the kernel's Winograd ratio, summed over one pair) / wall time / peak; per-kernel MFMA-busy and "
+                              "HBM bytes: profiles/r4_pair_backbone_*.md, r4_configB_*.md")},
         "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
     del bb, det, mB
     # ---- the 2D stage in front of the path: DispRCNN = R-50-FPN trunk + Stereo RPN + stereo box head + mask head on the pair

@@ -79,8 +79,8 @@ def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn):
 
 
 def test_config_a_bench_batch_distinct_rois_vs_oracle_subset(dev):
-    """One bench-sized step on DISTINCT synthetic ROI pairs (the bench's own inputs, bench.DEFAULT_ROIS of them); a sampled subset
-    of ROIs is checked against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py).  The round-1 batch of 256
+    """One bench-sized step on DISTINCT synthetic ROI pairs (the bench's own inputs, bench.DEFAULT_ROIS of them); 64 ROIs spread over the
+    batch are checked against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py).  The round-1 batch of 256
     is checked the same way: the launch heuristics depend on the batch."""
     import bench
     sd = state_for("A")
@@ -90,13 +90,40 @@ def test_config_a_bench_batch_distinct_rois_vs_oracle_subset(dev):
         with torch.no_grad():
             pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
         _assert_bench_kernels(m._rt._ws[("3d", N, 12, 28, 28)])
-        pick = [0, 37, N // 2, N - 1]
+        pick = sorted({int(i) for i in torch.linspace(0, N - 1, 64).round().tolist()} | {0, 37, N // 2, N - 1})
         with torch.no_grad():
             ref = O.psmnet_from_features(sd, fl[pick], fr[pick], 48, 0, 112, 112)
         err = (pred[pick] - ref).abs()
-        print(f"N={N} subset mean/max err px", err.mean().item(), err.max().item())
+        print(f"N={N}: {len(pick)} distinct ROIs, mean/max err px", err.mean().item(), err.max().item())
         assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (N, err.mean().item(), err.max().item())
+        assert err.reshape(len(pick), -1).mean(1).max().item() < 1e-3          # ... for every single ROI, not only on average
         assert torch.isfinite(pred).all() and pred.min() >= 0 and pred.max() <= 47
+
+
+# the plans of one image's ROIs (BASELINE configs[1]: 16 ROIs) and of four images': what bench.py's batch_sensitivity entries run
+SMALL_BATCH_PLANS = {
+    16: {"dres1.0": "wino3d_rb_kernel<14>", "hg1.conv1": "downdirect_kernel<7,4>", "hg1.conv2": "tapdirect_kernel<7,1>", "hg1.conv4": "tapdirect_kernel<7,1>"},
+    64: {"dres1.0": "wino3d_rb_kernel<14>", "hg1.conv1": "downdirect_kernel<7,4>", "hg1.conv2": "wino3d_kernel<2>", "hg1.conv4": "tapdirect_kernel<7,1>"},
+}
+
+
+@pytest.mark.parametrize("N", [16, 64])
+def test_config_a_small_batches_vs_oracle_and_plan_names(dev, N):
+    """Config A at the batch of ONE image (16 ROIs, BASELINE configs[1]) and of four: every ROI against the CPU oracle, and the kernels the
+    launch heuristics pick there (they differ from the bench batch's: fewer tile groups than CUs on the half-resolution maps)."""
+    sd = state_for("A")
+    m = _model(dev, "A", 48, 0)
+    fl, fr = synth.synth_features(N, 32, 28, 28, tag=f"small{N}")
+    with torch.no_grad():
+        pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
+        ref = O.psmnet_from_features(sd, fl, fr, 48, 0, 112, 112)
+    err = (pred - ref).abs()
+    print(f"N={N}: all ROIs, mean/max err px", err.mean().item(), err.max().item())
+    assert err.mean().item() < 1e-3 and err.max().item() < 2e-2 and err.reshape(N, -1).mean(1).max().item() < 1e-3
+    plans = m._rt._ws[("3d", N, 12, 28, 28)]["p"]
+    got = {k: plans[k].kname for k in SMALL_BATCH_PLANS[N]}
+    print(f"N={N} plans:", {k: pl.kname for k, pl in plans.items()})
+    assert got == SMALL_BATCH_PLANS[N], got
 
 
 def test_config_b_golden_replicated_to_16_crops(dev):

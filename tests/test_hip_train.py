@@ -97,12 +97,45 @@ def test_train_forward_images_vs_reference_golden(dev):
     assert abs(loss.item() - float(z["Bt_loss"])) < 2e-3 * float(z["Bt_loss"])
 
 
+def _fp32_noise_floor(loss_fn, sd, extra_inputs, ref64):
+    """What the REFERENCE graph itself loses in fp32: the oracle's autograd run in float32 against its float64 run (ref64: name -> grad),
+    per tensor -> {name: (max-norm error, 1 - cosine)}.  The whole-net gradient bounds below are stated against this floor: a batch-stat-BN
+    net at batch 2 amplifies last-ulp differences through ReLU-mask flips, differently in every tensor."""
+    d = {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v.clone())
+         for k, v in sd.items()}
+    for k, v in extra_inputs.items():
+        d[k] = v.clone().float().requires_grad_(True)
+    loss_fn(d).backward()
+    out = {}
+    for k, g64 in ref64.items():
+        if d[k].grad is None:
+            continue
+        g32, g64 = d[k].grad.double().reshape(-1), g64.reshape(-1)
+        cos = torch.dot(g32, g64).item() / (g32.norm().item() * g64.norm().item() + 1e-300)
+        out[k] = ((g32 - g64).abs().max().item() / (g64.abs().max().item() + 1e-300), 1.0 - cos)
+    return out
+
+
+def _check_grad(got, ref, name, floor, err_bar=5e-3, cos_bar=1e-4, slack=4.0):
+    """Per tensor: max-norm error <= 5e-3 and 1 - cosine <= 1e-4 -- or, where the reference graph's own fp32 run is worse than a quarter of
+    that (floor), `slack` times its distance from fp64.  A 1 % wiring error in any layer is 2x..10x outside either bound."""
+    got, ref = got.detach().cpu().double().reshape(-1), ref.reshape(-1)
+    cos = torch.dot(got, ref).item() / (got.norm().item() * ref.norm().item() + 1e-300)
+    err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-300)
+    f_err, f_cos = floor.get(name, (0.0, 0.0))
+    assert err <= max(err_bar, slack * f_err), (name, "max-norm error", err, "fp32 floor of the reference graph", f_err)
+    assert 1.0 - cos <= max(cos_bar, slack * f_cos), (name, "1 - cosine", 1.0 - cos, "fp32 floor", f_cos)
+    return err
+
+
 def test_backward_from_features_vs_oracle_autograd(dev):
     """loss.backward() through the HIP engine (BN-train backward, dgrad via the forward engine, MFMA wgrad, classifier /
     soft-argmin / cost-volume adjoints) vs torch autograd of the CPU oracle run in fp64.
-    A 26-layer batch-stat-BN net amplifies fp32 rounding through ReLU-mask flips (one flipped voxel moves a small layer's
-    gradient by several 1e-2 of its max), so the bar is: per tensor cosine >= 0.9995 and max-norm error <= 1e-1, and the MEDIAN
-    max-norm error over all tensors <= 1e-3 (measured 2e-4).  Single sites are pinned to 2e-4 in the per-site test."""
+    Per tensor (_check_grad): max-norm error <= 5e-3 and cosine >= 0.9999 -- unless the reference graph's OWN fp32 run (the oracle's
+    autograd in float32, computed here) is further than a quarter of that from fp64 for that tensor, then four times its distance: a
+    26-layer batch-stat-BN net amplifies fp32 rounding through ReLU-mask flips, one flipped voxel moves a small layer's gradient by
+    several 1e-2 of its max.  The MEDIAN max-norm error over all tensors <= 1e-3 (measured 2e-4).  Single sites are pinned to 2e-4 in the
+    per-site test."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
     from disprcnn_amd.utils.loss_utils import PSMLoss
     sd = state_for("At")
@@ -126,36 +159,30 @@ def test_backward_from_features_vs_oracle_autograd(dev):
     rloss.backward()
     assert abs(loss.item() - rloss.item()) < 1e-5 * abs(rloss.item())
     named = dict(m.named_parameters())
+    floor = _fp32_noise_floor(lambda d: O.psm_loss(O.psmnet_from_features(d, d["__l"], d["__r"], 48, 0, 112, 112, training=True), tgt.to(d["__l"].dtype), mask),
+                              sd, {"__l": fl, "__r": fr}, {**{k: v.grad for k, v in sdr.items() if torch.is_tensor(v) and v.requires_grad},
+                                                           "__l": rl.grad, "__r": rr.grad})
     errs = []
-
-    def check(got, ref, what):
-        got, ref = got.detach().cpu().double().reshape(-1), ref.reshape(-1)
-        cos = torch.dot(got, ref).item() / (got.norm().item() * ref.norm().item() + 1e-300)
-        err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-300)
-        assert cos >= 0.9995 and err <= 1e-1, (what, cos, err)
-        errs.append(err)
-
     for k, v in sdr.items():
         if not (torch.is_tensor(v) and v.requires_grad) or k.startswith("feature_extraction"):
             continue
         assert named[k].grad is not None, k
-        check(named[k].grad, v.grad, k)
+        errs.append(_check_grad(named[k].grad, v.grad, k, floor))
     assert len(errs) == 514 - 361 - sum(1 for k in sd if not k.startswith("feature_extraction") and k.endswith(("running_mean", "running_var", "num_batches_tracked")))
-    check(gl.grad, rl.grad, "left features")
-    check(gr.grad, rr.grad, "right features")
+    _check_grad(gl.grad, rl.grad, "__l", floor)
+    _check_grad(gr.grad, rr.grad, "__r", floor)
     errs.sort()
+    print("Config A whole-net gradients: median / max max-norm error", errs[len(errs) // 2], errs[-1])
     assert errs[len(errs) // 2] <= 1e-3, errs[len(errs) // 2]
 
 
 def test_full_psmnet_backward_vs_reference_gradients(dev):
     """Train step on image crops: loss.backward() through 2D CNN (both views), cost volume and regressor on the HIP engine,
     against (a) the gradient samples the REFERENCE itself recorded (tests/golden Bt_g:*), (b) the fp64 oracle's autograd
-    for every parameter.
-
-    Tolerances.  This ~90-layer batch-stat-BN net at batch 2 is ill conditioned in fp32: a last-ulp change in one batch
-    statistic flips ReLU masks downstream, and the reference's OWN fp32 gradients sit 2e-3..6e-3 * max|g| away from the fp64
-    restatement of the same graph (measured when the fixture was made).  So: loss to 1e-5 relative; sampled reference
-    gradients to 2e-2 * max|ref|; per-parameter cosine with the fp64 oracle >= 0.98 and median max-norm error <= 2e-2.
+    for every parameter, with the per-tensor bound of _check_grad (5e-3 / cosine 0.9999, or four times what the reference graph's own
+    fp32 run differs from fp64 where that is worse -- this ~90-layer batch-stat-BN net at batch 2 flips ReLU masks on last-ulp changes of a
+    batch statistic; the worst tensor is SPP branch1, whose BatchNorm sees 2 samples per channel).  Loss to 1e-5 relative; sampled
+    reference gradients to 2e-2 * max|ref| (the reference's own fp32 run sits 2e-3..6e-3 from fp64 there).
     The per-site tests below pin every backward kernel to 2e-4 on well conditioned single layers."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
     from disprcnn_amd.utils.loss_utils import PSMLoss
@@ -186,18 +213,18 @@ def test_full_psmnet_backward_vs_reference_gradients(dev):
                else (v.to(dt) if v.is_floating_point() else v)) for k, v in sd.items()}
     rp = O.psmnet_forward(sdr, left.to(dt), right.to(dt), 48, -48, training=True)
     O.psm_loss(rp, target.to(dt), mask).backward()
+    floor = _fp32_noise_floor(lambda d: O.psm_loss(O.psmnet_forward(d, left.to(d["__x"].dtype), right.to(d["__x"].dtype), 48, -48, training=True),
+                                                   target.to(d["__x"].dtype), mask),
+                              sd, {"__x": torch.zeros(1)}, {k: v.grad for k, v in sdr.items() if torch.is_tensor(v) and v.requires_grad})
     errs = []
     for k, v in sdr.items():
         if not (torch.is_tensor(v) and v.requires_grad):
             continue
-        got = named[k].grad
-        assert got is not None, k
-        got, ref = got.cpu().double().reshape(-1), v.grad.reshape(-1)
-        cos = torch.dot(got, ref).item() / (got.norm().item() * ref.norm().item() + 1e-300)
-        assert cos >= 0.98, (k, cos)      # worst: SPP branch1, whose BatchNorm sees 2 samples per channel (64x64 pool of a 56x56 map)
-        errs.append((got - ref).abs().max().item() / (ref.abs().max().item() + 1e-300))
+        assert named[k].grad is not None, k
+        errs.append(_check_grad(named[k].grad, v.grad, k, floor))
     errs.sort()
     assert len(errs) == sum(1 for _ in m.parameters())
+    print("Config B whole-net gradients: median / max max-norm error", errs[len(errs) // 2], errs[-1])
     assert errs[len(errs) // 2] <= 2e-2, errs[len(errs) // 2]
 
 
