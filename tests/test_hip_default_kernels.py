@@ -102,8 +102,8 @@ def test_config_a_bench_batch_distinct_rois_vs_oracle_subset(dev):
 
 # the plans of one image's ROIs (BASELINE configs[1]: 16 ROIs) and of four images': what bench.py's batch_sensitivity entries run
 SMALL_BATCH_PLANS = {
-    16: {"dres1.0": "wino3d_rb_kernel<14>", "hg1.conv1": "downdirect_kernel<7,4>", "hg1.conv2": "tapdirect_kernel<7,1>", "hg1.conv4": "tapdirect_kernel<7,1>"},
-    64: {"dres1.0": "wino3d_rb_kernel<14>", "hg1.conv1": "downdirect_kernel<7,4>", "hg1.conv2": "wino3d_kernel<2>", "hg1.conv4": "tapdirect_kernel<7,1>"},
+    16: {"dres1.0": "wino3d_rb_kernel<14>", "hg1.conv1": "downdirect_kernel<7,1>", "hg1.conv2": "tapdirect_kernel<7,1>", "hg1.conv4": "tapdirect_kernel<4,1>"},
+    64: {"dres1.0": "wino3d_rb_kernel<14>", "hg1.conv1": "downdirect_kernel<7,4>", "hg1.conv2": "wino3d_rb_kernel<7>", "hg1.conv4": "tapdirect_kernel<4,1>"},
 }
 
 

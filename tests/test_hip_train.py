@@ -131,11 +131,9 @@ def _check_grad(got, ref, name, floor, err_bar=5e-3, cos_bar=1e-4, slack=4.0):
 def test_backward_from_features_vs_oracle_autograd(dev):
     """loss.backward() through the HIP engine (BN-train backward, dgrad via the forward engine, MFMA wgrad, classifier /
     soft-argmin / cost-volume adjoints) vs torch autograd of the CPU oracle run in fp64.
-    Per tensor (_check_grad): max-norm error <= 5e-3 and cosine >= 0.9999 -- unless the reference graph's OWN fp32 run (the oracle's
-    autograd in float32, computed here) is further than a quarter of that from fp64 for that tensor, then four times its distance: a
-    26-layer batch-stat-BN net amplifies fp32 rounding through ReLU-mask flips, one flipped voxel moves a small layer's gradient by
-    several 1e-2 of its max.  The MEDIAN max-norm error over all tensors <= 1e-3 (measured 2e-4).  Single sites are pinned to 2e-4 in the
-    per-site test."""
+    Per tensor (_check_grad): max-norm error <= 1e-4 and 1 - cosine <= 1e-8 (measured on the tempered case: max 5.5e-6, median 2.4e-6) --
+    unless the reference graph's OWN fp32 run (the oracle's autograd in float32, computed here) is further than a quarter of that from
+    fp64 for that tensor, then four times its distance.  Single sites are pinned to 2e-4 in the per-site test."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
     from disprcnn_amd.utils.loss_utils import PSMLoss
     sd = state_for("At")
@@ -167,21 +165,24 @@ def test_backward_from_features_vs_oracle_autograd(dev):
         if not (torch.is_tensor(v) and v.requires_grad) or k.startswith("feature_extraction"):
             continue
         assert named[k].grad is not None, k
-        errs.append(_check_grad(named[k].grad, v.grad, k, floor))
+        errs.append(_check_grad(named[k].grad, v.grad, k, floor, err_bar=1e-4, cos_bar=1e-8))
     assert len(errs) == 514 - 361 - sum(1 for k in sd if not k.startswith("feature_extraction") and k.endswith(("running_mean", "running_var", "num_batches_tracked")))
-    _check_grad(gl.grad, rl.grad, "__l", floor)
-    _check_grad(gr.grad, rr.grad, "__r", floor)
+    _check_grad(gl.grad, rl.grad, "__l", floor, err_bar=1e-4, cos_bar=1e-8)
+    _check_grad(gr.grad, rr.grad, "__r", floor, err_bar=1e-4, cos_bar=1e-8)
     errs.sort()
     print("Config A whole-net gradients: median / max max-norm error", errs[len(errs) // 2], errs[-1])
-    assert errs[len(errs) // 2] <= 1e-3, errs[len(errs) // 2]
+    assert errs[len(errs) // 2] <= 1e-5, errs[len(errs) // 2]
 
 
 def test_full_psmnet_backward_vs_reference_gradients(dev):
     """Train step on image crops: loss.backward() through 2D CNN (both views), cost volume and regressor on the HIP engine,
     against (a) the gradient samples the REFERENCE itself recorded (tests/golden Bt_g:*), (b) the fp64 oracle's autograd
-    for every parameter, with the per-tensor bound of _check_grad (5e-3 / cosine 0.9999, or four times what the reference graph's own
-    fp32 run differs from fp64 where that is worse -- this ~90-layer batch-stat-BN net at batch 2 flips ReLU masks on last-ulp changes of a
-    batch statistic; the worst tensor is SPP branch1, whose BatchNorm sees 2 samples per channel).  Loss to 1e-5 relative; sampled
+    for every parameter, per tensor max-norm error <= 6e-2 and cosine >= 0.98, median <= 1.5e-2, at most 5 % of the tensors beyond
+    2e-2.  These bars are loose on purpose: this ~90-layer batch-stat-BN net at batch 2 flips ReLU masks on last-ulp changes of a batch
+    statistic (the reference graph's own fp32 run sits up to 5e-3 from its fp64 run, a different rounding realisation up to 4e-2: measured
+    here with a per-tensor floor, which does not bound the next realisation; the worst tensor is SPP branch1, whose BatchNorm sees 2
+    samples per channel).  The TIGHT whole-net wiring check is the Config-A test above (every regressor tensor to 1e-4 on the tempered
+    case); the 2D CNN's backward kernels are pinned per site below.  Loss to 1e-5 relative; sampled
     reference gradients to 2e-2 * max|ref| (the reference's own fp32 run sits 2e-3..6e-3 from fp64 there).
     The per-site tests below pin every backward kernel to 2e-4 on well conditioned single layers."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
@@ -213,19 +214,18 @@ def test_full_psmnet_backward_vs_reference_gradients(dev):
                else (v.to(dt) if v.is_floating_point() else v)) for k, v in sd.items()}
     rp = O.psmnet_forward(sdr, left.to(dt), right.to(dt), 48, -48, training=True)
     O.psm_loss(rp, target.to(dt), mask).backward()
-    floor = _fp32_noise_floor(lambda d: O.psm_loss(O.psmnet_forward(d, left.to(d["__x"].dtype), right.to(d["__x"].dtype), 48, -48, training=True),
-                                                   target.to(d["__x"].dtype), mask),
-                              sd, {"__x": torch.zeros(1)}, {k: v.grad for k, v in sdr.items() if torch.is_tensor(v) and v.requires_grad})
     errs = []
     for k, v in sdr.items():
         if not (torch.is_tensor(v) and v.requires_grad):
             continue
         assert named[k].grad is not None, k
-        errs.append(_check_grad(named[k].grad, v.grad, k, floor))
+        errs.append(_check_grad(named[k].grad, v.grad, k, {}, err_bar=6e-2, cos_bar=2e-2))
     errs.sort()
     assert len(errs) == sum(1 for _ in m.parameters())
-    print("Config B whole-net gradients: median / max max-norm error", errs[len(errs) // 2], errs[-1])
-    assert errs[len(errs) // 2] <= 2e-2, errs[len(errs) // 2]
+    beyond = [sum(e > b for e in errs) for b in (5e-3, 2e-2)]
+    print("Config B whole-net gradients: median / max max-norm error", errs[len(errs) // 2], errs[-1], "| tensors beyond 5e-3 / 2e-2:", beyond, "of", len(errs))
+    assert errs[len(errs) // 2] <= 1.5e-2, errs[len(errs) // 2]          # measured: median 8.5e-3, max 3.8e-2, 4 of 259 tensors beyond 2e-2
+    assert beyond[1] <= len(errs) // 20, beyond
 
 
 @pytest.mark.parametrize("n,cin,cout,dims,stride", [(5, 32, 32, (6, 28, 28), 1), (3, 32, 64, (12, 28, 28), 2), (2, 64, 64, (3, 7, 7), 1),
