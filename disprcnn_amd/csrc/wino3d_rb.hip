@@ -102,6 +102,11 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     // "slab" is the (n, depth tile, strip) plane of TH tile rows, tiles run (n, dt, strip, ht, wt) -- everything below sees TW-wide maps
     // whose columns start at strip * 2 TW (the strips share their boundary columns like tiles do).
     const int TD = D2 ? 1 : p.OD >> 1, TH = p.OH >> 1, WS = (p.OW >> 1) / TW;
+    // per-lane quotients by the run-time extents TH, WS, TD: (int)((x + 0.5) * (1 / d)) is exact for 0 <= x < 2^22 (the launcher checks the
+    // row count) and costs 4 vector instructions instead of the ~20 of the generic 32-bit division -- every vector instruction of this kernel
+    // is ~6 cycles taken from the matrix pipe (see rb_sub), and the geometry below runs once per round in every wave
+    const float rcpTH = 1.0f / (float)TH, rcpWS = 1.0f / (float)WS, rcpTD = 1.0f / (float)TD;
+    auto fdiv = [](int x, float rcp) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * rcp); };
     const int tiles = p.N * TD * WS * TH * TW;
     const int rows_total = p.N * TD * WS * TH;
     const int chunks = (tiles + 63) >> 6;
@@ -136,11 +141,13 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         const int R0 = t0 / TW, R = tile / TW;
         q.wt = tile - R * TW;
         int t = R;
-        q.ht = t % TH; t /= TH;
-        q.wt += (t % WS) * TW; t /= WS;             // the tile's column in the whole map
-        q.dt = t % TD;
-        q.n = t / TD;
-        int slot = 2 * (R - R0) + 2 * (R / TH - R0 / TH);
+        const int tq = fdiv(t, rcpTH);                  // = R / TH
+        q.ht = t - tq * TH; t = tq;
+        const int sq = fdiv(t, rcpWS);
+        q.wt += (t - sq * WS) * TW; t = sq;         // the tile's column in the whole map
+        q.n = fdiv(t, rcpTD);
+        q.dt = t - q.n * TD;
+        int slot = 2 * (R - R0) + 2 * (tq - R0 / TH);
         slot = slot > NS - 4 ? NS - 4 : slot;
         q.lds = (unsigned)(slot * SB + g * GS + (tile - R * TW) * 16);
         return q;
@@ -199,10 +206,12 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         int R = R0 + rel;
         R = R > rows_total - 1 ? rows_total - 1 : R;
         int t = R;
-        const int ht = t % TH; t /= TH;
-        const int wg = (t % WS) * TW + wt; t /= WS;     // the item's tile column in the whole map
-        const int dt = t % TD;
-        const int n = t / TD;
+        const int tq = fdiv(t, rcpTH);
+        const int ht = t - tq * TH; t = tq;
+        const int sq = fdiv(t, rcpWS);
+        const int wg = (t - sq * WS) * TW + wt; t = sq;     // the item's tile column in the whole map
+        const int n = fdiv(t, rcpTD);
+        const int dt = t - n * TD;
         if constexpr (CV) {         // byte offset of halo column 0 of feature-map row y = 2ht + h - 1 (+ the channel quad)
             it.goff = (unsigned)((n * cv.n_stride + (int64_t)(2 * ht + h - 1 + cv.pad) * cv.h_stride + gq * 4) * 4);
             it.x0 = 2 * wg - 1; it.d0 = 2 * dt - 1;
@@ -686,6 +695,7 @@ static int rb_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void*
         return -5;                                                              // 32-bit item offsets over the whole batch
     }
     if ((int64_t)p.N * p.OD * p.OH * p.OW / 8 >= (1LL << 31) - 64 || (int64_t)64 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
+    if ((int64_t)p.N * p.OD * p.OH >= (1LL << 23)) return -5;                    // tile rows < 2^22: the kernel's float-reciprocal quotients are exact
     hipStream_t s = (hipStream_t)stream;
     return p.OW == 14 ? launch_rb<7>(p, cv, s) : launch_rb<14>(p, cv, s);
 }
@@ -713,6 +723,7 @@ extern "C" int drc_conv2d_k3_wino_rb_fwd(const drc_tapconv_params* pp, void* str
     if (!drc_conv2d_k3_wino_rb_supported(p.cout_pad, p.OH, p.OW)) return -4;
     if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32)) return -5;
     if ((int64_t)p.N * p.OH * p.OW / 4 >= (1LL << 31) - 64 || (int64_t)16 * p.cb_in * p.cout_pad * 16 >= (1LL << 31)) return -5;
+    if ((int64_t)p.N * p.OH >= (1LL << 23)) return -5;
     hipStream_t s = (hipStream_t)stream;
     return p.OW == 14 ? launch_rb<7>(p, nullptr, s, true) : launch_rb<14>(p, nullptr, s, true);
 }

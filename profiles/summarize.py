@@ -42,7 +42,8 @@ def main(out, tag):
             rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(sum(v) for v in rows.values()) or 1
     cmd = os.environ.get("PROF_CMD", "python bench.py --steps 10 --warmup 3 --no-cpu --no-extra` (plus the instrumented repeat of the same 10 steps)")
-    lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "", f"Command: `{cmd}`" if not cmd.endswith(")") else f"Command: `{cmd}", ""]
+    commit = os.environ.get("PROF_COMMIT", "unknown")
+    lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "", f"Commit: `{commit}`", "", f"Command: `{cmd}`" if not cmd.endswith(")") else f"Command: `{cmd}", ""]
     bl = os.path.join(out, "bench_line.json")
     if os.path.exists(bl):
         lines += ["bench.py line of this run:", "", "```", open(bl).read().strip(), "```", ""]
@@ -56,7 +57,7 @@ def main(out, tag):
     write = load_counters(os.path.join(out, "write_counter_collection.csv"))
     sq = load_counters(os.path.join(out, "sq_counter_collection.csv"))
     lds = load_counters(os.path.join(out, "lds_counter_collection.csv"))
-    lines = [f"# rocprofv3 PMC summary ({tag})", "", "Averages per launch.  FETCH/WRITE in MB (raw KiB counters x 1024 / 1e6); "
+    lines = [f"# rocprofv3 PMC summary ({tag})", "", f"Commit: `{commit}`", "", "Averages per launch.  FETCH/WRITE in MB (raw KiB counters x 1024 / 1e6); "
              "`fetch x2` applies the gfx950 128-B-request correction.", "",
              "| kernel | launches | fetch MB | fetch x2 MB | write MB | avg us | MFMA busy % | clock GHz | waves/SIMD | wait_any % | wait_inst % | active % | LDS conflict % |",
              "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
