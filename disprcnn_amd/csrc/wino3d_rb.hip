@@ -18,7 +18,8 @@
 //     (no registers) half a step ahead;
 //   * the partial depth inverses are two running sums in registers (no LDS parking).
 // The arithmetic and its order are exactly wino3d.hip's: results are BIT-IDENTICAL to drc_conv3d_k3_wino_fwd.
-// LDS: ring 2 x 16 KB + brick 2 x NS slots x (256 * TW) B; NS = 16 for 28x28 maps (144 KB), 28 for 14x14 maps (130 KB).
+// LDS: ring 2 x 16 KB + 2 brick buffers of NS row slots in the bank-conflict-free layout of wino3d_rb_body (NS = 16 for 28x28 maps:
+// 146 KB in all; 28 for 14x14 maps: 136 KB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -42,10 +43,6 @@ __device__ __forceinline__ f32x4 rb_sub(const f32x4 a, const f32x4 b, const f32x
 #define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define RB_WAVES 8
 #define RB_RING_BYTES 32768
-#ifndef RB_PAIR
-#define RB_PAIR 0              // 1: staging items of one column pair, the neighbour's pair fetched with ds_bpermute (half the loads;
-                               //    bit-identical, measured 3-6 % slower: the exchange puts an LDS round trip into every item)
-#endif
 #ifdef RB_ABL_NOBARRIER
 #define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
@@ -78,15 +75,32 @@ namespace {
 // "slice" (no depth butterfly), 16 frequency points, a tile's accumulators go straight from the in-plane inverse to the epilogue.
 // Bit-identical to wino2d.hip.
 template <int TW, bool CV, bool D2>
-__device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, const drc_costvol_src& cv, int NS) {
+__device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, const drc_costvol_src& cv, int NS, int bufb) {
     static_assert(!(CV && D2), "the fused cost volume is a 3D input");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SB = 256 * TW;                   // bytes per row slot: [xw 4][g 4][wt TW] float4
+    // Brick layout (round 4: free of LDS bank conflicts).  A row slot holds [xw 4][tile column wt][quad g] float4 -- the four channel quads of
+    // a (row, column) are one 64-byte cell, so a staging quad-group writes 64 contiguous bytes.  Readers are the 16 lanes x 4 quads of an MFMA
+    // operand: lane (tile j, quad g) reads cell (row of its tile, its column).  For the 16 tiles of a group to hit 16 different 16-byte bank
+    // units in each of ds_read_b128's four lane groups, (a) the cell index has to run linearly with j ACROSS the wrap into the next tile row:
+    // two slots (one tile row further) are PAIR = 2 SB + EX cells apart with (PAIR / 64) % 4 == TW % 4, and a slab boundary, which inserts one
+    // more slot pair, is padded by K cells to a multiple of 4; (b) inside a cell the quad sits at g ^ 2*((linear position >> 2) & 1), the linear
+    // position being wt + TW * (tile rows from the chunk's first) -- writer and reader derive it from (slot, wt) alone.
+    // Simulated over all group alignments (tools/experiments/lds_bank_sim.py): 4.00 LDS cycles per ds_read_b128 (was 8.00: two-way conflicts
+    // on every transformed-row read), 8.0 / 9.1 array cycles per ds_write_b128 for TW = 14 / 7.
+    constexpr int SB = 256 * TW;                   // bytes per row slot
     constexpr int XWS = 64 * TW;                   // bytes per w-frequency plane of a slot
-    constexpr int GS = 16 * TW;                    // bytes per channel quad
+    constexpr int EX = TW % 4 == 2 ? 2 : (TW % 4 == 3 ? 3 : ((TW % 4) + 4 - (8 * TW) % 4) % 4);
+    constexpr int PAIR = 2 * SB + EX * 64;         // bytes from a slot to the slot two further
+    constexpr int KPAD = ((4 - (PAIR / 64) % 4) % 4) * 64;     // bytes added per slab boundary crossed
+    static_assert((PAIR / 64) % 4 == TW % 4 && ((PAIR + KPAD) / 64) % 4 == 0, "brick strides");
     char* const ring = smem;                       // [slab 2][unit = i * 2 + ct_local : 16][g 4][j 16] float4
-    char* const brick = smem + RB_RING_BYTES;      // [buffer 2][NS][SB]
-    const unsigned buf_bytes = (unsigned)NS * SB;
+    char* const brick = smem + RB_RING_BYTES;      // [buffer 2][buf_bytes]
+    const unsigned buf_bytes = (unsigned)bufb;
+    // byte offset of (slot pair, odd slot of the pair, slab boundaries before it, tile column, quad) inside a brick buffer (w-frequency 0)
+    auto cell = [](int pair, int odd, int slabs, int wt, int gq) __attribute__((always_inline)) {
+        const int sw = (((wt + TW * (pair - slabs)) >> 2) & 1) * 2;
+        return (unsigned)(pair * PAIR + odd * SB + slabs * KPAD + wt * 64 + ((gq ^ sw) * 16));
+    };
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -130,7 +144,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 
     // ---- geometry of a round.  Lane: its tile, the LDS offset of its rows inside a brick buffer.  Thread: its (at most two)
     // staging items (row slot, tile column, channel quad): global byte offset of the row's first column, LDS byte offset.
-    struct Geo { int n, dt, ht, wt; bool valid; unsigned lds; };
+    struct Geo { int n, dt, ht, wt; bool valid; unsigned lds01, lds23; };     // lds01 / lds23: the lane's rows 0,1 / 2,3 in a brick buffer
     auto geo_of = [&](int round) __attribute__((always_inline)) {
         Geo q;
         const int chunk = round * nbk + pos;
@@ -147,9 +161,11 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         q.wt += (t - sq * WS) * TW; t = sq;         // the tile's column in the whole map
         q.n = fdiv(t, rcpTD);
         q.dt = t - q.n * TD;
-        int slot = 2 * (R - R0) + 2 * (tq - R0 / TH);
-        slot = slot > NS - 4 ? NS - 4 : slot;
-        q.lds = (unsigned)(slot * SB + g * GS + (tile - R * TW) * 16);
+        const int sl = tq - R0 / TH;                    // slab boundaries between the chunk's first tile row and this one
+        int pair = (R - R0) + sl;
+        pair = pair > NS / 2 - 2 ? NS / 2 - 2 : pair;
+        q.lds01 = cell(pair, 0, sl, tile - R * TW, g);
+        q.lds23 = cell(pair + 1, 0, sl, tile - R * TW, g);
         return q;
     };
     // A staging item = (row slot, tile column wt, channel quad gq), thread t takes items t and t + 512: it loads the row's columns
@@ -158,11 +174,8 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     // one column PAIR with the neighbour's pair fetched by ds_bpermute / DPP -- half the loads, the same time; loads issued a half step
     // ahead or right before the barriers -- the wait is the LDS-DMA ring fill, not the loads; L2-warming touches -- slower: every extra
     // vector-memory instruction costs its issue slot behind the other seven waves' requests.)
-    constexpr bool kPair = RB_PAIR != 0;
-    constexpr int kCols = kPair ? 2 : 4;           // columns an item loads
-    constexpr int PPS = TW + 1 <= 8 ? 8 : 16;      // pair mode: column pairs per slot (padded), slots per wave item
-    constexpr int SPW = 16 / PPS;
-    struct Item { unsigned goff, loff; bool valid, live; int x0, d0; };   // x0, d0 (CV): volume column / slice of the patch origin; live: wave-uniform
+    constexpr int kCols = 4;                       // columns an item loads
+    struct Item { unsigned goff, loff; bool valid; int x0, d0; };   // x0, d0 (CV): volume column / slice of the patch origin
     auto item_of = [&](int round, int k) __attribute__((always_inline)) {
         Item it;
         const int chunk = round * nbk + pos;
@@ -171,27 +184,15 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         const int R0 = t0 / TW, R1 = t1 / TW;
         int nslots = 2 * (R1 - R0) + 2 * (R1 / TH - R0 / TH) + 4;
         nslots = nslots > NS ? NS : nslots;
-        int s0, wt, gq;
-        if constexpr (kPair) {
-            // a wave item (wave + 8k) = one slot of 16 column pairs (TW = 14) or two slots of 8 (TW = 7); lane = pair * 4 + quad, so lane + 4
-            // is the next pair of the same slot; pair TW only feeds its neighbour; every lane of a live wave item loads
-            s0 = (wave + 8 * k) * SPW + (SPW == 2 ? lane >> 5 : 0);
-            const int cp = (lane >> 2) & (PPS - 1);
-            gq = lane & 3;
-            it.valid = s0 < nslots && cp < TW;
-            it.live = __builtin_amdgcn_readfirstlane((wave + 8 * k) * SPW < nslots);
-            wt = cp < TW ? cp : TW;
-        } else {
-            const int q = (int)threadIdx.x + 512 * k;
-            it.valid = q < nslots * TW * 4;
-            it.live = true;
-            s0 = q / (4 * TW);
-            const int rem = q - s0 * (4 * TW);
-            wt = rem >> 2; gq = rem & 3;
-        }
+        const int q = (int)threadIdx.x + 512 * k;
+        it.valid = q < nslots * TW * 4;
+        const int s0 = q / (4 * TW);
+        const int rem = q - s0 * (4 * TW);
+        const int wt = rem >> 2, gq = rem & 3;
         // slot -> (tile row relative to R0, patch row h): two slots per tile row plus two per slab touched
         int s = s0 < nslots ? s0 : nslots - 1;
-        int left = TH - R0 % TH, base = 0, rel = 0, h = 0;
+        const int sc = s;                               // the (clamped) slot itself
+        int left = TH - R0 % TH, base = 0, rel = 0, h = 0, slabs = 0;
         for (;;) {
             const int span = 2 * left + 2;
             if (s < span) {
@@ -201,7 +202,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                 h = s - 2 * rr;
                 break;
             }
-            s -= span; base += left; left = TH;
+            s -= span; base += left; left = TH; ++slabs;
         }
         int R = R0 + rel;
         R = R > rows_total - 1 ? rows_total - 1 : R;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                                   (int64_t)(2 * wg + cls.dw0) * 16 + gq * 4) * 4);
             it.x0 = it.d0 = 0;
         }
-        it.loff = (unsigned)((s0 < NS ? s0 : NS - 1) * SB + gq * GS + (wt < TW ? wt : 0) * 16);
+        it.loff = cell(sc >> 1, sc & 1, slabs, wt, gq);
         return it;
     };
     struct Raw { f32x4 a[kCols], b[kCols]; };
@@ -230,7 +231,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #ifdef RB_ABL_NOSTAGE
         return;
 #endif
-        if (kPair ? !it.live : !it.valid) return;
+        if (!it.valid) return;
         if constexpr (CV) {
             const bool right = cb >= cv.cbi;                                      // wave-uniform
             const char* base = (const char*)((right ? cv.right : cv.left) + (int64_t)(right ? cb - cv.cbi : cb) * cv.cb_stride);
@@ -262,7 +263,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #ifdef RB_ABL_NOSTAGE
         return;
 #endif
-        if (kPair ? !it.live : !it.valid) return;
+        if (!it.valid) return;
         const float sgn = xd == 1 ? 1.f : -1.f;
         f32x4 d[4];
 #pragma unroll
@@ -273,14 +274,6 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
                 d[w].x = __builtin_fmaf(sgn, r.b[w].x, r.a[w].x); d[w].y = __builtin_fmaf(sgn, r.b[w].y, r.a[w].y);
                 d[w].z = __builtin_fmaf(sgn, r.b[w].z, r.a[w].z); d[w].w = __builtin_fmaf(sgn, r.b[w].w, r.a[w].w);
             }
-        }
-        if constexpr (kPair) {          // the next pair's columns from lane + 4 (scalars by value: __builtin_bit_cast on a vector-ELEMENT
-            auto nl = [&](float v) __attribute__((always_inline)) {            // lvalue reads element 0 with this hipcc)
-                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 4) & 63) * 4, __builtin_bit_cast(int, v)));
-            };
-#pragma unroll
-            for (int w = 0; w < 2; ++w) { d[2 + w].x = nl(d[w].x); d[2 + w].y = nl(d[w].y); d[2 + w].z = nl(d[w].z); d[2 + w].w = nl(d[w].w); }
-            if (!it.valid) return;
         }
         char* dst = bb + it.loff;
         *(f32x4*)(dst + 0 * XWS) = RB_SUB(d[0], d[2]);
@@ -316,7 +309,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         }
     // the MFMAs of one half step: frequency rows xh = 2*HALF, 2*HALF+1; tb = the lane's rows in the step's brick buffer,
     // rs = the half step's ring slab + the wave's cout tile + lane
-    auto consume = [&](auto first_tag, auto half_tag, const char* tb, const char* rs, auto&& between) __attribute__((always_inline)) {
+    auto consume = [&](auto first_tag, auto half_tag, const char* tb01, const char* tb23, const char* rs, auto&& between) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int HALF = decltype(half_tag)::value;
         f32x4 wf0[4], wf1[4], ta[4], tb_[4], tc[4], v0[4], v1[4];
@@ -334,9 +327,9 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #pragma unroll
         for (int xw = 0; xw < 4; ++xw) wf0[xw] = *(const f32x4*)(rs + (0 * 4 + xw) * 2048);
 #pragma unroll
-        for (int xw = 0; xw < 4; ++xw) ta[xw] = *(const f32x4*)(tb + (HALF == 0 ? 0 : 1) * SB + xw * XWS);
+        for (int xw = 0; xw < 4; ++xw) ta[xw] = *(const f32x4*)(tb01 + (HALF == 0 ? 0 : 1) * SB + xw * XWS);
 #pragma unroll
-        for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb + 2 * SB + xw * XWS);
+        for (int xw = 0; xw < 4; ++xw) tb_[xw] = *(const f32x4*)(tb23 + xw * XWS);
         }
         __builtin_amdgcn_sched_barrier(0);
         // the staging loads of this half step (8 vector-memory instructions, ~100 issue cycles each behind the other waves' requests) are
@@ -359,7 +352,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         {
         // second row's operands, requested before the first row's MFMAs so that they arrive in their shadow
 #pragma unroll
-        for (int xw = 0; xw < 4; ++xw) tc[xw] = *(const f32x4*)(tb + (HALF == 0 ? 1 : 3) * SB + xw * XWS);
+        for (int xw = 0; xw < 4; ++xw) tc[xw] = *(const f32x4*)((HALF == 0 ? tb01 : tb23) + SB + xw * XWS);
 #pragma unroll
         for (int xw = 0; xw < 4; ++xw) wf1[xw] = *(const f32x4*)(rs + (1 * 4 + xw) * 2048);
         }
@@ -499,13 +492,14 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         const Cursor c1 = advance(c0);
         const bool next_round = c1.round != c0.round;
         if (next_round && c1.round < rounds) { itA = item_of(c1.round, 0); itB = item_of(c1.round, 1); }
-        const char* tb = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds;
+        const char* tb01 = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds01;
+        const char* tb23 = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds23;
         char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
         Raw r;
         RB_MARK(0);
         ring_fill(1, c0.xd, c0.cb, 1);
         RB_MARK(1);
-        consume(first_tag, std::integral_constant<int, 0>{}, tb, rs_lane, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
+        consume(first_tag, std::integral_constant<int, 0>{}, tb01, tb23, rs_lane, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
         RB_MARK(2);
         stage_finish(itA, c1.xd, nb, r);
         RB_MARK(3);
@@ -513,7 +507,7 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         RB_MARK(4);
         ring_fill(0, c1.xd, c1.cb, 0);
         RB_MARK(5);
-        consume(first_tag, std::integral_constant<int, 1>{}, tb, rs_lane + 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
+        consume(first_tag, std::integral_constant<int, 1>{}, tb01, tb23, rs_lane + 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
         RB_MARK(6);
         stage_finish(itB, c1.xd, nb, r);
         RB_MARK(7);
@@ -538,32 +532,44 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 }
 
 template <int TW>
-__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_tapconv_params p, int NS) {
-    wino3d_rb_body<TW, false, false>(p, drc_costvol_src{}, NS);
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_kernel(const drc_tapconv_params p, int NS, int bufb) {
+    wino3d_rb_body<TW, false, false>(p, drc_costvol_src{}, NS, bufb);
 }
 
 template <int TW>
-__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_cv_kernel(const drc_tapconv_params p, const drc_costvol_src cv, int NS) {
-    wino3d_rb_body<TW, true, false>(p, cv, NS);
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino3d_rb_cv_kernel(const drc_tapconv_params p, const drc_costvol_src cv, int NS, int bufb) {
+    wino3d_rb_body<TW, true, false>(p, cv, NS, bufb);
 }
 
 template <int TW>
-__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino2d_rb_kernel(const drc_tapconv_params p, int NS) {
-    wino3d_rb_body<TW, false, true>(p, drc_costvol_src{}, NS);
+__global__ __launch_bounds__(64 * RB_WAVES, 2) void wino2d_rb_kernel(const drc_tapconv_params p, int NS, int bufb) {
+    wino3d_rb_body<TW, false, true>(p, drc_costvol_src{}, NS, bufb);
 }
 
 // slots a 64-tile chunk can touch: two per tile row plus two per slab
-inline int rb_slots(int TW, int TH) {
+inline int rb_slots(int TW, int TH, int* slabs_max_out = nullptr) {
     const int rows_max = 63 / TW + 2;
     int slabs_max = (rows_max - 2) / TH + 2;
     if (slabs_max > rows_max) slabs_max = rows_max;
+    if (slabs_max_out) *slabs_max_out = slabs_max;
     return 2 * rows_max + 2 * slabs_max;
+}
+
+// bytes of one brick buffer in the kernel's layout (wino3d_rb_body: PAIR per two slots + the slab padding), rounded to 256
+inline int rb_buffer_bytes(int TW, int TH) {
+    int slabs_max = 0;
+    const int NS = rb_slots(TW, TH, &slabs_max);
+    const int ex = TW % 4 == 2 ? 2 : (TW % 4 == 3 ? 3 : ((TW % 4) + 4 - (8 * TW) % 4) % 4);
+    const int pair = 2 * 256 * TW + ex * 64;
+    const int kpad = ((4 - (pair / 64) % 4) % 4) * 64;
+    return ((NS / 2) * pair + (slabs_max - 1) * kpad + 255) / 256 * 256;
 }
 
 template <int TW>
 int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_t stream, bool d2 = false) {
     const int NS = rb_slots(TW, p.OH / 2);
-    const size_t lds = RB_RING_BYTES + (size_t)2 * NS * 256 * TW;
+    const int bufb = rb_buffer_bytes(TW, p.OH / 2);
+    const size_t lds = RB_RING_BYTES + (size_t)2 * bufb;
     if (lds > 163840 || NS * TW * 4 > 1024) return -4;
     static bool attr_set = false;                  // idempotent: racing first calls set the same value
     if (!attr_set) {
@@ -580,11 +586,11 @@ int launch_rb(const drc_tapconv_params& p, const drc_costvol_src* cv, hipStream_
     if (per_cg > chunks) per_cg = chunks;
     if (per_cg < 1) per_cg = 1;
     if (d2)
-        hipLaunchKernelGGL((wino2d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
+        hipLaunchKernelGGL((wino2d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS, bufb);
     else if (cv)
-        hipLaunchKernelGGL((wino3d_rb_cv_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, *cv, NS);
+        hipLaunchKernelGGL((wino3d_rb_cv_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, *cv, NS, bufb);
     else
-        hipLaunchKernelGGL((wino3d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS);
+        hipLaunchKernelGGL((wino3d_rb_kernel<TW>), dim3((unsigned)(per_cg * n_cg)), dim3(64 * RB_WAVES), lds, stream, p, NS, bufb);
     return (int)hipGetLastError();
 }
 
@@ -673,7 +679,7 @@ extern "C" int drc_conv3d_k3_wino_rb_supported(int cout_pad, int OD, int OH, int
     if (OW != 14 && OW % 28) return 0;                      // 14-wide maps: TW = 7; multiples of 28: strips of TW = 14 tile columns
     const int TW = OW == 14 ? 7 : 14;
     const int NS = rb_slots(TW, OH / 2);
-    return RB_RING_BYTES + (size_t)2 * NS * 256 * TW <= 163840 && NS * TW * 4 <= 1024;
+    return RB_RING_BYTES + (size_t)2 * rb_buffer_bytes(TW, OH / 2) <= 163840 && NS * TW * 4 <= 1024;
 }
 
 static int rb_fwd(const drc_tapconv_params* pp, const drc_costvol_src* cv, void* stream) {

@@ -192,8 +192,9 @@ def test_conv3d_winograd_kernel_vs_oracle(dev, n, cin, cout, dims, with_res):
     (2, 64, 32, (4, 12, 28), False, True),       # TH = 6 != TW
     (5, 64, 64, (6, 14, 14), True, True),        # hourglass conv2 at half resolution (TW = 7, two cout groups, four channel blocks)
     (1, 32, 32, (2, 28, 28), False, True),       # fewer chunks than blocks, a partial last chunk
-    (4, 40, 64, (4, 6, 28), True, True),         # three channel blocks (one partial), TH = 3: a chunk spans three slabs
-    (2, 32, 32, (4, 8, 56), True, True),         # a 56-wide map (Config B's volume): two strips of 14 tile columns
+    (4, 40, 64, (4, 6, 14), True, True),         # three channel blocks (one partial), TH = 3 on a 14-wide map: a chunk spans four slabs
+    (4, 40, 64, (4, 6, 28), True, False),        # the same on a 28-wide map: 18 row slots of the conflict-free layout exceed the LDS -> wino3d.hip
+    (2, 32, 32, (4, 16, 56), True, True),        # a 56-wide map (Config B's volume): two strips of 14 tile columns
     (1, 16, 64, (2, 56, 84), False, True),       # three strips, TH = 28, one (partial) channel block, two cout groups
     (7, 48, 32, (2, 2, 14), True, False),        # TH = 1: more row slots than the LDS holds -> the engine keeps wino3d.hip
     (2, 32, 32, (4, 20, 20), True, False)])      # a width the row-brick kernel is not built for
