@@ -3,9 +3,10 @@
 # (FETCH_SIZE / WRITE_SIZE / SQ busy + waits, LDS and cache counters for the headline), each pass in its own run, never combined with
 # sys/runtime traces.  Run from the repo root of the authoring container:
 #     git rev-parse HEAD > profiles/.head && gpurun --timeout 2400 -- 'bash profiles/collect_all.sh r4'
-# (the GPU box has no .git: profiles/.head carries the commit the snapshot was taken from; every summary quotes it).  Raw CSVs land in
-# gpurun_out/prof_<tag>_<workload>/ (scratch); profiles/summarize.py writes the committed summaries; profiles/check_profiles.py fails
-# if any <tag>_*_pmc.md came out without rows.
+# (the GPU box has no .git: profiles/.head carries the commit the snapshot was taken from; every summary quotes it).  Raw CSVs stay on the
+# box (/tmp/prof_<tag>_<workload>/: tens of MB per PMC pass, gpurun returns at most 64 MiB); profiles/summarize.py writes the summaries, which
+# are copied to gpurun_out/profiles_<tag>/ -- copy them from there into profiles/ and commit; profiles/check_profiles.py fails if any
+# <tag>_*_pmc.md came out without rows.
 set -u
 TAG=${1:-r4}
 ONLY=${2:-}      # optional: space-separated list of workloads
@@ -17,7 +18,7 @@ PMC_CACHE="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MIS
 run() {   # name, suffix of the summary files, description, full (1: also LDS + cache passes), command...
   if [ -n "$ONLY" ] && [[ " $ONLY " != *" $1 "* ]]; then return; fi
   local name=$1 sfx=$2 desc=$3 full=$4; shift 4
-  local OUT=gpurun_out/prof_${TAG}_$name
+  local OUT=/tmp/prof_${TAG}_$name
   rm -rf "$OUT"; mkdir -p "$OUT"
   local t0=$SECONDS
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- "$@" > "$OUT/trace.log" 2>&1
@@ -40,4 +41,6 @@ run stress16 _stress16 "WHAT=psm16 python tools/prof_pair.py  (configs[3]: 64 RO
 run train _train "N=64 python tools/prof_train.py  (Config A train step from the feature boundary, 64 ROI pairs: fwd + PSMLoss + bwd; 2 + 3 steps, then 3 forward-only passes)" 0 env N=64 python tools/prof_train.py
 run trainB _trainB "N=8 CFG_B=1 python tools/prof_train.py  (Config B train step, full PSMNet on 8 crops 224x224, D=96: fwd + PSMLoss + bwd; 2 + 3 steps)" 0 env N=8 CFG_B=1 python tools/prof_train.py
 python profiles/check_profiles.py "$TAG"
-ls profiles/ | grep "^$TAG"
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_*.md profiles/${TAG}_*.json profiles/${TAG}*.md gpurun_out/profiles_$TAG/ 2>/dev/null
+for w in headline configB pair_backbone stage2d stress16 train trainB; do tail -3 /tmp/prof_${TAG}_$w/trace.log > gpurun_out/profiles_$TAG/$w.trace_tail.log 2>/dev/null; done
+ls gpurun_out/profiles_$TAG | head -40
