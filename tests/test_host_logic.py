@@ -316,3 +316,14 @@ def test_packed_weight_cache_is_tied_to_the_live_parameter():
     del lin, cache, other
     gc.collect()
     assert k not in H._PACKED_W
+
+
+def test_newest_profile_set_is_complete_and_from_one_commit():
+    """VERDICT r3 #9-10: no empty PMC tables, every summary of a round's set from the same commit (profiles/collect_all.sh writes it)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_profiles", os.path.join(root, "profiles", "check_profiles.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check("r4") == []
