@@ -130,6 +130,10 @@ _SIGS = {
     "drc_cost_volume16_from16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv16_k3_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
     "drc_conv16_k3_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_conv16_k3s2_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
+    "drc_conv16_k3s2_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_deconv16_k3s2_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
+    "drc_deconv16_k3s2_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_cost_volume16_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_nms_sorted_fwd": (_I, [_P, _I, C.c_float, _I, _P, _P, _P]),
     "drc_nms_sorted_batch_fwd": (_I, [_P, _I, _I, C.c_float, _I, _P, _P, _P]),

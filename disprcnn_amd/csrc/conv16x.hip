@@ -1,0 +1,476 @@
+// conv16x.hip -- the fp16-storage STRIDE-2 and TRANSPOSED 3x3x3 convolutions with the input tile staged in LDS (gfx950 / CDNA4), round 4.
+//
+//   reference arithmetic: hourglass conv1 / conv3 (convbn_3d k3 s2 p1) and conv5 / conv6 (ConvTranspose3d k3 s2 p1 output_padding 1 + BN),
+//   stackhourglass.py:11-30,35-49; fp16 storage, fp32 accumulation on v_mfma_f32_16x16x32_f16 as in conv16.hip / conv16t.hip (the reference
+//   is fp32-only: this path is held to a stated bound against the fp32 oracle, tests/test_hip_f16.py).
+//
+// Why: these twelve launches of the stress shape (BASELINE configs[3]) ran on conv16.hip's generic tap walk, which reads both MFMA operands
+// from global memory -- MFMA busy 6 %, 3.5 of the regressor's 8.6 ms (profiles/r4_stress16_*).  conv16t.hip's recipe (a block of four waves
+// stages the input rows of its output tile once per channel block with LDS-DMA, every tap reads its B fragment from LDS, weights through
+// the vector-memory path a few taps ahead) carries over with two changes:
+//
+//   * stride 2 (conv16d_kernel): output column j of tap kw reads input column 2j + kw.  A staged input row is split into its even and odd
+//     columns -- two 1-KiB planes, one global_load_lds each (lane (g, v) fetches channels 8g..8g+7 of column 2v + plane: still one 64-byte
+//     line per four lanes) -- so that tap kw reads plane kw & 1 at entry j + (kw >> 1): unit stride over the lanes, no bank conflicts.
+//     Rows: output row r of tap kh reads staged row 2r + kh (2 TR + 1 rows per depth tap); depth taps are staged one at a time.
+//   * transposed (conv16u_kernel): the eight output-parity classes are stride-1 convolutions over the INPUT grid with 1, 2, 4 or 8 taps
+//     (o = 2i - 1 + k: an even output has the single tap k = 1 at i, an odd one k = 2 at i and k = 0 at i + 1).  A block stages the
+//     (TR + 1) x 16 input positions of its tile in the two depth slices i, i + 1 for ALL channel blocks once, then walks the classes:
+//     accumulate the class's taps over the channel blocks, epilogue, store to the strided outputs -- 27 taps per tile in all, one stage.
+//
+// Layouts as in conv16t.hip: activations half[N][C/32][D+2][H+2][W+2][32] (zero halo), weights [tap][cb32][cout_pad][32] fp16
+// (engine.pack_weight16), LDS row = [g 0..3][voxel 0..15][8 halfs].
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define X16_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define X16_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define X16_WAVES 4
+#define X16_COLS 14
+#define X16_WPF 4          // weight sets (taps) requested ahead of their MFMAs
+
+namespace {
+
+typedef const __attribute__((address_space(3))) volatile f16x8 x16_lds_frag;       // (volatile: re-read per tap instead of kept live, as conv16t)
+
+// BN scale / shift, residual, ReLU, fp16 store of one accumulator tile row (shared by both kernels)
+__device__ __forceinline__ f16x4 x16_finish(const f32x4 acc, const f32x4 sc, const f32x4 sh, const f16x4 rv, int relu) {
+    f32x4 v = acc * sc + sh;
+    v.x += (float)rv.x; v.y += (float)rv.y; v.z += (float)rv.z; v.w += (float)rv.w;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    f16x4 hv;
+    hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
+    return hv;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16d_kernel<RW,CT>: Conv3d k3 stride 2 pad 1.  Tile = TR = 4 RW output rows x 14 output columns of one (n, od); wave w owns rows
+// w*RW .. w*RW+RW-1, lane (j, g) output column j (lanes j = 14, 15 compute two columns nobody stores, as in conv16t).
+template <int RW, int CT>
+__global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapconv_params p) {
+    constexpr int TR = RW * X16_WAVES;
+    constexpr int IR = 2 * TR + 1;                     // staged input rows per depth tap
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // [IR][plane 2][1 KiB] + one row of slack
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const _Float16* x = (const _Float16*)p.x;
+    const drc_tap_class cls = p.cls[0];
+    const int n_ct = (p.OW + X16_COLS - 1) / X16_COLS, n_rt = (p.OH + TR - 1) / TR;
+    const int n_cg = p.cout_pad / 16 / CT;
+    const unsigned tiles = (unsigned)p.N * p.OD * n_rt * n_ct * n_cg;   // cout group fastest: neighbouring blocks share the input tile in L2
+    const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride, xc = (int)p.x_cb_stride;
+    const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
+    const int rh = (int)p.r_h_stride, rd_ = (int)p.r_d_stride, rc = (int)p.r_cb_stride;
+    const int Hp = xd / xh, Wp = xh / 32;              // padded input extents (rows / columns): staging clamps to them on ragged tiles
+    const long w_cb = (long)p.cout_pad * 32, w_tap = w_cb * p.cb_in;   // halfs
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, -1, 0x00020000);
+
+    f32x4 acc[RW][CT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's B-fragment offset inside the stage buffer: staged row 2*(wave*RW), plane 0, entry j
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 2 * 2048);
+
+    for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned t = tile, u;
+        u = t / (unsigned)n_cg; const int cg = (int)(t - u * (unsigned)n_cg); t = u;
+        u = t / (unsigned)n_ct; const int c0 = (int)(t - u * (unsigned)n_ct) * X16_COLS; t = u;
+        u = t / (unsigned)n_rt; const int r0 = (int)(t - u * (unsigned)n_rt) * TR; t = u;
+        u = t / (unsigned)p.OD; const int od = (int)(t - u * (unsigned)p.OD);
+        const int n = (int)u;
+        // padded input coordinate of (output o, tap k) = 2 o + first + k; columns of the two planes, clamped into the row
+        int colE = 2 * (c0 + j) + cls.dw0, colO = colE + 1;
+        colE = colE < Wp ? colE : Wp - 1; colO = colO < Wp ? colO : Wp - 1;
+        const _Float16* xn = x + (long)n * p.x_n_stride + g * 8;
+        const unsigned wlo = 2u * (unsigned)(((cg * CT) * 16 + j) * 32 + g * 8);
+        for (int cb = 0; cb < p.cb_in; ++cb) {
+            unsigned wo = 2u * (unsigned)(cb * (int)w_cb);
+            const unsigned wstep = 2u * (unsigned)w_tap;
+            f16x8 wt[X16_WPF + 1][CT];
+            auto wfetch = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    wt[set][ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo + ct * 1024, wo, 0));
+                wo += wstep;
+            };
+#pragma unroll
+            for (int tq = 0; tq < X16_WPF; ++tq) wfetch(tq);           // taps 0..WPF-1 of this channel block (tap order = kd, kh, kw)
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                // ---- stage the IR input rows of depth tap kd, even and odd columns as separate planes (waves take DMAs round robin)
+                const _Float16* src = xn + (cb * xc + (2 * od + cls.dd0 + kd) * xd);
+#pragma unroll
+                for (int i0 = 0; i0 < 2 * IR; i0 += X16_WAVES) {
+                    const int i = i0 + wave;
+                    if (i < 2 * IR) {
+                        int row = 2 * r0 + cls.dh0 + (i >> 1);
+                        row = row < Hp ? row : Hp - 1;
+                        __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (row * xh + ((i & 1) ? colO : colE) * 32)), X16_LDS_PTR(lds + i * 1024), 16, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + lane_b;
+                f16x8 bA[RW], bB[RW];
+                auto bfetch = [&](f16x8 (&bv)[RW], int t9) __attribute__((always_inline)) {
+                    const int kh = t9 / 3, kw = t9 - kh * 3;
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        bv[r] = *(x16_lds_frag*)(bb + ((2 * r + kh) * 2 + (kw & 1)) * 1024 + (kw >> 1) * 16);
+                };
+                auto mfmas = [&](const f16x8 (&bv)[RW], int set) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[set][ct], bv[r], acc[r][ct], 0, 0, 0);
+                };
+                bfetch(bA, 0);
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    const int tap = kd * 9 + t9;
+                    if (t9 + 1 < 9) { if (t9 & 1) bfetch(bA, t9 + 1); else bfetch(bB, t9 + 1); }
+                    if (tap + X16_WPF < 27) wfetch((tap + X16_WPF) % (X16_WPF + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t9 & 1) mfmas(bB, tap % (X16_WPF + 1)); else mfmas(bA, tap % (X16_WPF + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // every wave is done reading the buffer before the next stage's DMA overwrites it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+        // ---- epilogue (fp32 BN / residual / ReLU, fp16 store) and clear
+        const int col = c0 + j;
+        const bool col_ok = j < X16_COLS && col < p.OW;
+        _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride;
+        const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride : nullptr;
+        const int row0 = r0 + wave * RW;
+        const int yl = od * yd_ + row0 * yh + col * 32 + g * 4, rl = od * rd_ + row0 * rh + col * 32 + g * 4;
+        f16x4 rv[RW][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int cot = cg * CT + ct;
+                rv[r][ct] = (f16x4){0, 0, 0, 0};
+                if (res && col_ok && row0 + r < p.OH) rv[r][ct] = *(const f16x4*)(res + rl + (cot >> 1) * rc + r * rh + (cot & 1) * 16);
+            }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int cot = cg * CT + ct;
+            const f32x4 sc = *(const f32x4*)(p.scale + cot * 16 + g * 4);
+            const f32x4 sh = *(const f32x4*)(p.shift + cot * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const f16x4 hv = x16_finish(acc[r][ct], sc, sh, rv[r][ct], p.relu);
+                if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + (cot >> 1) * yc + r * yh + (cot & 1) * 16) = hv;
+                acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16u_kernel<RW,CT>: ConvTranspose3d k3 s2 p1 op1 as its eight output-parity classes (p.cls[0..7] as engine.taps_deconv3d_k3s2 builds
+// them: class (pd, ph, pw) has 1 or 2 taps per dimension, input offsets 0 / 0,1 from `first`, weight index wbase + a wsd + b wsh + c wsw,
+// output offset (pd, ph, pw)).  Tile = TR x 14 positions of the INPUT grid of one (n, id); the block stages rows r0..r0+TR and entries
+// c0..c0+15 of slices id, id+1 for every channel block once: [cb][slice 2][row TR+1][1 KiB].
+template <int RW, int CT, int CBN>
+__global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapconv_params p) {
+    constexpr int TR = RW * X16_WAVES;
+    constexpr int SR = TR + 1;                         // staged rows per slice
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const _Float16* x = (const _Float16*)p.x;
+    const int n_ct = (p.OW + X16_COLS - 1) / X16_COLS, n_rt = (p.OH + TR - 1) / TR;       // (OD, OH, OW = the INPUT grid)
+    const int n_cg = p.cout_pad / 16 / CT;
+    const unsigned tiles = (unsigned)p.N * p.OD * n_rt * n_ct * n_cg;
+    const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride, xc = (int)p.x_cb_stride;
+    const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
+    const int rh = (int)p.r_h_stride, rd_ = (int)p.r_d_stride, rc = (int)p.r_cb_stride;
+    const int Hp = xd / xh, Wp = xh / 32;
+    const long w_cb = (long)p.cout_pad * 32, w_tap = w_cb * p.cb_in;   // halfs
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, -1, 0x00020000);
+    const int first_d = p.cls[0].dd0, first_h = p.cls[0].dh0, first_w = p.cls[0].dw0;     // the same for every class (the input halo)
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 1024);
+
+    for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        unsigned t = tile, u;
+        u = t / (unsigned)n_cg; const int cg = (int)(t - u * (unsigned)n_cg); t = u;
+        u = t / (unsigned)n_ct; const int c0 = (int)(t - u * (unsigned)n_ct) * X16_COLS; t = u;
+        u = t / (unsigned)n_rt; const int r0 = (int)(t - u * (unsigned)n_rt) * TR; t = u;
+        u = t / (unsigned)p.OD; const int id = (int)(t - u * (unsigned)p.OD);
+        const int n = (int)u;
+        // ---- stage: every wave is done with the previous tile's buffer (the barrier that ended it); rows clamped on ragged tiles
+        {
+            int colv = c0 + first_w + j;
+            colv = colv < Wp ? colv : Wp - 1;
+            const _Float16* src = x + (long)n * p.x_n_stride + ((id + first_d) * xd + colv * 32 + g * 8);
+            constexpr int rows = CBN * 2 * SR;
+#if defined(X16_ABL) && (X16_ABL & 4)
+            if (p.relu == 77)
+#endif
+            for (int i = wave; i < rows; i += X16_WAVES) {
+                const int cb = i / (2 * SR), rem = i - cb * (2 * SR), sl = rem / SR;
+                int row = r0 + first_h + (rem - sl * SR);
+                row = row < Hp ? row : Hp - 1;
+                __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (cb * xc + sl * xd + row * xh)), X16_LDS_PTR(lds + i * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + lane_b;
+        const unsigned wlo = 2u * (unsigned)(((cg * CT) * 16 + j) * 32 + g * 8);
+        const int col = c0 + j;
+        const bool col_ok = j < X16_COLS && col < p.OW;
+        const int row0 = r0 + wave * RW;
+        f32x4 sc[CT], sh[CT];                          // BN scale / shift of the tile's cout group: once per tile, not per class
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            sc[ct] = *(const f32x4*)(p.scale + (cg * CT + ct) * 16 + g * 4);
+            sh[ct] = *(const f32x4*)(p.shift + (cg * CT + ct) * 16 + g * 4);
+        }
+        _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride;
+        const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride : nullptr;
+        // A "batch" = (class c, channel block cb): its nd*nh*nw x CT weight fragments.  They are requested ONE BATCH AHEAD (two register
+        // sets, static rotation: the loops are fully unrolled), so that a class never starts with a global-load round trip.
+#ifndef X16_SETS
+#define X16_SETS 2
+#endif
+        constexpr int SETS = CT <= 2 ? X16_SETS : 1;          // (four cout tiles: 8 x 4 fragments are 128 registers already -- fetched at the batch's start)
+        f16x8 wt[SETS][8][CT];
+        auto wfetch = [&](int set, int c, int cb) __attribute__((always_inline)) {
+            const int pd = c >> 2, ph = (c >> 1) & 1, pw = c & 1;
+            const int nd = pd ? 2 : 1, nh = ph ? 2 : 1, nw = pw ? 2 : 1;
+            const drc_tap_class k = p.cls[c];
+#pragma unroll
+            for (int a = 0; a < nd; ++a)
+#pragma unroll
+                for (int b = 0; b < nh; ++b)
+#pragma unroll
+                    for (int e = 0; e < nw; ++e) {
+                        const int widx = k.wbase + a * k.wsd + b * k.wsh + e * k.wsw;
+                        const unsigned wo = 2u * (unsigned)((long)widx * w_tap + cb * w_cb);
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            wt[set][(a * 2 + b) * 2 + e][ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo + ct * 1024, wo, 0));
+                    }
+        };
+        if constexpr (SETS == 2) wfetch(0, 0, 0);
+        // Classes are walked in (pd, ph, pw) order and the two pw classes of a (pd, ph) pair are stored TOGETHER: they are the even and the odd
+        // output columns of the same rows, i.e. the two 64-byte voxels of each 128-byte line.  Stored class by class the half lines reached
+        // the memory side microseconds apart (rocprof: 457 MB fetched for 226 MB of staged input -- read-modify-write of 335 MB of output).
+        f32x4 acc[2][RW][CT];
+        f16x4 rv[2][RW][CT];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int pd = c >> 2, ph = (c >> 1) & 1, pw = c & 1;      // class order of taps_deconv3d_k3s2: (pd, ph, pw) lexicographic
+            const int nd = pd ? 2 : 1, nh = ph ? 2 : 1, nw = pw ? 2 : 1;
+            const int yl = (2 * id + pd) * yd_ + (2 * row0 + ph) * yh + (2 * col) * 32 + g * 4;          // (+ 32 halfs for the odd column)
+            const int rl = (2 * id + pd) * rd_ + (2 * row0 + ph) * rh + (2 * col) * 32 + g * 4;
+            if (pw == 0) {                             // residuals of both classes of the pair, requested ahead of their MFMAs
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < RW; ++r) {
+                            const int cot = cg * CT + ct;
+                            rv[q][r][ct] = (f16x4){0, 0, 0, 0};
+#if defined(X16_ABL) && (X16_ABL & 2)
+                            if (p.relu == 77)
+#endif
+                            if (res && col_ok && row0 + r < p.OH)
+                                rv[q][r][ct] = *(const f16x4*)(res + rl + q * 32 + (cot >> 1) * rc + 2 * r * rh + (cot & 1) * 16);
+                        }
+            }
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[pw][r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < CBN; ++cb) {
+                const int batch = c * CBN + cb;
+#if defined(X16_ABL) && (X16_ABL & 8)
+                if (p.relu == 77)
+#endif
+                if constexpr (SETS == 2) {
+                    if (batch + 1 < 8 * CBN) wfetch((batch + 1) & 1, (batch + 1) / CBN, (batch + 1) % CBN);
+                } else {
+                    wfetch(0, c, cb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < nd; ++a)
+#pragma unroll
+                    for (int b = 0; b < nh; ++b)
+#pragma unroll
+                        for (int e = 0; e < nw; ++e) {
+                            f16x8 bv[RW];
+#pragma unroll
+                            for (int r = 0; r < RW; ++r)
+                                bv[r] = *(x16_lds_frag*)(bb + ((cb * 2 + a) * SR + r + b) * 1024 + e * 16);
+#pragma unroll
+                            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                                for (int ct = 0; ct < CT; ++ct)
+                                    acc[pw][r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[SETS == 2 ? (batch & 1) : 0][(a * 2 + b) * 2 + e][ct], bv[r],
+                                                                                             acc[pw][r][ct], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pw == 1) {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int cot = cg * CT + ct;
+                            const f16x4 hv = x16_finish(acc[q][r][ct], sc[ct], sh[ct], rv[q][r][ct], p.relu);
+#if defined(X16_ABL) && (X16_ABL & 1)
+                            if (p.relu == 77)
+#endif
+                            if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + q * 32 + (cot >> 1) * yc + 2 * r * yh + (cot & 1) * 16) = hv;
+                        }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the buffer is free for the next tile's stage
+    }
+}
+
+template <int RW, int CT>
+int launch_d(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int TR = RW * X16_WAVES;
+    constexpr size_t lds = (size_t)(2 * (2 * TR + 1) * 1024 + 1024);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv16d_kernel<RW, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CT);
+    if (tiles >= (1L << 31)) return -5;
+    long per_cu = (160 * 1024) / (long)lds;
+    if (per_cu > 4) per_cu = 4;
+    long blocks = 256 * per_cu;
+    if (blocks > tiles) blocks = tiles;
+    hipLaunchKernelGGL((conv16d_kernel<RW, CT>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <int RW, int CT, int CBN>
+int launch_u_cb(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int TR = RW * X16_WAVES;
+    constexpr size_t lds = (size_t)CBN * 2 * (TR + 1) * 1024 + 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv16u_kernel<RW, CT, CBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CT);
+    if (tiles >= (1L << 31)) return -5;
+    long per_cu = (160 * 1024) / (long)lds;
+    if (per_cu > 4) per_cu = 4;
+    long blocks = 256 * per_cu;
+    if (blocks > tiles) blocks = tiles;
+    hipLaunchKernelGGL((conv16u_kernel<RW, CT, CBN>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <int RW, int CT>
+int launch_u(const drc_tapconv_params& p, hipStream_t stream) {
+    switch (p.cb_in) {                                 // channel blocks of 32: the regressor has 1 or 2; 3 and 4 cover the layer tests / wider nets
+        case 1: return launch_u_cb<RW, CT, 1>(p, stream);
+        case 2: return launch_u_cb<RW, CT, 2>(p, stream);
+        case 3: return launch_u_cb<RW, CT, 3>(p, stream);
+        case 4: return launch_u_cb<RW, CT, 4>(p, stream);
+        default: return -4;
+    }
+}
+
+bool x16_common_ok(const drc_tapconv_params& p) {
+    return p.cout_pad > 0 && !(p.cout_pad & 15) && p.cb_in > 0 && p.reserved != 1 && p.x_h_stride > 0 && p.x_d_stride % p.x_h_stride == 0 &&
+           p.x_h_stride % 32 == 0;
+}
+
+int x16_check_sizes(const drc_tapconv_params& p) {
+    if ((int64_t)p.cb_in * p.cout_pad * 32 * 27 * 2 >= (1LL << 31)) return -5;          // 32-bit byte offsets inside the weights
+    if (p.x_n_stride * 2 >= (1LL << 31) || p.y_n_stride * 2 >= (1LL << 31) || (p.res && p.r_n_stride * 2 >= (1LL << 31))) return -5;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int drc_conv16_k3s2_tile_supported(const drc_tapconv_params* pp) {
+    if (!pp) return 0;
+    const drc_tapconv_params& p = *pp;
+    const drc_tap_class& k = p.cls[0];
+    if (p.n_classes != 1 || p.in_mul != 2 || p.out_mul != 1) return 0;
+    if (k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 || k.sw != 1) return 0;
+    if (k.out_off_d || k.out_off_h || k.out_off_w) return 0;
+    if (k.wbase != 0 || k.wsw != 1 || k.wsh != 3 || k.wsd != 9) return 0;                 // weights in tap order
+    return p.cout_pad > 0 && !(p.cout_pad & 15) && p.cb_in > 0 && p.reserved != 1;
+}
+
+extern "C" int drc_conv16_k3s2_tile_fwd(const drc_tapconv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (!drc_conv16_k3s2_tile_supported(pp) || !x16_common_ok(p)) return -4;
+    if (int e = x16_check_sizes(p)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ct = p.cout_pad / 16;
+    const bool tall = p.OH >= 12;                       // 8-row tiles (34 KiB per block) when the map has them, else 4-row tiles
+#ifndef X16_D_CT4
+#define X16_D_CT4 1
+#endif
+    if (X16_D_CT4 && ct % 4 == 0) return tall ? launch_d<2, 4>(p, s) : launch_d<1, 4>(p, s);
+    if (ct % 2 == 0) return tall ? launch_d<2, 2>(p, s) : launch_d<1, 2>(p, s);
+    return tall ? launch_d<2, 1>(p, s) : launch_d<1, 1>(p, s);
+}
+
+extern "C" int drc_deconv16_k3s2_tile_supported(const drc_tapconv_params* pp) {
+    if (!pp) return 0;
+    const drc_tapconv_params& p = *pp;
+    if (p.n_classes != 8 || p.in_mul != 1 || p.out_mul != 2) return 0;
+    for (int c = 0; c < 8; ++c) {
+        const drc_tap_class& k = p.cls[c];
+        const int pd = c >> 2, ph = (c >> 1) & 1, pw = c & 1;
+        if (k.nd != (pd ? 2 : 1) || k.nh != (ph ? 2 : 1) || k.nw != (pw ? 2 : 1) || k.sd != 1 || k.sh != 1 || k.sw != 1) return 0;
+        if (k.out_off_d != pd || k.out_off_h != ph || k.out_off_w != pw) return 0;
+        if (k.dd0 != p.cls[0].dd0 || k.dh0 != p.cls[0].dh0 || k.dw0 != p.cls[0].dw0) return 0;
+        if (k.wbase < 0 || k.wbase > 26) return 0;
+    }
+    if (p.cb_in > 4) return 0;                          // (instantiated channel-block counts; wider layers keep conv16.hip)
+    return p.cout_pad > 0 && !(p.cout_pad & 15) && p.cb_in > 0 && p.reserved != 1;
+}
+
+extern "C" int drc_deconv16_k3s2_tile_fwd(const drc_tapconv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (!drc_deconv16_k3s2_tile_supported(pp) || !x16_common_ok(p)) return -4;
+    if (int e = x16_check_sizes(p)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ct = p.cout_pad / 16;
+    const bool tall = p.OH >= 12 && (size_t)p.cb_in * 2 * 9 * 1024 + 1024 <= 80 * 1024;
+#ifndef X16_U_CT4
+#define X16_U_CT4 1
+#endif
+    if (X16_U_CT4 && ct % 4 == 0) return tall ? launch_u<2, 4>(p, s) : launch_u<1, 4>(p, s);
+    if (ct % 2 == 0) return tall ? launch_u<2, 2>(p, s) : launch_u<1, 2>(p, s);
+    return tall ? launch_u<2, 1>(p, s) : launch_u<1, 1>(p, s);
+}

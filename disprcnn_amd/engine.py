@@ -1123,7 +1123,7 @@ def choose_tile16(OH, OW):
     return best[1], best[2]
 
 
-C16_TILE = {"enabled": True}      # stride-1 3x3x3 / 3x3 fp16 layers on the LDS-tiled kernel (conv16t.hip); False: conv16.hip as in round 2
+C16_TILE = {"enabled": True}      # 3x3x3 / 3x3 fp16 layers on the LDS-tiled kernels (conv16t.hip: stride 1; conv16x.hip: stride 2 and transposed, round 4); False: conv16.hip as in round 2
 
 
 class ConvPlan16:
@@ -1160,6 +1160,17 @@ class ConvPlan16:
             self.kname = "conv16t_kernel<%d,%d,%d>" % (rw, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1), classes[0]["n"][0])
             if classes[0]["n"][0] == 3 and x.cb == 1 and p.cout_pad <= 32 and OD >= 4:      # conv16t.hip: the depth-sliding walk
                 self.kname = "conv16s_kernel<%d,%d>" % (rw, p.cout_pad // 16)
+        # round 4 (conv16x.hip): the stride-2 and transposed 3x3x3 layers on LDS tiles too
+        self.tile_x = None
+        if C16_TILE["enabled"] and not self.tile and not dense1:
+            ct = p.cout_pad // 16
+            ctn = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
+            if _lib.lib().drc_conv16_k3s2_tile_supported(C.byref(p)):
+                self.tile_x = "drc_conv16_k3s2_tile_fwd"
+                self.kname = "conv16d_kernel<%d,%d>" % (2 if OH >= 12 else 1, ctn)
+            elif _lib.lib().drc_deconv16_k3s2_tile_supported(C.byref(p)):
+                self.tile_x = "drc_deconv16_k3s2_tile_fwd"
+                self.kname = "conv16u_kernel<%d,%d>" % (2 if OH >= 12 and x.cb * 18 + 1 <= 80 else 1, ctn)
 
     def run(self, x, w16, scale, shift, y, res=None):
         p = self.p
@@ -1186,6 +1197,9 @@ class ConvPlan16:
         if self.tile:
             st = _lib.lib().drc_conv16_k3_tile_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_conv16_k3_tile_fwd")
+        elif self.tile_x:
+            st = getattr(_lib.lib(), self.tile_x)(C.byref(p), _stream_ptr(self.device))
+            _lib.check(st, self.tile_x)
         else:
             st = _lib.lib().drc_conv16_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_conv16_fwd")

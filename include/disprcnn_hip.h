@@ -329,6 +329,15 @@ int drc_bilinear_up_blocked16(const void* x16, void* y16, int N, int CB32, int I
 int drc_cost_volume16_from16(const void* feat16, void* cost16, int N, int right_first_unit, int C, int Dp, int Hp, int Wp, int mindisp4,
                              int maxdisp4, int feat_pad, void* stream);
 int drc_conv16_k3_tile_fwd(const drc_tapconv_params* p, void* stream);
+
+/* Round 4: the same recipe for the stride-2 and the transposed 3x3x3 layers of the fp16-storage regressor (conv16x.hip; hourglass conv1 /
+ * conv3 and conv5 / conv6, stackhourglass.py:11-30): drc_conv16_k3s2_tile_* takes the single-class stride-2 grid (in_mul = 2, canonical
+ * weight order), drc_deconv16_k3s2_tile_* the eight output-parity classes of ConvTranspose3d(k3, s2, p1, op1) (out_mul = 2, the classes in
+ * (pd, ph, pw) order); *_supported returns 1 when the parameter block is one they take, else the caller uses drc_conv16_fwd. */
+int drc_conv16_k3s2_tile_supported(const drc_tapconv_params* p);
+int drc_conv16_k3s2_tile_fwd(const drc_tapconv_params* p, void* stream);
+int drc_deconv16_k3s2_tile_supported(const drc_tapconv_params* p);
+int drc_deconv16_k3s2_tile_fwd(const drc_tapconv_params* p, void* stream);
 /* fp32 features (NCHW if in_blocked_pad < 0, else the fp32 blocked 2D layout with that halo) -> fp16 blocked cost volume
  * [N][2][Dp+2][Hp+2][Wp+2][32] (block 0 = left, block 1 = shifted right; stackhourglass.py:115-128); C <= 32. */
 int drc_cost_volume16_blocked_fwd(const float* left, const float* right, void* cost16, int N, int C, int Dp, int Hp, int Wp,

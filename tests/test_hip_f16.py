@@ -35,7 +35,10 @@ def _h(t):
     (40, 48, 2, False, (6, 10, 18), False), (32, 32, 1, False, (2, 56, 56), True),
     # one input block, <= 32 couts, depth >= 4: the depth-sliding walk (conv16s_kernel), incl. ragged rows / columns and 16 couts
     (32, 32, 1, False, (6, 28, 28), True), (32, 32, 1, False, (5, 20, 17), False), (24, 16, 1, False, (4, 9, 30), True),
-    (32, 32, 1, False, (9, 56, 56), True)])
+    (32, 32, 1, False, (9, 56, 56), True),
+    # round 4 (conv16x.hip): the stress shape's stride-2 / transposed layers at full size, odd input extents, one row / column tiles
+    (32, 64, 2, False, (8, 56, 56), True), (64, 32, 1, True, (4, 28, 28), True), (64, 64, 2, False, (5, 27, 31), False),
+    (32, 16, 1, True, (2, 3, 5), False), (96, 32, 2, False, (4, 8, 8), True), (96, 64, 1, True, (2, 13, 15), True)])
 def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, transposed, dims, with_res):
     from disprcnn_amd import engine as E
     n = 2
@@ -56,6 +59,8 @@ def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, t
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale.to(dev); sh[:cout] = shift.to(dev)
     assert plan.tile == (stride == 1 and not transposed)            # stride-1 layers: the LDS-tiled kernel (conv16t.hip)
+    assert plan.tile_x == (None if plan.tile else ("drc_deconv16_k3s2_tile_fwd" if transposed else "drc_conv16_k3s2_tile_fwd"))    # round 4: conv16x.hip
+    assert plan.kname.startswith("conv16u" if transposed else ("conv16d" if stride == 2 else ("conv16t", "conv16s"))), plan.kname
     assert plan.kname.startswith("conv16s") == (plan.tile and cin <= 32 and cout <= 32 and dims[0] >= 4)
     plan.run(xb, E.pack_weight16(w.to(dev), transposed), sc, sh, yb, rb)
     got = yb.to_dense().cpu()

@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from disprcnn_amd import _lib
+if os.environ.get("DRC_LIB"):          # development: a variant library from tools/experiments/build_variant_any.sh
+    _lib.LIB_PATH = os.environ["DRC_LIB"]
 from types import SimpleNamespace as NS
 from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
 from disprcnn_amd.modeling.backbone import build_backbone
