@@ -420,6 +420,11 @@ int pick(const drc_tapconv_params& p, hipStream_t s) {
 
 }  // namespace
 
+#ifndef T16_X3D
+#define T16_X3D 1
+#endif
+int drc_x16_conv3d_s1_launch(const drc_tapconv_params& p, hipStream_t s);       // conv16x.hip
+
 extern "C" int drc_conv16_k3_tile_supported(const drc_tapconv_params* pp) {
     if (!pp) return 0;
     const drc_tapconv_params& p = *pp;
@@ -453,5 +458,6 @@ extern "C" int drc_conv16_k3_tile_fwd(const drc_tapconv_params* pp, void* stream
         if (p.cout_pad == 32) return tall ? launch_slide<4, 2>(p, s) : launch_slide<2, 2>(p, s);
         return tall ? launch_slide<4, 1>(p, s) : launch_slide<2, 1>(p, s);
     }
+    if (T16_X3D && p.cls[0].nd == 3 && p.reserved != 1) return drc_x16_conv3d_s1_launch(p, s);      // conv16x.hip: cout-split waves, double-buffered stages (round 4)
     return p.cls[0].nd == 3 ? pick<3>(p, s) : pick<1>(p, s);
 }

@@ -24,6 +24,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/disprcnn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,20 +53,28 @@ __device__ __forceinline__ f16x4 x16_finish(const f32x4 acc, const f32x4 sc, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// conv16d_kernel<RW,CT>: Conv3d k3 stride 2 pad 1.  Tile = TR = 4 RW output rows x 14 output columns of one (n, od); wave w owns rows
-// w*RW .. w*RW+RW-1, lane (j, g) output column j (lanes j = 14, 15 compute two columns nobody stores, as in conv16t).
-template <int RW, int CT>
+// conv16d_kernel<RW,CW,ST>: Conv3d k3 pad 1, stride ST = 2 or 1.  The four waves are CW cout tiles x RG = 4/CW row groups; a wave owns ONE
+// 16-channel cout tile and RW output rows (see conv16u_kernel below for why: weights per output through L2).  Tile = TR = RW RG output
+// rows x 14 output columns of one (n, od); lane (j, g) output column j (lanes j = 14, 15 compute two columns nobody stores, as in conv16t).
+// A "stage" = the IR = ST TR + 3 - ST input rows of one (channel block, depth tap) -- at stride 2 the even and the odd columns as separate
+// planes -- and stages are double-buffered: the DMAs and the nine weight fragments of stage s + 1 are issued before the MFMAs of stage s,
+// one barrier per stage.  ST = 1 serves the stride-1 layers with two input blocks or 64 couts (dres0[0], hourglass conv2 / conv4), which
+// conv16t.hip ran with every wave fetching all cout tiles' weights for two or four rows.
+template <int RW, int CW, int ST>
 __global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapconv_params p) {
-    constexpr int TR = RW * X16_WAVES;
-    constexpr int IR = 2 * TR + 1;                     // staged input rows per depth tap
-    extern __shared__ __attribute__((aligned(16))) char lds[];        // [IR][plane 2][1 KiB] + one row of slack
+    constexpr int RG = X16_WAVES / CW;
+    constexpr int TR = RW * RG;
+    constexpr int IR = ST * TR + 3 - ST;               // staged input rows per depth tap
+    constexpr int BUF = (ST * IR + 1) * 1024;          // [IR][plane ST][1 KiB] + one row of slack (entries past 15 of the last row)
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // two stage buffers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wave % CW, rg = wave / CW;
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     const _Float16* x = (const _Float16*)p.x;
     const drc_tap_class cls = p.cls[0];
     const int n_ct = (p.OW + X16_COLS - 1) / X16_COLS, n_rt = (p.OH + TR - 1) / TR;
-    const int n_cg = p.cout_pad / 16 / CT;
+    const int n_cg = p.cout_pad / 16 / CW;
     const unsigned tiles = (unsigned)p.N * p.OD * n_rt * n_ct * n_cg;   // cout group fastest: neighbouring blocks share the input tile in L2
     const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride, xc = (int)p.x_cb_stride;
     const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
@@ -72,14 +82,9 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapco
     const int Hp = xd / xh, Wp = xh / 32;              // padded input extents (rows / columns): staging clamps to them on ragged tiles
     const long w_cb = (long)p.cout_pad * 32, w_tap = w_cb * p.cb_in;   // halfs
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, -1, 0x00020000);
-
-    f32x4 acc[RW][CT];
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // this lane's B-fragment offset inside the stage buffer: staged row 2*(wave*RW), plane 0, entry j
-    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 2 * 2048);
+    const int S = 3 * p.cb_in;                         // stages per tile, (cb, kd) in this order
+    // this lane's B-fragment offset inside a stage buffer: staged row ST*(rg*RW), plane 0, entry j
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + rg * RW * ST * ST * 1024);
 
     for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         unsigned t = tile, u;
@@ -88,112 +93,107 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapco
         u = t / (unsigned)n_rt; const int r0 = (int)(t - u * (unsigned)n_rt) * TR; t = u;
         u = t / (unsigned)p.OD; const int od = (int)(t - u * (unsigned)p.OD);
         const int n = (int)u;
-        // padded input coordinate of (output o, tap k) = 2 o + first + k; columns of the two planes, clamped into the row
-        int colE = 2 * (c0 + j) + cls.dw0, colO = colE + 1;
+        // padded input coordinate of (output o, tap k) = ST o + first + k; columns of the plane(s), clamped into the row
+        int colE = ST * (c0 + j) + cls.dw0, colO = colE + 1;
         colE = colE < Wp ? colE : Wp - 1; colO = colO < Wp ? colO : Wp - 1;
         const _Float16* xn = x + (long)n * p.x_n_stride + g * 8;
-        const unsigned wlo = 2u * (unsigned)(((cg * CT) * 16 + j) * 32 + g * 8);
-        for (int cb = 0; cb < p.cb_in; ++cb) {
-            unsigned wo = 2u * (unsigned)(cb * (int)w_cb);
-            const unsigned wstep = 2u * (unsigned)w_tap;
-            f16x8 wt[X16_WPF + 1][CT];
-            auto wfetch = [&](int set) __attribute__((always_inline)) {
+        const int cot = cg * CW + cw;
+        const unsigned wlo = 2u * (unsigned)((cot * 16 + j) * 32 + g * 8);
+        f16x8 wt[2][9];
+        f32x4 acc[RW];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    wt[set][ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo + ct * 1024, wo, 0));
-                wo += wstep;
-            };
-#pragma unroll
-            for (int tq = 0; tq < X16_WPF; ++tq) wfetch(tq);           // taps 0..WPF-1 of this channel block (tap order = kd, kh, kw)
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                // ---- stage the IR input rows of depth tap kd, even and odd columns as separate planes (waves take DMAs round robin)
-                const _Float16* src = xn + (cb * xc + (2 * od + cls.dd0 + kd) * xd);
-#pragma unroll
-                for (int i0 = 0; i0 < 2 * IR; i0 += X16_WAVES) {
-                    const int i = i0 + wave;
-                    if (i < 2 * IR) {
-                        int row = 2 * r0 + cls.dh0 + (i >> 1);
-                        row = row < Hp ? row : Hp - 1;
-                        __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (row * xh + ((i & 1) ? colO : colE) * 32)), X16_LDS_PTR(lds + i * 1024), 16, 0, 0);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + lane_b;
-                f16x8 bA[RW], bB[RW];
-                auto bfetch = [&](f16x8 (&bv)[RW], int t9) __attribute__((always_inline)) {
-                    const int kh = t9 / 3, kw = t9 - kh * 3;
-#pragma unroll
-                    for (int r = 0; r < RW; ++r)
-                        bv[r] = *(x16_lds_frag*)(bb + ((2 * r + kh) * 2 + (kw & 1)) * 1024 + (kw >> 1) * 16);
-                };
-                auto mfmas = [&](const f16x8 (&bv)[RW], int set) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int r = 0; r < RW; ++r)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[set][ct], bv[r], acc[r][ct], 0, 0, 0);
-                };
-                bfetch(bA, 0);
-#pragma unroll
-                for (int t9 = 0; t9 < 9; ++t9) {
-                    const int tap = kd * 9 + t9;
-                    if (t9 + 1 < 9) { if (t9 & 1) bfetch(bA, t9 + 1); else bfetch(bB, t9 + 1); }
-                    if (tap + X16_WPF < 27) wfetch((tap + X16_WPF) % (X16_WPF + 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (t9 & 1) mfmas(bB, tap % (X16_WPF + 1)); else mfmas(bA, tap % (X16_WPF + 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // every wave is done reading the buffer before the next stage's DMA overwrites it
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int r = 0; r < RW; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // stage s -> buffer `par`: the DMAs (waves take rows round robin) and this wave's nine weight fragments (tap order kd, kh, kw)
+        auto request = [&](int s, int par) __attribute__((always_inline)) {
+            const int cb = s / 3, kd = s - cb * 3;
+            const _Float16* src = xn + (cb * xc + (ST * od + cls.dd0 + kd) * xd);
+            for (int i = wave; i < ST * IR; i += X16_WAVES) {
+                int row = ST * r0 + cls.dh0 + (ST == 2 ? (i >> 1) : i);
+                row = row < Hp ? row : Hp - 1;
+                __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (row * xh + ((ST == 2 && (i & 1)) ? colO : colE) * 32)), X16_LDS_PTR(lds + par * BUF + i * 1024), 16, 0, 0);
             }
+            const unsigned wo = 2u * (unsigned)((long)(kd * 9) * w_tap + cb * w_cb);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+                wt[par][t9] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo, wo + 2u * (unsigned)(t9 * (int)w_tap), 0));
+        };
+        auto half_step = [&](int s, auto PAR) __attribute__((always_inline)) {
+            constexpr int par = decltype(PAR)::value;
+            // stage s has landed (every wave's share: the barrier), and every wave is done reading the other buffer (stage s - 1)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + 1 < S) request(s + 1, par ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + par * BUF + lane_b;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                // the wave's staged rows 0 .. ST RW + 2 - ST, read once for the three row taps: output row r, tap kh reads row ST r + kh
+                // (stride 2: plane kw & 1 at entry j + (kw >> 1); stride 1: entry j + kw)
+                constexpr int NB = ST * RW + 3 - ST;
+                f16x8 bf[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    bf[i] = *(x16_lds_frag*)(bb + (ST == 2 ? (i * 2 + (kw & 1)) * 1024 + (kw >> 1) * 16 : i * 1024 + kw * 16));
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[par][kh * 3 + kw], bf[ST * r + kh], acc[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        request(0, 0);
+        for (int s = 0; s < S; s += 2) {
+            half_step(s, std::integral_constant<int, 0>{});
+            if (s + 1 < S) half_step(s + 1, std::integral_constant<int, 1>{});
         }
-        // ---- epilogue (fp32 BN / residual / ReLU, fp16 store) and clear
+        // ---- epilogue (fp32 BN / residual / ReLU, fp16 store)
         const int col = c0 + j;
         const bool col_ok = j < X16_COLS && col < p.OW;
-        _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride;
-        const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride : nullptr;
-        const int row0 = r0 + wave * RW;
-        const int yl = od * yd_ + row0 * yh + col * 32 + g * 4, rl = od * rd_ + row0 * rh + col * 32 + g * 4;
-        f16x4 rv[RW][CT];
+        _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride + ((cot >> 1) * yc + (cot & 1) * 16 + g * 4);
+        const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride + ((cot >> 1) * rc + (cot & 1) * 16 + g * 4) : nullptr;
+        const int row0 = r0 + rg * RW;
+        const int yl = od * yd_ + row0 * yh + col * 32, rl = od * rd_ + row0 * rh + col * 32;
+        f16x4 rv[RW];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const int cot = cg * CT + ct;
-                rv[r][ct] = (f16x4){0, 0, 0, 0};
-                if (res && col_ok && row0 + r < p.OH) rv[r][ct] = *(const f16x4*)(res + rl + (cot >> 1) * rc + r * rh + (cot & 1) * 16);
-            }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int cot = cg * CT + ct;
-            const f32x4 sc = *(const f32x4*)(p.scale + cot * 16 + g * 4);
-            const f32x4 sh = *(const f32x4*)(p.shift + cot * 16 + g * 4);
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const f16x4 hv = x16_finish(acc[r][ct], sc, sh, rv[r][ct], p.relu);
-                if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + (cot >> 1) * yc + r * yh + (cot & 1) * 16) = hv;
-                acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+        for (int r = 0; r < RW; ++r) {
+            rv[r] = (f16x4){0, 0, 0, 0};
+            if (res && col_ok && row0 + r < p.OH) rv[r] = *(const f16x4*)(res + rl + r * rh);
         }
+        const f32x4 sc = *(const f32x4*)(p.scale + cot * 16 + g * 4);
+        const f32x4 sh = *(const f32x4*)(p.shift + cot * 16 + g * 4);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const f16x4 hv = x16_finish(acc[r], sc, sh, rv[r], p.relu);
+            if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + r * yh) = hv;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // buffer 0 is free for the next tile's first stage
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// conv16u_kernel<RW,CT>: ConvTranspose3d k3 s2 p1 op1 as its eight output-parity classes (p.cls[0..7] as engine.taps_deconv3d_k3s2 builds
-// them: class (pd, ph, pw) has 1 or 2 taps per dimension, input offsets 0 / 0,1 from `first`, weight index wbase + a wsd + b wsh + c wsw,
-// output offset (pd, ph, pw)).  Tile = TR x 14 positions of the INPUT grid of one (n, id); the block stages rows r0..r0+TR and entries
-// c0..c0+15 of slices id, id+1 for every channel block once: [cb][slice 2][row TR+1][1 KiB].
-template <int RW, int CT, int CBN>
+// conv16u_kernel<RW,CW,CBN>: ConvTranspose3d k3 s2 p1 op1 as its eight output-parity classes (p.cls[0..7] as engine.taps_deconv3d_k3s2
+// builds them: class (pd, ph, pw) has 1 or 2 taps per dimension, input offsets 0 / 0,1 from `first`, weight index wbase + a wsd + b wsh +
+// c wsw, output offset (pd, ph, pw)).  Tile = TR x 14 positions of the INPUT grid of one (n, id); the block stages rows r0..r0+TR and
+// entries c0..c0+15 of slices id, id+1 for every channel block once: [cb][slice 2][row TR+1][1 KiB].
+//
+// Who computes what (second form, round 4): the four waves are CW cout tiles x RG = 4/CW row groups; a wave owns ONE 16-channel cout tile
+// and RW rows.  The first form gave every wave RW = 2 rows of ALL cout tiles, so each wave pulled the layer's whole weight set (108 KB for
+// 64 -> 32 channels) through L2 per two rows: 2.65 GB of L2 -> CU traffic per launch of the stress shape, and ablations showed the kernel
+// bound by exactly that (350 us; 232 us with the weights fetched once; the MFMA + LDS skeleton alone 95 us).  One cout tile x seven rows
+// cuts the weight traffic per output 7x (3.5x per launch at CW = 2), and the RW + 1 B fragments of a (slice, column shift) serve both row
+// taps, so LDS reads per MFMA do not grow.
+template <int RW, int CW, int CBN>
 __global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapconv_params p) {
-    constexpr int TR = RW * X16_WAVES;
+    constexpr int RG = X16_WAVES / CW;
+    constexpr int TR = RW * RG;
     constexpr int SR = TR + 1;                         // staged rows per slice
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wave % CW, rg = wave / CW;
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     const _Float16* x = (const _Float16*)p.x;
     const int n_ct = (p.OW + X16_COLS - 1) / X16_COLS, n_rt = (p.OH + TR - 1) / TR;       // (OD, OH, OW = the INPUT grid)
-    const int n_cg = p.cout_pad / 16 / CT;
+    const int n_cg = p.cout_pad / 16 / CW;
     const unsigned tiles = (unsigned)p.N * p.OD * n_rt * n_ct * n_cg;
     const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride, xc = (int)p.x_cb_stride;
     const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapco
     const long w_cb = (long)p.cout_pad * 32, w_tap = w_cb * p.cb_in;   // halfs
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, -1, 0x00020000);
     const int first_d = p.cls[0].dd0, first_h = p.cls[0].dh0, first_w = p.cls[0].dw0;     // the same for every class (the input halo)
-    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 1024);
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + rg * RW * 1024);
 
     for (unsigned tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         unsigned t = tile, u;
@@ -217,9 +217,6 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapco
             colv = colv < Wp ? colv : Wp - 1;
             const _Float16* src = x + (long)n * p.x_n_stride + ((id + first_d) * xd + colv * 32 + g * 8);
             constexpr int rows = CBN * 2 * SR;
-#if defined(X16_ABL) && (X16_ABL & 4)
-            if (p.relu == 77)
-#endif
             for (int i = wave; i < rows; i += X16_WAVES) {
                 const int cb = i / (2 * SR), rem = i - cb * (2 * SR), sl = rem / SR;
                 int row = r0 + first_h + (rem - sl * SR);
@@ -227,30 +224,13 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapco
                 __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (cb * xc + sl * xd + row * xh)), X16_LDS_PTR(lds + i * 1024), 16, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + lane_b;
-        const unsigned wlo = 2u * (unsigned)(((cg * CT) * 16 + j) * 32 + g * 8);
-        const int col = c0 + j;
-        const bool col_ok = j < X16_COLS && col < p.OW;
-        const int row0 = r0 + wave * RW;
-        f32x4 sc[CT], sh[CT];                          // BN scale / shift of the tile's cout group: once per tile, not per class
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            sc[ct] = *(const f32x4*)(p.scale + (cg * CT + ct) * 16 + g * 4);
-            sh[ct] = *(const f32x4*)(p.shift + (cg * CT + ct) * 16 + g * 4);
-        }
-        _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride;
-        const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride : nullptr;
-        // A "batch" = (class c, channel block cb): its nd*nh*nw x CT weight fragments.  They are requested ONE BATCH AHEAD (two register
-        // sets, static rotation: the loops are fully unrolled), so that a class never starts with a global-load round trip.
-#ifndef X16_SETS
-#define X16_SETS 2
-#endif
-        constexpr int SETS = CT <= 2 ? X16_SETS : 1;          // (four cout tiles: 8 x 4 fragments are 128 registers already -- fetched at the batch's start)
-        f16x8 wt[SETS][8][CT];
+        const int cot = cg * CW + cw;
+        const unsigned wlo = 2u * (unsigned)((cot * 16 + j) * 32 + g * 8);
+        // A "batch" = (class c, channel block cb): its nd*nh*nw weight fragments, requested ONE BATCH AHEAD (two register sets, static
+        // rotation: the loops are fully unrolled), so that a class never starts with an L2 round trip.
+        f16x8 wt[2][8];
         auto wfetch = [&](int set, int c, int cb) __attribute__((always_inline)) {
-            const int pd = c >> 2, ph = (c >> 1) & 1, pw = c & 1;
-            const int nd = pd ? 2 : 1, nh = ph ? 2 : 1, nw = pw ? 2 : 1;
+            const int nd = (c >> 2) ? 2 : 1, nh = ((c >> 1) & 1) ? 2 : 1, nw = (c & 1) ? 2 : 1;
             const drc_tap_class k = p.cls[c];
 #pragma unroll
             for (int a = 0; a < nd; ++a)
@@ -260,139 +240,135 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapco
                     for (int e = 0; e < nw; ++e) {
                         const int widx = k.wbase + a * k.wsd + b * k.wsh + e * k.wsw;
                         const unsigned wo = 2u * (unsigned)((long)widx * w_tap + cb * w_cb);
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            wt[set][(a * 2 + b) * 2 + e][ct] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo + ct * 1024, wo, 0));
+                        wt[set][(a * 2 + b) * 2 + e] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlo, wo, 0));
                     }
         };
-        if constexpr (SETS == 2) wfetch(0, 0, 0);
-        // Classes are walked in (pd, ph, pw) order and the two pw classes of a (pd, ph) pair are stored TOGETHER: they are the even and the odd
-        // output columns of the same rows, i.e. the two 64-byte voxels of each 128-byte line.  Stored class by class the half lines reached
-        // the memory side microseconds apart (rocprof: 457 MB fetched for 226 MB of staged input -- read-modify-write of 335 MB of output).
-        f32x4 acc[2][RW][CT];
-        f16x4 rv[2][RW][CT];
+        wfetch(0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const __attribute__((address_space(3))) char* bb = (const __attribute__((address_space(3))) char*)lds + lane_b;
+        const int col = c0 + j;
+        const bool col_ok = j < X16_COLS && col < p.OW;
+        const int row0 = r0 + rg * RW;
+        const f32x4 sc = *(const f32x4*)(p.scale + cot * 16 + g * 4);          // BN scale / shift of the wave's cout tile: once per tile
+        const f32x4 sh = *(const f32x4*)(p.shift + cot * 16 + g * 4);
+        _Float16* y = (_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride + ((cot >> 1) * yc + (cot & 1) * 16 + g * 4);
+        const _Float16* res = p.res ? (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride + ((cot >> 1) * rc + (cot & 1) * 16 + g * 4) : nullptr;
+        // Classes are walked in (pd, ph, pw) order; the two pw classes of a (pd, ph) pair are the even and the odd output columns of the same
+        // rows -- the two 64-byte voxels of each 128-byte line -- and are stored together.
+        f16x4 ov[RW];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int pd = c >> 2, ph = (c >> 1) & 1, pw = c & 1;      // class order of taps_deconv3d_k3s2: (pd, ph, pw) lexicographic
             const int nd = pd ? 2 : 1, nh = ph ? 2 : 1, nw = pw ? 2 : 1;
-            const int yl = (2 * id + pd) * yd_ + (2 * row0 + ph) * yh + (2 * col) * 32 + g * 4;          // (+ 32 halfs for the odd column)
-            const int rl = (2 * id + pd) * rd_ + (2 * row0 + ph) * rh + (2 * col) * 32 + g * 4;
-            if (pw == 0) {                             // residuals of both classes of the pair, requested ahead of their MFMAs
+            const int yl = (2 * id + pd) * yd_ + (2 * row0 + ph) * yh + (2 * col + pw) * 32;
+            const int rl = (2 * id + pd) * rd_ + (2 * row0 + ph) * rh + (2 * col + pw) * 32;
+            f16x4 rv[RW];
+            f32x4 acc[RW];
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int r = 0; r < RW; ++r) {
-                            const int cot = cg * CT + ct;
-                            rv[q][r][ct] = (f16x4){0, 0, 0, 0};
-#if defined(X16_ABL) && (X16_ABL & 2)
-                            if (p.relu == 77)
-#endif
-                            if (res && col_ok && row0 + r < p.OH)
-                                rv[q][r][ct] = *(const f16x4*)(res + rl + q * 32 + (cot >> 1) * rc + 2 * r * rh + (cot & 1) * 16);
-                        }
+            for (int r = 0; r < RW; ++r) {
+                rv[r] = (f16x4){0, 0, 0, 0};
+                if (res && col_ok && row0 + r < p.OH) rv[r] = *(const f16x4*)(res + rl + 2 * r * rh);
+                acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[pw][r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cb = 0; cb < CBN; ++cb) {
                 const int batch = c * CBN + cb;
-#if defined(X16_ABL) && (X16_ABL & 8)
-                if (p.relu == 77)
-#endif
-                if constexpr (SETS == 2) {
-                    if (batch + 1 < 8 * CBN) wfetch((batch + 1) & 1, (batch + 1) / CBN, (batch + 1) % CBN);
-                } else {
-                    wfetch(0, c, cb);
-                }
+                if (batch + 1 < 8 * CBN) wfetch((batch + 1) & 1, (batch + 1) / CBN, (batch + 1) % CBN);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int a = 0; a < nd; ++a)
 #pragma unroll
-                    for (int b = 0; b < nh; ++b)
+                    for (int e = 0; e < nw; ++e) {
+                        f16x8 bf[RW + 1];                              // rows r .. r + RW of (slice a, column shift e): both row taps read them
 #pragma unroll
-                        for (int e = 0; e < nw; ++e) {
-                            f16x8 bv[RW];
+                        for (int i = 0; i < RW + nh - 1; ++i)
+                            bf[i] = *(x16_lds_frag*)(bb + ((cb * 2 + a) * SR + i) * 1024 + e * 16);
+#pragma unroll
+                        for (int b = 0; b < nh; ++b)
 #pragma unroll
                             for (int r = 0; r < RW; ++r)
-                                bv[r] = *(x16_lds_frag*)(bb + ((cb * 2 + a) * SR + r + b) * 1024 + e * 16);
-#pragma unroll
-                            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                                for (int ct = 0; ct < CT; ++ct)
-                                    acc[pw][r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[SETS == 2 ? (batch & 1) : 0][(a * 2 + b) * 2 + e][ct], bv[r],
-                                                                                             acc[pw][r][ct], 0, 0, 0);
-                        }
+                                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wt[batch & 1][(a * 2 + b) * 2 + e], bf[r + b], acc[r], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (pw == 1) {
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int cot = cg * CT + ct;
-                            const f16x4 hv = x16_finish(acc[q][r][ct], sc[ct], sh[ct], rv[q][r][ct], p.relu);
-#if defined(X16_ABL) && (X16_ABL & 1)
-                            if (p.relu == 77)
-#endif
-                            if (col_ok && row0 + r < p.OH) *(f16x4*)(y + yl + q * 32 + (cot >> 1) * yc + 2 * r * yh + (cot & 1) * 16) = hv;
-                        }
+            for (int r = 0; r < RW; ++r) {
+                const f16x4 hv = x16_finish(acc[r], sc, sh, rv[r], p.relu);
+                if (pw == 0) {
+                    ov[r] = hv;
+                } else if (col_ok && row0 + r < p.OH) {
+                    *(f16x4*)(y + yl - 32 + 2 * r * yh) = ov[r];
+                    *(f16x4*)(y + yl + 2 * r * yh) = hv;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the buffer is free for the next tile's stage
     }
 }
 
-template <int RW, int CT>
-int launch_d(const drc_tapconv_params& p, hipStream_t stream) {
-    constexpr int TR = RW * X16_WAVES;
-    constexpr size_t lds = (size_t)(2 * (2 * TR + 1) * 1024 + 1024);
+template <int RW, int CW, int ST>
+int launch_d_rw(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int TR = RW * (X16_WAVES / CW);
+    constexpr size_t lds = (size_t)2 * (ST * (ST * TR + 3 - ST) + 1) * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv16d_kernel<RW, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv16d_kernel<RW, CW, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CT);
+    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CW);
     if (tiles >= (1L << 31)) return -5;
     long per_cu = (160 * 1024) / (long)lds;
     if (per_cu > 4) per_cu = 4;
     long blocks = 256 * per_cu;
     if (blocks > tiles) blocks = tiles;
-    hipLaunchKernelGGL((conv16d_kernel<RW, CT>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
+    hipLaunchKernelGGL((conv16d_kernel<RW, CW, ST>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-template <int RW, int CT, int CBN>
+// Rows per wave (engine.x16_rows mirrors this rule for the plan's kernel name).  Stride 2: the block's two stage buffers stay below 80 KiB
+// (two blocks per CU) with TR <= 8 -- seven rows for one row group, four for two, two for four; stride 1: seven.  The small tile (two
+// rows, one with four row groups at stride 2) when the big one pads the map's rows by more than 25 % over the small one's.
+template <int CW, int ST>
+int launch_d(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int RG = X16_WAVES / CW;
+    constexpr int BIG = ST == 1 ? 7 : (RG == 1 ? 7 : RG == 2 ? 4 : 2), SMALL = (ST == 2 && RG == 4) ? 1 : 2;
+    const int trb = BIG * RG, trs = SMALL * RG;
+    const long padb = (long)((p.OH + trb - 1) / trb) * trb, pads = (long)((p.OH + trs - 1) / trs) * trs;
+    return padb * 4 <= pads * 5 ? launch_d_rw<BIG, CW, ST>(p, stream) : launch_d_rw<SMALL, CW, ST>(p, stream);
+}
+
+template <int RW, int CW, int CBN>
 int launch_u_cb(const drc_tapconv_params& p, hipStream_t stream) {
-    constexpr int TR = RW * X16_WAVES;
+    constexpr int TR = RW * (X16_WAVES / CW);
     constexpr size_t lds = (size_t)CBN * 2 * (TR + 1) * 1024 + 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv16u_kernel<RW, CT, CBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv16u_kernel<RW, CW, CBN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CT);
+    const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CW);
     if (tiles >= (1L << 31)) return -5;
     long per_cu = (160 * 1024) / (long)lds;
     if (per_cu > 4) per_cu = 4;
     long blocks = 256 * per_cu;
     if (blocks > tiles) blocks = tiles;
-    hipLaunchKernelGGL((conv16u_kernel<RW, CT, CBN>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
+    hipLaunchKernelGGL((conv16u_kernel<RW, CW, CBN>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-template <int RW, int CT>
+// rows per wave: seven when the block's TR = 7 RG rows tile the map well and the stage leaves room for two blocks per CU, else two
+template <int CW>
 int launch_u(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int RG = X16_WAVES / CW;
+    const int tr7 = 7 * RG, tr2 = 2 * RG;
+    const bool fits7 = (size_t)p.cb_in * 2 * (tr7 + 1) * 1024 + 1024 <= 80 * 1024;
+    const long pad7 = (long)((p.OH + tr7 - 1) / tr7) * tr7, pad2 = (long)((p.OH + tr2 - 1) / tr2) * tr2;
+    const bool seven = fits7 && pad7 * 4 <= pad2 * 5;                         // (at most 25 % more padded rows than the small tile)
     switch (p.cb_in) {                                 // channel blocks of 32: the regressor has 1 or 2; 3 and 4 cover the layer tests / wider nets
-        case 1: return launch_u_cb<RW, CT, 1>(p, stream);
-        case 2: return launch_u_cb<RW, CT, 2>(p, stream);
-        case 3: return launch_u_cb<RW, CT, 3>(p, stream);
-        case 4: return launch_u_cb<RW, CT, 4>(p, stream);
+        case 1: return seven ? launch_u_cb<7, CW, 1>(p, stream) : launch_u_cb<2, CW, 1>(p, stream);
+        case 2: return seven ? launch_u_cb<7, CW, 2>(p, stream) : launch_u_cb<2, CW, 2>(p, stream);
+        case 3: return seven ? launch_u_cb<7, CW, 3>(p, stream) : launch_u_cb<2, CW, 3>(p, stream);
+        case 4: return seven ? launch_u_cb<7, CW, 4>(p, stream) : launch_u_cb<2, CW, 4>(p, stream);
         default: return -4;
     }
 }
@@ -409,6 +385,16 @@ int x16_check_sizes(const drc_tapconv_params& p) {
 }
 
 }  // namespace
+
+// stride-1 3x3x3 layers, called by drc_conv16_k3_tile_fwd (conv16t.hip) after its own argument checks
+int drc_x16_conv3d_s1_launch(const drc_tapconv_params& p, hipStream_t s) {
+    if (!x16_common_ok(p)) return -4;
+    if (int e = x16_check_sizes(p)) return e;
+    const int ct = p.cout_pad / 16;
+    if (ct % 4 == 0) return launch_d<4, 1>(p, s);
+    if (ct % 2 == 0) return launch_d<2, 1>(p, s);
+    return launch_d<1, 1>(p, s);
+}
 
 extern "C" int drc_conv16_k3s2_tile_supported(const drc_tapconv_params* pp) {
     if (!pp) return 0;
@@ -431,13 +417,9 @@ extern "C" int drc_conv16_k3s2_tile_fwd(const drc_tapconv_params* pp, void* stre
     if (int e = x16_check_sizes(p)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int ct = p.cout_pad / 16;
-    const bool tall = p.OH >= 12;                       // 8-row tiles (34 KiB per block) when the map has them, else 4-row tiles
-#ifndef X16_D_CT4
-#define X16_D_CT4 1
-#endif
-    if (X16_D_CT4 && ct % 4 == 0) return tall ? launch_d<2, 4>(p, s) : launch_d<1, 4>(p, s);
-    if (ct % 2 == 0) return tall ? launch_d<2, 2>(p, s) : launch_d<1, 2>(p, s);
-    return tall ? launch_d<2, 1>(p, s) : launch_d<1, 1>(p, s);
+    if (ct % 4 == 0) return launch_d<4, 2>(p, s);
+    if (ct % 2 == 0) return launch_d<2, 2>(p, s);
+    return launch_d<1, 2>(p, s);
 }
 
 extern "C" int drc_deconv16_k3s2_tile_supported(const drc_tapconv_params* pp) {
@@ -466,11 +448,7 @@ extern "C" int drc_deconv16_k3s2_tile_fwd(const drc_tapconv_params* pp, void* st
     if (int e = x16_check_sizes(p)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int ct = p.cout_pad / 16;
-    const bool tall = p.OH >= 12 && (size_t)p.cb_in * 2 * 9 * 1024 + 1024 <= 80 * 1024;
-#ifndef X16_U_CT4
-#define X16_U_CT4 1
-#endif
-    if (X16_U_CT4 && ct % 4 == 0) return tall ? launch_u<2, 4>(p, s) : launch_u<1, 4>(p, s);
-    if (ct % 2 == 0) return tall ? launch_u<2, 2>(p, s) : launch_u<1, 2>(p, s);
-    return tall ? launch_u<2, 1>(p, s) : launch_u<1, 1>(p, s);
+    if (ct % 4 == 0) return launch_u<4>(p, s);
+    if (ct % 2 == 0) return launch_u<2>(p, s);
+    return launch_u<1>(p, s);
 }

@@ -1126,6 +1126,22 @@ def choose_tile16(OH, OW):
 C16_TILE = {"enabled": True}      # 3x3x3 / 3x3 fp16 layers on the LDS-tiled kernels (conv16t.hip: stride 1; conv16x.hip: stride 2 and transposed, round 4); False: conv16.hip as in round 2
 
 
+def x16_rows(OH, cw, stride, cb=1):
+    """Rows per wave of the conv16x.hip kernels (launch_d / launch_u there): the big tile unless it pads the map's rows by more than
+    25 % over the small one's.  stride 0 = the transposed kernel (big = seven rows if its stage leaves two blocks per CU)."""
+    rg = 4 // cw
+    if stride == 0:
+        big, small = 7, 2
+        if cb * 2 * (7 * rg + 1) * 1024 + 1024 > 80 * 1024:
+            return small
+    elif stride == 1:
+        big, small = 7, 2
+    else:
+        big, small = {1: 7, 2: 4, 4: 2}[rg], (1 if rg == 4 else 2)
+    pad = lambda rw: -(-OH // (rw * rg)) * rw * rg
+    return big if pad(big) * 4 <= pad(small) * 5 else small
+
+
 class ConvPlan16:
     """A resolved conv16 launch (tap-grid classes as in ConvPlan).  dense1: the 32 -> 1 classifier conv, whose single cout is
     written as a dense fp32 [N,D,H,W] volume (+ an optional dense fp32 residual)."""
@@ -1154,23 +1170,25 @@ class ConvPlan16:
         self.flops = 2 * x.N * OD * OH * OW * ntaps * x.C * cout
         self.kname = "conv16_kernel<%d,%d>" % (min(-(-(p.R * p.WT) // 16), 4), 2 if (p.cout_pad // 16) % 2 == 0 else 1)
         self.tile = bool(C16_TILE["enabled"] and _lib.lib().drc_conv16_k3_tile_supported(C.byref(p)))
+        ct = p.cout_pad // 16
+        cw = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)                       # cout tiles side by side in a block of conv16x.hip
         if self.tile:
-            ct = p.cout_pad // 16
             rw = 4 if (OH % 16 == 0 or OH >= 48) else 2
-            self.kname = "conv16t_kernel<%d,%d,%d>" % (rw, 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1), classes[0]["n"][0])
             if classes[0]["n"][0] == 3 and x.cb == 1 and p.cout_pad <= 32 and OD >= 4:      # conv16t.hip: the depth-sliding walk
-                self.kname = "conv16s_kernel<%d,%d>" % (rw, p.cout_pad // 16)
+                self.kname = "conv16s_kernel<%d,%d>" % (rw, ct)
+            elif classes[0]["n"][0] == 3 and not dense1:                                     # conv16x.hip, stride 1 (round 4)
+                self.kname = "conv16d_kernel<%d,%d,1>" % (x16_rows(OH, cw, 1), cw)
+            else:
+                self.kname = "conv16t_kernel<%d,%d,%d>" % (rw, cw, classes[0]["n"][0])
         # round 4 (conv16x.hip): the stride-2 and transposed 3x3x3 layers on LDS tiles too
         self.tile_x = None
         if C16_TILE["enabled"] and not self.tile and not dense1:
-            ct = p.cout_pad // 16
-            ctn = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
             if _lib.lib().drc_conv16_k3s2_tile_supported(C.byref(p)):
                 self.tile_x = "drc_conv16_k3s2_tile_fwd"
-                self.kname = "conv16d_kernel<%d,%d>" % (2 if OH >= 12 else 1, ctn)
+                self.kname = "conv16d_kernel<%d,%d,2>" % (x16_rows(OH, cw, 2), cw)
             elif _lib.lib().drc_deconv16_k3s2_tile_supported(C.byref(p)):
                 self.tile_x = "drc_deconv16_k3s2_tile_fwd"
-                self.kname = "conv16u_kernel<%d,%d>" % (2 if OH >= 12 and x.cb * 18 + 1 <= 80 else 1, ctn)
+                self.kname = "conv16u_kernel<%d,%d,%d>" % (x16_rows(OH, cw, 0, x.cb), cw, x.cb)
 
     def run(self, x, w16, scale, shift, y, res=None):
         p = self.p

@@ -58,10 +58,11 @@ def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, t
     cp = E.cout_pad_of(cout)
     sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
     sc[:cout] = scale.to(dev); sh[:cout] = shift.to(dev)
-    assert plan.tile == (stride == 1 and not transposed)            # stride-1 layers: the LDS-tiled kernel (conv16t.hip)
+    assert plan.tile == (stride == 1 and not transposed)            # stride-1 layers: drc_conv16_k3_tile_fwd (conv16t.hip's entry)
     assert plan.tile_x == (None if plan.tile else ("drc_deconv16_k3s2_tile_fwd" if transposed else "drc_conv16_k3s2_tile_fwd"))    # round 4: conv16x.hip
-    assert plan.kname.startswith("conv16u" if transposed else ("conv16d" if stride == 2 else ("conv16t", "conv16s"))), plan.kname
-    assert plan.kname.startswith("conv16s") == (plan.tile and cin <= 32 and cout <= 32 and dims[0] >= 4)
+    slide = plan.tile and cin <= 32 and cout <= 32 and dims[0] >= 4                  # conv16t.hip's depth-sliding walk; everything else: conv16x.hip
+    assert plan.kname.startswith("conv16u_kernel" if transposed else ("conv16s_kernel" if slide else "conv16d_kernel")), plan.kname
+    assert transposed or slide or plan.kname.endswith(",%d>" % stride), plan.kname
     plan.run(xb, E.pack_weight16(w.to(dev), transposed), sc, sh, yb, rb)
     got = yb.to_dense().cpu()
     assert got.shape == ref.shape

@@ -261,8 +261,9 @@ def test_stem_space_to_depth_weight_is_the_same_convolution():
 
 
 def test_fp16_kernel_selection():
-    """Which fp16 kernel a layer takes (engine.ConvPlan16): the depth-sliding walk for one input block / <= 32 couts / depth >= 4, the
-    LDS-tiled kernel for the other stride-1 3x3x3 and 3x3 layers, conv16.hip's generic tap walk for strides, transposed, dilated and 1x1."""
+    """Which fp16 kernel a layer takes (engine.ConvPlan16): the depth-sliding walk for one input block / <= 32 couts / depth >= 4; the
+    cout-split, double-buffered kernels of conv16x.hip for the other 3x3x3 layers (stride 1, stride 2, transposed; round 4); conv16t.hip
+    for the 3x3 layers; conv16.hip's generic tap walk for dilated and 1x1."""
     from disprcnn_amd import engine as E
     dev = torch.device("cpu")
 
@@ -276,10 +277,15 @@ def test_fp16_kernel_selection():
         return b
 
     assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16s_kernel<4,2>"
-    assert E.plan_conv3d16(geo(4, 64, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16t_kernel<4,2,3>"      # two input blocks
-    assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16t_kernel<2,4,3>"
-    assert E.plan_conv3d16(geo(4, 32, 3, 28, 28), geo(4, 32, 3, 28, 28), 1, 32, True).kname == "conv16t_kernel<2,2,3>"        # depth < 4
-    assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 64, 12, 28, 28), 2, 64, True).kname.startswith("conv16_kernel")
+    assert E.plan_conv3d16(geo(4, 64, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16d_kernel<7,2,1>"      # two input blocks
+    assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16d_kernel<7,4,1>"
+    assert E.plan_conv3d16(geo(4, 32, 3, 28, 28), geo(4, 32, 3, 28, 28), 1, 32, True).kname == "conv16d_kernel<7,2,1>"        # depth < 4
+    assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 64, 12, 28, 28), 2, 64, True).kname == "conv16d_kernel<7,4,2>"
+    assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 6, 14, 14), 2, 64, True).kname == "conv16d_kernel<7,4,2>"
+    assert E.plan_conv3d16(geo(4, 32, 12, 12, 12), geo(4, 32, 6, 6, 6), 2, 32, True).kname == "conv16d_kernel<4,2,2>"        # 6 rows: one 8-row tile
+    assert E.plan_deconv3d16(geo(4, 64, 12, 28, 28), geo(4, 32, 24, 56, 56), 32, False).kname == "conv16u_kernel<7,2,2>"
+    assert E.plan_deconv3d16(geo(4, 64, 6, 14, 14), geo(4, 64, 12, 28, 28), 64, False).kname == "conv16u_kernel<7,4,2>"
+    assert E.x16_rows(4, 4, 1) == 2 and E.x16_rows(6, 4, 1) == 7 and E.x16_rows(28, 4, 1) == 7 and E.x16_rows(8, 1, 2) == 2 and E.x16_rows(28, 1, 0, cb=4) == 2
     assert E.plan_conv3d16_cout1(geo(4, 32, 24, 56, 56)).kname == "conv16s_kernel<4,1>"
     x2 = geo(8, 64, 1, 56, 56, pad=1, pd=0)
     assert E.plan_conv2d16(x2, geo(8, 64, 1, 56, 56, pd=0), 3, 1, 1, 1, 64, True).kname == "conv16t_kernel<4,4,1>"
