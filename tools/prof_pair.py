@@ -1,4 +1,5 @@
-"""Development tool: Config B (16 ROI crops 224x224, D=96, full PSMNet) and the R-50-FPN trunk, for rocprofv3 --kernel-trace."""
+"""Development tool: Config B (16 ROI crops 224x224, D=96, full PSMNet), the stress shape, the headline step and the R-50-FPN trunk, for
+rocprofv3 --kernel-trace (WHAT = psm | psm16 | psm16f | cfgA | anything else: trunk; DRC_LIB = a variant library)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,6 +22,12 @@ if what in ("psm16", "psm16f"):
     l, r = synth.synth_images(64, 224, 224, tag="benchB64")
     l, r = l.to(dev), r.to(dev)
     f = lambda: m((l, r))
+elif what == "cfgA":                    # the headline step: Config A regressor from ROI features (ROIS = batch, default 1024)
+    import bench
+    m, _sd = bench.build_model(dev, 48, 0, "A")
+    fl, fr = synth.synth_features(int(os.environ.get("ROIS", "1024")), 32, 28, 28, tag="bench0")
+    fl, fr = fl.to(dev), fr.to(dev)
+    f = lambda: m.forward_from_features(fl, fr, (112, 112))
 elif what == "psm":
     m = PSMNet(48, -48)
     m.load_state_dict(synth.synth_state_dict(m.state_dict()), strict=True)
