@@ -27,10 +27,13 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/disprcnn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -372,6 +375,218 @@ __global__ __launch_bounds__(64 * T16_WAVES) void conv16s_kernel(const drc_tapco
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16sp_kernel<RW,CT>: conv16s_kernel with the next-but-one slice in flight (round 4).  conv16s issues slice od+3's DMA at the top of
+// step od and drains the queue (vmcnt(0)) at its end: one MFMA phase (1.5 us at RW = 4) to cover an HBM round trip under load, with one
+// wave per SIMD and nothing else to run -- 8.7 K cycles per step against 3.5 K of MFMA.  Here
+//   * the ring has FIVE slots and step od requests slice od+4; the wait at its end is COUNTED: everything up to slice od+3 and this
+//     step's residual tile must have landed, while slice od+4's DMAs, the NEXT step's residual tile (requested one step ahead, second
+//     register set) and the previous step's stores stay in flight.  vmcnt retires in order, so the count must be exact: every wave
+//     issues the same number of DMAs per stage (the clamped duplicate rows of waves 2, 3 rewrite a row with the same bytes), slices
+//     past the volume's end are still requested (clamped, into slots nobody reads), and the kernel only takes maps whose rows fill the
+//     tiles (OH % TR == 0: no row-masked -- possibly skipped -- store or residual load);
+//   * RW = 7 rows per wave on 28- and 56-row maps: 378 MFMAs per step and weight set instead of 216, no padded rows (16-row tiles padded
+//     56 rows to 64).
+// MODE: 0 = blocked fp16 output, no residual; 1 = ... with a blocked fp16 residual; 2 = the dense fp32 single-cout head (reserved == 1),
+// no residual; 3 = ... with a dense fp32 residual.  (Template argument, not a run-time branch: with branches around the residual requests
+// the compiler's wait-count pass gave up on counting and drained the queue right behind the DMAs.)
+// s_waitcnt as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): the compiler's own wait-count pass
+// reads it.  Behind inline-asm waits it still believed the kernel's first loads (the weights) pending at the head of the od loop and
+// drained the queue before every step's first MFMA.
+#ifndef T16_DBG_N
+#define T16_DBG_N (NDMA + (RES ? 2 : 1) * NST)
+#endif
+#define T16_WAITCNT(vm, lgkm) (((vm) & 15) | (7 << 4) | ((lgkm) << 8) | (((vm) >> 4) << 14))
+#define T16_WAIT_BARRIER(imm) do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(imm); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <int RW, int CT, int MODE>
+__global__ __launch_bounds__(64 * T16_WAVES) void conv16sp_kernel(const drc_tapconv_params p) {
+    constexpr int TR = RW * T16_WAVES;
+    constexpr int NR = TR + 2;                         // staged rows per slice
+    constexpr int SLOT = NR * 1024;
+    constexpr int SLOTS = 5;
+    constexpr int NDMA = (NR + T16_WAVES - 1) / T16_WAVES;                // per wave and stage, the same for every wave
+    constexpr bool DENSE = MODE >= 2, RES = MODE & 1;
+    constexpr int NST = DENSE ? RW : RW * CT;                             // stores per step = residual loads per step (when RES)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef const __attribute__((address_space(3))) volatile f16x8 lds_frag;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const _Float16* x = (const _Float16*)p.x;
+    const drc_tap_class cls = p.cls[0];
+    const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride;
+    const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
+    const int rh = (int)p.r_h_stride, rd_ = (int)p.r_d_stride, rc = (int)p.r_cb_stride;
+    const int n_ct = (p.OW + T16_COLS - 1) / T16_COLS, n_rt = p.OH / TR;
+    const unsigned columns = (unsigned)p.N * n_rt * n_ct;
+
+    f16x8 wreg[27][CT];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            wreg[tap][ct] = *(const f16x8*)((const _Float16*)p.w + ((long)tap * p.cout_pad + ct * 16 + j) * 32 + g * 8);
+    const __attribute__((address_space(3))) char* ring = (const __attribute__((address_space(3))) char*)lds;
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + wave * RW * 1024);
+    f32x4 sc_[CT], sh_[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        sc_[ct] = DENSE ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(p.scale + ct * 16 + g * 4);
+        sh_[ct] = DENSE ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(p.shift + ct * 16 + g * 4);
+    }
+
+    f32x4 acc[RW][CT];
+    for (unsigned col = blockIdx.x; col < columns; col += gridDim.x) {
+        unsigned t = col;
+        unsigned u = t / (unsigned)n_ct; const int c0 = (int)(t - u * (unsigned)n_ct) * T16_COLS; t = u;
+        u = t / (unsigned)n_rt; const int r0 = (int)(t - u * (unsigned)n_rt) * TR;
+        const int n = (int)u;
+        const _Float16* src0 = x + (long)n * p.x_n_stride + (cls.dd0 * xd + (r0 + cls.dh0) * xh + (c0 + cls.dw0 + j) * 32 + g * 8);
+        auto stage = [&](int ps, int slot) __attribute__((always_inline)) {            // padded slice ps (clamped to the last one) -> ring slot
+            const int psc = ps < p.OD + 2 ? ps : p.OD + 1;
+            char* dst = lds + slot * SLOT;
+#pragma unroll
+            for (int k = 0; k < NDMA; ++k) {
+                int rr = k * T16_WAVES + wave;
+                rr = rr < NR ? rr : NR - 1;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src0 + (psc * xd + rr * xh)), LDS_PTR(dst + rr * 1024), 16, 0, 0);
+            }
+        };
+        const int col_ = c0 + j;
+        const bool col_ok = j < T16_COLS && col_ < p.OW;
+        const int col_c = col_ < p.OW ? col_ : p.OW - 1;                                // (residual requests of the unused lanes stay inside the map)
+        const int row0 = r0 + wave * RW;
+        const _Float16* res = (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride;
+        const float* resd = (const float*)p.res;
+        // this unit's output as a buffer: [base, base + 2 GiB) (the launcher checks the per-unit sizes)
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            DENSE ? (void*)((float*)p.y + (long)n * p.OD * p.OH * p.OW) : (void*)((_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride), 0, 0x7FFFFF00, 0x00020000);
+        f16x4 rv[2][RW][CT];                           // residual tiles of this step and the next (static rotation: the od loop runs in pairs)
+        float rdv[2][RW];
+        auto res_request = [&](int od, int set) __attribute__((always_inline)) {        // always NST loads (RES), whatever od
+            if constexpr (RES) {
+                const int odc = od < p.OD ? od : p.OD - 1;
+                const int rl = odc * rd_ + row0 * rh + col_c * 32 + g * 4;
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    if constexpr (DENSE) {
+                        rdv[set][r] = resd[(((long)n * p.OD + odc) * p.OH + row0 + r) * p.OW + col_c];
+                    } else {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) rv[set][r][ct] = *(const f16x4*)(res + rl + (ct >> 1) * rc + r * rh + (ct & 1) * 16);
+                    }
+                }
+            }
+        };
+        // every wave is done with the previous column's slots before they are overwritten
+        T16_WAIT_BARRIER(T16_WAITCNT(63, 0));
+        stage(0, 0); stage(1, 1); stage(2, 2); stage(3, 3);
+        res_request(0, 0);
+        T16_WAIT_BARRIER(T16_WAITCNT(0, 15));
+        int s0 = 0, s4 = 4;                            // ring slots of padded slices od and od + 4
+        auto step = [&](int od, auto SET) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET)::value;
+            // slices od .. od+3 are resident or landing; slot s4 is free (slice od-1: the barrier that ended the previous step)
+            stage(od + 4, s4);
+            res_request(od + 1, set ^ 1);
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int s1 = s0 + 1 < SLOTS ? s0 + 1 : s0 + 1 - SLOTS, s2 = s0 + 2 < SLOTS ? s0 + 2 : s0 + 2 - SLOTS;
+            const __attribute__((address_space(3))) char* sl[3] = {ring + s0 * SLOT + lane_b, ring + s1 * SLOT + lane_b, ring + s2 * SLOT + lane_b};
+            f16x8 rowA[RW + 2], rowB[RW + 2];
+            auto gfetch = [&](f16x8 (&rows)[RW + 2], int grp) __attribute__((always_inline)) {
+                const int kd = grp / 3, kw = grp - kd * 3;
+#pragma unroll
+                for (int rr = 0; rr < RW + 2; ++rr) rows[rr] = *(lds_frag*)(sl[kd] + kw * 16 + rr * 1024);
+            };
+            auto gmfma = [&](const f16x8 (&rows)[RW + 2], int grp) __attribute__((always_inline)) {
+                const int kd = grp / 3, kw = grp - kd * 3;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[(kd * 3 + kh) * 3 + kw][ct], rows[r + kh], acc[r][ct], 0, 0, 0);
+            };
+            gfetch(rowA, 0);
+#pragma unroll
+            for (int grp = 0; grp < 9; ++grp) {
+                if (grp + 1 < 9) { if (grp & 1) gfetch(rowA, grp + 1); else gfetch(rowB, grp + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp & 1) gmfma(rowB, grp); else gmfma(rowA, grp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // in flight past this point: slice od+4 (NDMA), the next step's residual tile (NST if RES), the previous step's stores (NST)
+            // -- all younger than slice od+3 and this step's residual tile.  (At od = 0 there are no stores yet and the prologue has
+            // drained everything older: the wait is then simply weaker than it may be.)
+            __builtin_amdgcn_s_waitcnt(T16_WAITCNT(T16_DBG_N, 15));
+            __builtin_amdgcn_sched_barrier(0);         // (the epilogue's register reads must not be scheduled above the wait)
+            static_assert(NDMA + 2 * NST <= 63, "vmcnt is a 6-bit counter");
+            // ---- epilogue of output slice od.  Buffer stores, the lanes without an output (j = 14, 15, columns past the map, g != 0 of the
+            // dense head) pointed past the descriptor's range: the hardware drops them, the instruction count stays the same on every path
+            // (behind exec-masked branches the compiler no longer trusted its own count and drained the queue before the epilogue).
+            if constexpr (DENSE) {
+                const unsigned yo = (g == 0 && col_ok) ? (unsigned)(((od * p.OH + row0) * p.OW + col_) * 4) : 0x80000000u;   // (+ the per-store offsets below: still past num_records, no 32-bit wrap)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r][0].x + (RES ? rdv[set][r] : 0.f)), yr, yo + (unsigned)(r * p.OW * 4), 0, 0);
+            } else {
+                const unsigned yo = col_ok ? (unsigned)((od * yd_ + row0 * yh + col_ * 32 + g * 4) * 2) : 0x80000000u;   // (+ the per-store offsets below: still past num_records, no 32-bit wrap)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) {
+                        f32x4 v = acc[r][ct] * sc_[ct] + sh_[ct];
+                        if constexpr (RES) {
+                            v.x += (float)rv[set][r][ct].x; v.y += (float)rv[set][r][ct].y; v.z += (float)rv[set][r][ct].z; v.w += (float)rv[set][r][ct].w;
+                        }
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        f16x4 hv;
+                        hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), yr, yo + (unsigned)(((ct >> 1) * yc + r * yh + (ct & 1) * 16) * 2), 0, 0);
+                    }
+                }
+            }
+            T16_WAIT_BARRIER(T16_WAITCNT(63, 0));     // every wave's rows of slice od+3 landed; everyone is done reading slice od's slot
+            s0 = s1;
+            s4 = s4 + 1 < SLOTS ? s4 + 1 : 0;
+        };
+        for (int od = 0; od < p.OD; od += 2) {
+            step(od, std::integral_constant<int, 0>{});
+            if (od + 1 < p.OD) step(od + 1, std::integral_constant<int, 1>{});
+        }
+    }
+}
+
+template <int RW, int CT, int MODE>
+int launch_slide_deep_mode(const drc_tapconv_params& p, hipStream_t stream) {
+    constexpr int TR = RW * T16_WAVES;
+    constexpr size_t lds = 5 * (size_t)(TR + 2) * 1024 + 1024;
+    static_assert(lds <= 160 * 1024, "ring exceeds the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv16sp_kernel<RW, CT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long columns = (long)p.N * (p.OH / TR) * ((p.OW + T16_COLS - 1) / T16_COLS);
+    if (columns >= (1L << 31)) return -5;
+    long blocks = 256;                                   // one block per CU: the weights take the wave's register file
+    if (blocks > columns) blocks = columns;
+    hipLaunchKernelGGL((conv16sp_kernel<RW, CT, MODE>), dim3((unsigned)blocks), dim3(64 * T16_WAVES), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <int RW>
+int launch_slide_deep(const drc_tapconv_params& p, hipStream_t stream) {
+    if (p.reserved == 1) return p.res ? launch_slide_deep_mode<RW, 1, 3>(p, stream) : launch_slide_deep_mode<RW, 1, 2>(p, stream);
+    if (p.cout_pad == 32) return p.res ? launch_slide_deep_mode<RW, 2, 1>(p, stream) : launch_slide_deep_mode<RW, 2, 0>(p, stream);
+    return p.res ? launch_slide_deep_mode<RW, 1, 1>(p, stream) : launch_slide_deep_mode<RW, 1, 0>(p, stream);
+}
+
 template <int RW, int CT>
 int launch_slide(const drc_tapconv_params& p, hipStream_t stream) {
     constexpr int TR = RW * T16_WAVES;
@@ -454,6 +669,11 @@ extern "C" int drc_conv16_k3_tile_fwd(const drc_tapconv_params* pp, void* stream
 #define T16_SLIDE 1
 #endif
     if (T16_SLIDE && p.cls[0].nd == 3 && p.cb_in == 1 && p.cout_pad <= 32 && p.OD >= 4) {      // one input block, <= 32 couts: depth-sliding walk
+#ifndef T16_DEEP
+#define T16_DEEP 1
+#endif
+        if (T16_DEEP && p.OH % 28 == 0) return launch_slide_deep<7>(p, s);        // full 28-row tiles (the regressor's 28- and 56-row maps)
+        if (T16_DEEP && p.OH % 16 == 0) return launch_slide_deep<4>(p, s);
         const bool tall = p.OH % 16 == 0 || p.OH >= 48;
         if (p.cout_pad == 32) return tall ? launch_slide<4, 2>(p, s) : launch_slide<2, 2>(p, s);
         return tall ? launch_slide<4, 1>(p, s) : launch_slide<2, 1>(p, s);

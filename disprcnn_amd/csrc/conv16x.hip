@@ -60,8 +60,16 @@ __device__ __forceinline__ f16x4 x16_finish(const f32x4 acc, const f32x4 sc, con
 // planes -- and stages are double-buffered: the DMAs and the nine weight fragments of stage s + 1 are issued before the MFMAs of stage s,
 // one barrier per stage.  ST = 1 serves the stride-1 layers with two input blocks or 64 couts (dres0[0], hourglass conv2 / conv4), which
 // conv16t.hip ran with every wave fetching all cout tiles' weights for two or four rows.
-template <int RW, int CW, int ST>
-__global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapconv_params p) {
+//
+// CV (stride 1 only): the input is the fp16 cost volume of stackhourglass.py:115-128, never materialised.  p.x is the FEATURE PAIR
+// half[N][2: left, right][3][H+2][W+2][32] (the cost-volume layout with one depth slice; drc_cost_volume16_blocked_fwd with D = 1 and
+// disparity 0 writes it), OD = the volume's depth and `lo4` its first disparity.  Slice d of the volume is the left row where the shifted
+// pixel exists and the right row moved by s = lo4 + d columns: both are the SAME feature rows for every d, read through per-lane
+// addresses -- a lane whose voxel is zero in the volume (xw - s outside [0, W), the halo, a depth tap outside [0, D)) is pointed at
+// column 0 of the row, the zero halo.  No extra instruction in the MFMA phase; the 617 MB volume of the stress shape (and the
+// kernel that wrote it) are gone, the features stay L2-resident.
+template <int RW, int CW, int ST, bool CV>
+__global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapconv_params p, const int lo4) {
     constexpr int RG = X16_WAVES / CW;
     constexpr int TR = RW * RG;
     constexpr int IR = ST * TR + 3 - ST;               // staged input rows per depth tap
@@ -106,11 +114,19 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16d_kernel(const drc_tapco
         // stage s -> buffer `par`: the DMAs (waves take rows round robin) and this wave's nine weight fragments (tap order kd, kh, kw)
         auto request = [&](int s, int par) __attribute__((always_inline)) {
             const int cb = s / 3, kd = s - cb * 3;
-            const _Float16* src = xn + (cb * xc + (ST * od + cls.dd0 + kd) * xd);
+            const _Float16* src = xn + (cb * xc + (CV ? 1 : ST * od + cls.dd0 + kd) * xd);
+            int colA = colE;
+            if constexpr (CV) {
+                // volume slice d = od + kd - 1 (cls.dd0 = 0: the padded depth index is od + kd), shift sft = lo4 + d; this lane's voxel
+                // xw = colE - 1 is non-zero iff 0 <= d < OD, 0 <= xw < W and 0 <= xw - sft < W; the right block reads column xw - sft
+                const int d = od + cls.dd0 + kd - 1, sft = lo4 + d, xw = colE - 1, xs = xw - sft, Wr = Wp - 2;
+                const bool ok = d >= 0 && d < p.OD && xw >= 0 && xw < Wr && xs >= 0 && xs < Wr;
+                colA = ok ? (cb ? xs + 1 : colE) : 0;
+            }
             for (int i = wave; i < ST * IR; i += X16_WAVES) {
                 int row = ST * r0 + cls.dh0 + (ST == 2 ? (i >> 1) : i);
                 row = row < Hp ? row : Hp - 1;
-                __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (row * xh + ((ST == 2 && (i & 1)) ? colO : colE) * 32)), X16_LDS_PTR(lds + par * BUF + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(X16_GLOBAL_PTR(src + (row * xh + ((ST == 2 && (i & 1)) ? colO : colA) * 32)), X16_LDS_PTR(lds + par * BUF + i * 1024), 16, 0, 0);
             }
             const unsigned wo = 2u * (unsigned)((long)(kd * 9) * w_tap + cb * w_cb);
 #pragma unroll
@@ -306,13 +322,13 @@ __global__ __launch_bounds__(64 * X16_WAVES) void conv16u_kernel(const drc_tapco
     }
 }
 
-template <int RW, int CW, int ST>
-int launch_d_rw(const drc_tapconv_params& p, hipStream_t stream) {
+template <int RW, int CW, int ST, bool CV = false>
+int launch_d_rw(const drc_tapconv_params& p, hipStream_t stream, int lo4 = 0) {
     constexpr int TR = RW * (X16_WAVES / CW);
     constexpr size_t lds = (size_t)2 * (ST * (ST * TR + 3 - ST) + 1) * 1024;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv16d_kernel<RW, CW, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv16d_kernel<RW, CW, ST, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const long tiles = (long)p.N * p.OD * ((p.OH + TR - 1) / TR) * ((p.OW + X16_COLS - 1) / X16_COLS) * (p.cout_pad / 16 / CW);
@@ -321,20 +337,20 @@ int launch_d_rw(const drc_tapconv_params& p, hipStream_t stream) {
     if (per_cu > 4) per_cu = 4;
     long blocks = 256 * per_cu;
     if (blocks > tiles) blocks = tiles;
-    hipLaunchKernelGGL((conv16d_kernel<RW, CW, ST>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p);
+    hipLaunchKernelGGL((conv16d_kernel<RW, CW, ST, CV>), dim3((unsigned)blocks), dim3(64 * X16_WAVES), lds, stream, p, lo4);
     return (int)hipGetLastError();
 }
 
 // Rows per wave (engine.x16_rows mirrors this rule for the plan's kernel name).  Stride 2: the block's two stage buffers stay below 80 KiB
 // (two blocks per CU) with TR <= 8 -- seven rows for one row group, four for two, two for four; stride 1: seven.  The small tile (two
 // rows, one with four row groups at stride 2) when the big one pads the map's rows by more than 25 % over the small one's.
-template <int CW, int ST>
-int launch_d(const drc_tapconv_params& p, hipStream_t stream) {
+template <int CW, int ST, bool CV = false>
+int launch_d(const drc_tapconv_params& p, hipStream_t stream, int lo4 = 0) {
     constexpr int RG = X16_WAVES / CW;
     constexpr int BIG = ST == 1 ? 7 : (RG == 1 ? 7 : RG == 2 ? 4 : 2), SMALL = (ST == 2 && RG == 4) ? 1 : 2;
     const int trb = BIG * RG, trs = SMALL * RG;
     const long padb = (long)((p.OH + trb - 1) / trb) * trb, pads = (long)((p.OH + trs - 1) / trs) * trs;
-    return padb * 4 <= pads * 5 ? launch_d_rw<BIG, CW, ST>(p, stream) : launch_d_rw<SMALL, CW, ST>(p, stream);
+    return padb * 4 <= pads * 5 ? launch_d_rw<BIG, CW, ST, CV>(p, stream, lo4) : launch_d_rw<SMALL, CW, ST, CV>(p, stream, lo4);
 }
 
 template <int RW, int CW, int CBN>
@@ -394,6 +410,26 @@ int drc_x16_conv3d_s1_launch(const drc_tapconv_params& p, hipStream_t s) {
     if (ct % 4 == 0) return launch_d<4, 1>(p, s);
     if (ct % 2 == 0) return launch_d<2, 1>(p, s);
     return launch_d<1, 1>(p, s);
+}
+
+extern "C" int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* pp, int mindisp4, void* stream) {
+    if (!pp) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.y || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    const drc_tap_class& k = p.cls[0];
+    if (p.n_classes != 1 || p.in_mul != 1 || p.out_mul != 1 || p.cb_in != 2) return -4;                 // 32 left + 32 right channels
+    if (k.nd != 3 || k.nh != 3 || k.nw != 3 || k.sd != 1 || k.sh != 1 || k.sw != 1 || k.dd0 || k.dh0 || k.dw0) return -4;   // pad 1 on a halo-1 layout
+    if (k.out_off_d || k.out_off_h || k.out_off_w || k.wbase != 0 || k.wsw != 1 || k.wsh != 3 || k.wsd != 9) return -4;
+    if (!x16_common_ok(p)) return -4;
+    if (p.x_h_stride != (int64_t)(p.OW + 2) * 32 || p.x_d_stride != (int64_t)(p.OH + 2) * p.x_h_stride) return -4;   // the feature pair: halo 1
+    if (int e = x16_check_sizes(p)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ct = p.cout_pad / 16;
+    if (ct % 4 == 0) return launch_d<4, 1, true>(p, s, mindisp4);
+    if (ct % 2 == 0) return launch_d<2, 1, true>(p, s, mindisp4);
+    return launch_d<1, 1, true>(p, s, mindisp4);
 }
 
 extern "C" int drc_conv16_k3s2_tile_supported(const drc_tapconv_params* pp) {

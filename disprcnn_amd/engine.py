@@ -1176,10 +1176,13 @@ class ConvPlan16:
             rw = 4 if (OH % 16 == 0 or OH >= 48) else 2
             if classes[0]["n"][0] == 3 and x.cb == 1 and p.cout_pad <= 32 and OD >= 4:      # conv16t.hip: the depth-sliding walk
                 self.kname = "conv16s_kernel<%d,%d>" % (rw, ct)
+                if OH % 28 == 0 or OH % 16 == 0:                                            # rows fill the tiles: two slices in flight (round 4)
+                    self.kname = "conv16sp_kernel<%d,%d>" % (7 if OH % 28 == 0 else 4, ct)
             elif classes[0]["n"][0] == 3 and not dense1:                                     # conv16x.hip, stride 1 (round 4)
                 self.kname = "conv16d_kernel<%d,%d,1>" % (x16_rows(OH, cw, 1), cw)
             else:
                 self.kname = "conv16t_kernel<%d,%d,%d>" % (rw, cw, classes[0]["n"][0])
+        self.costvol_lo4 = None          # plan_conv3d16_costvol: x is the feature pair, the cost volume is folded into the stage addresses
         # round 4 (conv16x.hip): the stride-2 and transposed 3x3x3 layers on LDS tiles too
         self.tile_x = None
         if C16_TILE["enabled"] and not self.tile and not dense1:
@@ -1212,7 +1215,10 @@ class ConvPlan16:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        if self.tile:
+        if self.costvol_lo4 is not None:
+            st = _lib.lib().drc_conv16_k3_costvol_fwd(C.byref(p), self.costvol_lo4, _stream_ptr(self.device))
+            _lib.check(st, "drc_conv16_k3_costvol_fwd")
+        elif self.tile:
             st = _lib.lib().drc_conv16_k3_tile_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_conv16_k3_tile_fwd")
         elif self.tile_x:
@@ -1229,6 +1235,23 @@ class ConvPlan16:
 def plan_conv3d16(x, y, stride, cout, relu):
     assert (x.pd, x.ph, x.pw) == (1, 1, 1)
     return ConvPlan16(x, y, taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)), stride, 1, (y.D, y.H, y.W), cout, relu)
+
+
+COSTVOL16_FUSED = {"enabled": True}      # dres0[0] reads the fp16 feature pair instead of a materialised fp16 cost volume (conv16x.hip, round 4)
+
+
+def plan_conv3d16_costvol(pair, y, lo4, cout, relu):
+    """The first 3D layer of the fp16-storage regressor on the cost volume of stackhourglass.py:115-128 without the volume: pair = Blocked16
+    [N,64,1,H,W] (channel block 0 = left features, block 1 = right features; cost_volume16_blocked / cost_volume16_from16 with one slice at
+    disparity 0), y = Blocked16 [N,cout,D,H,W], lo4 = the volume's first disparity.  Bit-identical to the two-kernel form."""
+    assert (pair.pd, pair.ph, pair.pw) == (1, 1, 1) and pair.C == 64 and pair.D == 1 and (pair.H, pair.W) == (y.H, y.W)
+    pl = ConvPlan16(pair, y, taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)), 1, 1, (y.D, y.H, y.W), cout, relu)
+    pl.costvol_lo4, pl.tile, pl.tile_x = int(lo4), False, None
+    ct = pl.p.cout_pad // 16
+    cw = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
+    pl.kname = "conv16d_kernel<%d,%d,1,cv>" % (x16_rows(y.H, cw, 1), cw)
+    pl.flops = 2 * y.N * y.D * y.H * y.W * 27 * 64 * cout
+    return pl
 
 
 def plan_deconv3d16(x, y, cout, relu):

@@ -409,7 +409,11 @@ class PSMNetRuntime:
         def B(name, c, d, h, w):
             t[name] = pool.blocked16(name, N, c, d, h, w, 1, 1, 1)
 
-        B("cost", 64, *full)
+        fused_cv = E.COSTVOL16_FUSED["enabled"]
+        if fused_cv:
+            B("pair", 64, 1, Hp, Wp)            # left | right features, one slice: dres0[0] builds the volume's rows from it (conv16x.hip)
+        else:
+            B("cost", 64, *full)
         for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3", "cls_t1", "cls_t2", "cls_t3"):
             B(n, 32, *full)
         for k in (1, 2, 3):
@@ -417,7 +421,8 @@ class PSMNetRuntime:
             B(f"hg{k}.c3", 64, *quart); B(f"hg{k}.c4", 64, *quart)
             t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
         p = {}
-        p["dres0.0"] = E.plan_conv3d16(t["cost"], t["d0a"], 1, 32, True)
+        p["dres0.0"] = (E.plan_conv3d16_costvol(t["pair"], t["d0a"], 0, 32, True) if fused_cv        # (first disparity: set per call, _costvol16)
+                        else E.plan_conv3d16(t["cost"], t["d0a"], 1, 32, True))
         p["dres0.2"] = E.plan_conv3d16(t["d0a"], t["cost0a"], 1, 32, True)
         p["dres1.0"] = E.plan_conv3d16(t["cost0a"], t["d1a"], 1, 32, True)
         p["dres1.2"] = E.plan_conv3d16(t["d1a"], t["cost0"], 1, 32, False)
@@ -434,6 +439,18 @@ class PSMNetRuntime:
         ws = dict(t=t, p=p, pool=pool, flops=sum(pl.flops for pl in p.values()))
         return self._ws_put(key, ws)
 
+    def _costvol16(self, ws, mn, mx, left=None, right=None, in_pad=-1, feat16=None, right_first=0):
+        """The fp16 cost volume of stackhourglass.py:115-128 from fp32 features (NCHW, or blocked 2D storage with halo in_pad) or from a
+        Blocked16 feature tensor -- or, fused (engine.COSTVOL16_FUSED), only the one-slice feature pair dres0[0] builds the volume's rows from."""
+        t = ws["t"]
+        dst, lo, hi = (t["pair"], 0, 1) if "pair" in t else (t["cost"], mn // 4, mx // 4)
+        if "pair" in t:
+            ws["p"]["dres0.0"].costvol_lo4 = mn // 4
+        if feat16 is not None:
+            E.cost_volume16_from16(feat16, right_first, dst, lo, hi)
+        else:
+            E.cost_volume16_blocked(left, right, dst, lo, hi, in_pad)
+
     def _regress16(self, ws, W):
         """The schedule of _regress on fp16-storage tensors (eval: BatchNorm folded into the fp32 epilogue)."""
         t, p = ws["t"], ws["p"]
@@ -443,7 +460,7 @@ class PSMNetRuntime:
             c = W[wname]
             p[plan].run(t[x], W16[wname], c.scale, c.shift, t[y], t[res] if res else None)
 
-        run("dres0.0", "dres0.0", "cost", "d0a")
+        run("dres0.0", "dres0.0", "pair" if "pair" in t else "cost", "d0a")
         run("dres0.2", "dres0.2", "d0a", "cost0a")
         run("dres1.0", "dres1.0", "cost0a", "d1a")
         run("dres1.2", "dres1.2", "d1a", "cost0", res="cost0a")
@@ -521,7 +538,7 @@ class PSMNetRuntime:
         if self._use_f16(training):
             ws = self._ws3d16(N, (mx - mn) // 4, Hp, Wp)
             self._stamp(ws)
-            E.cost_volume16_blocked(fl.contiguous(), fr.contiguous(), ws["t"]["cost"], mn // 4, mx // 4, -1)
+            self._costvol16(ws, mn, mx, fl.contiguous(), fr.contiguous())
             return self._heads(self._regress16(ws, Wt), N, H, W, mx, mn, False)
         ws = self._ws3d(N, (mx - mn) // 4, Hp, Wp)
         self._stamp(ws)
@@ -758,13 +775,13 @@ class PSMNetRuntime:
                 ws2 = self._ws2d16(2 * N, H, W)
                 self._stamp(ws3, ws2)
                 feat = self._features16(ws2, Wt, torch.cat((left, right), 0))
-                E.cost_volume16_from16(feat, N, ws3["t"]["cost"], mn // 4, mx // 4)
+                self._costvol16(ws3, mn, mx, feat16=feat, right_first=N)
                 return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
             ws2 = self._ws2d(2 * N, H, W)
             self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, torch.cat((left, right), 0))
             fv = feat.storage
-            E.cost_volume16_blocked(fv, fv[N * feat.n_stride:], ws3["t"]["cost"], mn // 4, mx // 4, feat.ph)
+            self._costvol16(ws3, mn, mx, fv, fv[N * feat.n_stride:], feat.ph)
             return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
         ws3 = self._ws3d(N, (mx - mn) // 4, H // 4, W // 4)
         cv = None

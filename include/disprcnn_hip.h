@@ -330,6 +330,12 @@ int drc_cost_volume16_from16(const void* feat16, void* cost16, int N, int right_
                              int maxdisp4, int feat_pad, void* stream);
 int drc_conv16_k3_tile_fwd(const drc_tapconv_params* p, void* stream);
 
+/* The first 3D layer on the fp16 cost volume WITHOUT the volume (conv16x.hip, round 4): x = the fp16 feature pair
+ * half[N][2: left, right][3][H+2][W+2][32] (drc_cost_volume16_blocked_fwd / drc_cost_volume16_from16 with one depth slice at disparity 0),
+ * OD = the volume's depth, mindisp4 = its first disparity; cb_in = 2, weights as drc_conv16_k3_tile_fwd.  Bit-identical to
+ * drc_cost_volume16_* followed by drc_conv16_k3_tile_fwd.  Replaces the concat loop of disprcnn/modeling/psmnet/stackhourglass.py:115-128
+ * plus dres0[0] (:63-66) in the fp16-storage mode. */
+int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* p, int mindisp4, void* stream);
 /* Round 4: the same recipe for the stride-2 and the transposed 3x3x3 layers of the fp16-storage regressor (conv16x.hip; hourglass conv1 /
  * conv3 and conv5 / conv6, stackhourglass.py:11-30): drc_conv16_k3s2_tile_* takes the single-class stride-2 grid (in_mul = 2, canonical
  * weight order), drc_deconv16_k3s2_tile_* the eight output-parity classes of ConvTranspose3d(k3, s2, p1, op1) (out_mul = 2, the classes in

@@ -276,7 +276,9 @@ def test_fp16_kernel_selection():
         b.device = dev
         return b
 
-    assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16s_kernel<4,2>"
+    assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16sp_kernel<7,2>"         # 56 rows = two full 28-row tiles: the counted-wait walk
+    assert E.plan_conv3d16(geo(4, 32, 24, 20, 56), geo(4, 32, 24, 20, 56), 1, 32, True).kname == "conv16s_kernel<2,2>"          # ragged rows: conv16s
+    assert E.plan_conv3d16(geo(4, 32, 24, 32, 56), geo(4, 32, 24, 32, 56), 1, 32, True).kname == "conv16sp_kernel<4,2>"
     assert E.plan_conv3d16(geo(4, 64, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16d_kernel<7,2,1>"      # two input blocks
     assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16d_kernel<7,4,1>"
     assert E.plan_conv3d16(geo(4, 32, 3, 28, 28), geo(4, 32, 3, 28, 28), 1, 32, True).kname == "conv16d_kernel<7,2,1>"        # depth < 4
@@ -286,7 +288,7 @@ def test_fp16_kernel_selection():
     assert E.plan_deconv3d16(geo(4, 64, 12, 28, 28), geo(4, 32, 24, 56, 56), 32, False).kname == "conv16u_kernel<7,2,2>"
     assert E.plan_deconv3d16(geo(4, 64, 6, 14, 14), geo(4, 64, 12, 28, 28), 64, False).kname == "conv16u_kernel<7,4,2>"
     assert E.x16_rows(4, 4, 1) == 2 and E.x16_rows(6, 4, 1) == 7 and E.x16_rows(28, 4, 1) == 7 and E.x16_rows(8, 1, 2) == 2 and E.x16_rows(28, 1, 0, cb=4) == 2
-    assert E.plan_conv3d16_cout1(geo(4, 32, 24, 56, 56)).kname == "conv16s_kernel<4,1>"
+    assert E.plan_conv3d16_cout1(geo(4, 32, 24, 56, 56)).kname == "conv16sp_kernel<7,1>"
     x2 = geo(8, 64, 1, 56, 56, pad=1, pd=0)
     assert E.plan_conv2d16(x2, geo(8, 64, 1, 56, 56, pd=0), 3, 1, 1, 1, 64, True).kname == "conv16t_kernel<4,4,1>"
     assert E.plan_conv2d16(geo(8, 128, 1, 56, 56, pad=2, pd=0), geo(8, 128, 1, 56, 56, pd=0), 3, 1, 2, 2, 128, True).kname.startswith("conv16_kernel")
