@@ -109,7 +109,12 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
 #pragma unroll
     for (int q = 0; q < kFill; ++q) {
         const int e = q * 256 + (int)threadIdx.x;
-        fill_off[q] = (e / (64 * CT)) * w_xi + (e % (64 * CT)) * 4;
+        // Inside a [cout 16][16 channels] tile the ring holds float4 (cout j, channel group g) at position g*16 + j -- the order the MFMA
+        // fragments are read in (lanes j = 0..15 of a group: consecutive 16-byte words, no bank conflict; in the packed [cout][16] order
+        // their ds_read_b128 hit four banks four ways: SQ_LDS_BANK_CONFLICT 40 % of the LDS-active cycles, profiles/r4_configB_pmc.md).
+        // The permutation costs nothing: it is the global address this thread fetches from (the weights are cache-resident).
+        const int r_ = e % (64 * CT), c_ = r_ & 63;
+        fill_off[q] = (e / (64 * CT)) * w_xi + (r_ >> 6) * 256 + (c_ & 15) * 16 + (c_ >> 4) * 4;
     }
     const float* wbase = p.w + ct0 * 256;
     f32x4 fill[kFill];
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(64 * W2_WAVES) void wino2d_kernel(const drc_tapconv
 #pragma unroll
         for (int xw = 0; xw < 4; ++xw)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[xw][ct] = *(const f32x4*)&w_ring[slab][(row & 1) * 4 + xw][ct][j * 16 + g * 4];
+            for (int ct = 0; ct < CT; ++ct) wf[xw][ct] = *(const f32x4*)&w_ring[slab][(row & 1) * 4 + xw][ct][(g * 16 + j) * 4];
     };
 
     f32x4 acc[4][4][CT];
