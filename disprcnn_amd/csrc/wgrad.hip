@@ -26,6 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+typedef const __attribute__((address_space(3))) float wg_lds_f;
+
 template <int NT>   // taps per depth tap (nh*nw): 1, 2, 4, 9 (49 handled by NT=49 instantiation)
 __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_params p) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
@@ -89,45 +91,71 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
         // guarded every step by `m < nm`, and the branches kept the reads of a step from being issued under the previous step's MFMAs:
         // 10 ds_reads, lgkmcnt(0), 9 MFMAs, repeat).  Slots outside the tile or the output grid (ragged last tiles) get b = 0.
         int sr = g / p.WT, sc = g - sr * p.WT;           // (row, col) of this lane's slot, advanced by 4 slots per step
-        auto fetch = [&](float (&av)[NT], float& bv, int m) __attribute__((always_inline)) {
+        // Round 4: for NT <= 9 the NT + 1 LDS reads of a step are written out as ds_read_b32 and the wait in front of a step's MFMAs is
+        // COUNTED -- lgkmcnt(NT + 1): this step's reads have landed (LDS returns in order), the next step's stay in flight.  The compiler's
+        // own wait there was lgkmcnt(0), which also waited for the reads issued a moment earlier: the "pipeline" overlapped nothing.  The
+        // b value is masked at use, by a multiplication (the b tile is staged from valid addresses: finite).
+        constexpr bool COUNTED = NT <= 9;
+        constexpr int WAIT_FETCHED = 0xC07F | ((COUNTED ? NT + 1 : 0) << 8), WAIT_ALL = 0xC07F;
+        auto fetch = [&](float (&av)[NT], float& bv, float& okf, int m) __attribute__((always_inline)) {
             const int slot = 4 * m + g;
             const bool ok = slot < nslots && oh0 + sr < p.OH && ow0 + sc < p.OW;
             const int r = slot < nslots ? sr : 0, c = slot < nslots ? sc : 0;
             const float* ap = lds_a + (p.in_mul * r * seg_vox + p.in_mul * c) * 16 + j;
-            const float b_ = lds_b[(slot < nslots ? slot : 0) * 16 + j];
-            bv = ok ? b_ : 0.f;
+            if constexpr (COUNTED) {
+                okf = ok ? 1.f : 0.f;
+                const unsigned bb_ = (unsigned)(uintptr_t)(wg_lds_f*)(lds_b + (slot < nslots ? slot : 0) * 16 + j);
+                const unsigned ab = (unsigned)(uintptr_t)(wg_lds_f*)ap;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(bv) : "v"(bb_));
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tb = t / p.nw, tc = t - tb * p.nw;
-                av[t] = ap[(tb * p.sh * seg_vox + tc * p.sw) * 16];
+                for (int t = 0; t < NT; ++t) {
+                    const int tb = t / p.nw, tc = t - tb * p.nw;
+                    const unsigned aa = ab + (unsigned)((tb * p.sh * seg_vox + tc * p.sw) * 64);
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(av[t]) : "v"(aa));
+                }
+            } else {
+                okf = 1.f;
+                const float b_ = lds_b[(slot < nslots ? slot : 0) * 16 + j];
+                bv = ok ? b_ : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tb = t / p.nw, tc = t - tb * p.nw;
+                    av[t] = ap[(tb * p.sh * seg_vox + tc * p.sw) * 16];
+                }
             }
             sc += 4;
             while (sc >= p.WT) { sc -= p.WT; ++sr; }
         };
-        auto mfmas = [&](const float (&av)[NT], float bv) __attribute__((always_inline)) {
+        auto mfmas = [&](const float (&av)[NT], float bv, float okf, int wait_imm) __attribute__((always_inline)) {
+            if constexpr (COUNTED) {
+                if (wait_imm == WAIT_ALL) __builtin_amdgcn_s_waitcnt(WAIT_ALL); else __builtin_amdgcn_s_waitcnt(WAIT_FETCHED);
+                __builtin_amdgcn_sched_barrier(0);
+                bv *= okf;
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[t], 0, 0, 0);
         };
-        float avA[NT], avB[NT], bvA, bvB;
-        fetch(avA, bvA, 0);
+        float avA[NT], avB[NT], bvA, bvB, okA, okB;
+        fetch(avA, bvA, okA, 0);
         int m = 0;
         for (; m + 2 < nm; m += 2) {
-            fetch(avB, bvB, m + 1);
+            fetch(avB, bvB, okB, m + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(avA, bvA);
+            mfmas(avA, bvA, okA, WAIT_FETCHED);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(avA, bvA, m + 2);
+            fetch(avA, bvA, okA, m + 2);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(avB, bvB);
+            mfmas(avB, bvB, okB, WAIT_FETCHED);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (m + 2 == nm) {                              // two steps left
-            fetch(avB, bvB, m + 1);
+            fetch(avB, bvB, okB, m + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(avA, bvA);
-            mfmas(avB, bvB);
+            mfmas(avA, bvA, okA, WAIT_FETCHED);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(avB, bvB, okB, WAIT_ALL);
         } else {                                        // one step left
-            mfmas(avA, bvA);
+            mfmas(avA, bvA, okA, WAIT_ALL);
         }
         // all LDS reads of this group are consumed by the MFMAs above before the next group's DMA is issued (in-order wave)
     }

@@ -25,6 +25,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+typedef const __attribute__((address_space(3))) float ws_lds_f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// NK: the tile's k-steps (R*WT/4, rounded up) as a compile-time constant, 0 = run-time (any tile).  With a run-time count every stage of
+// the software pipeline sat behind a wave-uniform branch, the b value behind an exec-masked read, and the compiler's LDS wait in front of
+// each stage's MFMAs became lgkmcnt(0): it also waited for the NEXT stage's reads, issued a moment earlier -- the pipeline overlapped
+// nothing (MFMA busy 49 %; the staging DMAs, ablated, were 3 % of the time).  Straight-line stages get counted waits (LDS returns in order).
+template <int NK>
 __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wgrad_params p, int R, int WT, int nseg, int seglen) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -43,7 +51,7 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
     const int a_floats = pieces_a * 256, b_floats = pieces_b * 256;
     float* lds_a = lds_all + wave * (3 * a_floats + 2 * b_floats);     // ring of three a slices
     float* lds_b = lds_a + 3 * a_floats;                               // two b tiles
-    const int nslots = R * WT, nk = (nslots + 3) >> 2;
+    const int nslots = R * WT, nk = NK ? NK : (nslots + 3) >> 2;
     const unsigned mag_a = ((1u << 20) + seg * 4 - 1) / (seg * 4), mag_b = ((1u << 20) + WT * 4 - 1) / (WT * 4);
 
     // per-lane offsets of voxel slot 4m+g inside an a slice tile (tap (0,0)), and its (row, col)
@@ -103,6 +111,10 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
             const int r = s / WT, c = s - r * WT;
             if (s < nslots && r < nr && c < nc) okmask |= 1u << m;
         }
+        // (the b tile is staged from clamped, i.e. valid and finite, addresses: a multiplication by 0 / 1 masks it without a branch)
+        float okf[WS_MAXK];
+#pragma unroll
+        for (int m = 0; m < WS_MAXK; ++m) okf[m] = (float)((okmask >> m) & 1u);
         const char* abase = (const char*)(p.a + (int64_t)n * p.a_n_stride + (int64_t)ca * p.a_cb_stride + (int64_t)p.dd0 * p.a_d_stride +
                                           (int64_t)(oh0 + p.dh0) * p.a_h_stride + (int64_t)(ow0 + p.dw0) * 16);
         const char* bbase = (const char*)(p.b + p.b_off0 + (int64_t)n * p.b_n_stride + (int64_t)cbb * p.b_cb_stride + (int64_t)oh0 * p.b_h_stride +
@@ -134,16 +146,32 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
             float avs[2][9], bvs[2];
             auto fetch = [&](int set, int kd, int m, int aoff) __attribute__((always_inline)) {
                 const float* at = lds_a + ((od + kd) % 3) * a_floats;
-                bvs[set] = ((okmask >> m) & 1u) ? bt[(4 * m + g) * 16 + j] : 0.f;
+                if constexpr (NK > 0) {
+                    // exactly SEVEN LDS instructions, written out: the stage's wait below counts them (14 in flight at most: lgkmcnt is a
+                    // 4-bit counter).  Row r of the 3x3 taps: columns 0, 1 as one ds_read2_b32 (offsets in dwords), column 2 at +128 B; the
+                    // b value is masked at use (a multiply here would wait for the read it follows).
+                    const unsigned ab = (unsigned)(uintptr_t)(ws_lds_f*)(at + aoff), bb_ = (unsigned)(uintptr_t)(ws_lds_f*)(bt + (4 * m + g) * 16 + j);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) avs[set][t] = at[aoff + ((t / 3) * seg + (t % 3)) * 16];
+                    for (int r = 0; r < 3; ++r) {
+                        f32x2 pr;
+                        const unsigned ar = ab + (unsigned)(r * seg * 64);
+                        asm volatile("ds_read2_b32 %0, %1 offset1:16" : "=v"(pr) : "v"(ar));
+                        asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(avs[set][r * 3 + 2]) : "v"(ar));
+                        avs[set][r * 3] = pr.x; avs[set][r * 3 + 1] = pr.y;
+                    }
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(bvs[set]) : "v"(bb_));
+                } else {
+                    bvs[set] = ((okmask >> m) & 1u) ? bt[(4 * m + g) * 16 + j] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) avs[set][t] = at[aoff + ((t / 3) * seg + (t % 3)) * 16];
+                }
             };
             fetch(0, 0, 0, a_off[0]);
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll
                 for (int m = 0; m < WS_MAXK; ++m) {
-                    if (m < nk) {                                      // wave-uniform
+                    if (NK > 0 ? m < NK : m < nk) {                    // compile-time (NK) or wave-uniform
                         const int cur = m & 1;                         // every depth tap starts in set 0
                         // next stage: (kd, m+1) into the other set, or (kd+1, 0) into set 0 after the last k-step of this tap -- before
                         // the MFMAs when this stage runs out of set 1, after them when it occupies set 0 itself (odd nk)
@@ -154,9 +182,18 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
                             fetch(0, kd + 1, 0, a_off[0]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (NK > 0) {
+                            // LDS returns in order: this stage's seven reads are older than the next stage's seven, which stay in flight.  (The
+                            // compiler's own wait here was lgkmcnt(0).)  gfx9 s_waitcnt: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
+                            const bool fetched = !last_m || (kd < 2 && cur == 1);
+                            if (fetched) __builtin_amdgcn_s_waitcnt(0xC07F | (7 << 8));
+                            else __builtin_amdgcn_s_waitcnt(0xC07F);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const float bm = NK > 0 ? bvs[cur] * okf[m] : bvs[cur];
 #pragma unroll
                         for (int t = 0; t < 9; ++t)
-                            acc[kd * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[cur][t], bvs[cur], acc[kd * 9 + t], 0, 0, 0);
+                            acc[kd * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[cur][t], bm, acc[kd * 9 + t], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         if (last_m && kd < 2 && cur == 0) fetch(0, kd + 1, 0, a_off[0]);
                     }
@@ -211,7 +248,10 @@ extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* str
     if (lds > 160 * 1024) return 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_slide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_slide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_slide_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_slide_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_slide_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const long cols = (long)p.N * ((p.OH + R - 1) / R) * ((p.OW + WT - 1) / WT);
@@ -236,7 +276,13 @@ extern "C" int drc_tapconv_wgrad_slide_try(const drc_wgrad_params* pp, void* str
         const double cost = (double)((cols * ns + nworkers - 1) / nworkers) * (len + 0.75);
         if (cost < best - 1e-9) { best = cost; nseg = ns; seglen = len; }
     }
-    hipLaunchKernelGGL(wgrad_slide_kernel, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT, nseg, seglen);
+    // k-steps of the regressor's maps: 28- and 14-wide -> 56 slots (14), 7-wide -> 49 (13), full 64-slot tiles (16); anything else: run-time count
+    switch ((R * WT + 3) / 4) {
+        case 13: hipLaunchKernelGGL(wgrad_slide_kernel<13>, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT, nseg, seglen); break;
+        case 14: hipLaunchKernelGGL(wgrad_slide_kernel<14>, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT, nseg, seglen); break;
+        case 16: hipLaunchKernelGGL(wgrad_slide_kernel<16>, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT, nseg, seglen); break;
+        default: hipLaunchKernelGGL(wgrad_slide_kernel<0>, grid, dim3(64 * WS_WAVES), lds, (hipStream_t)stream, p, R, WT, nseg, seglen);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess || !partial) return e == hipSuccess ? 0 : (int)e;
     return drc_wgrad_reduce(p, (int)grid.x * WS_WAVES, jobs, 27, (hipStream_t)stream);
