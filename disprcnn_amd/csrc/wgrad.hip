@@ -240,11 +240,19 @@ int launch(const drc_wgrad_params& p0, hipStream_t s) {
     drc_wgrad_params p = p0;
     const long groups = (long)p.N * p.OD * ((p.OH + p.R - 1) / p.R) * ((p.OW + p.WT - 1) / p.WT);
     const long jobs = (long)p.nd * p.cb_a * p.cb_b;
-    // one wave per SIMD across all jobs: every extra wave adds a full set of atomicAdd flushes onto the same few addresses
-    // (measured on the Config-A train step: 8192 waves 60 ms, 1024 waves 41 ms)
-    long workers = 1024 / (jobs > 0 ? jobs : 1);
-    if (workers > groups) workers = groups;
-    if (workers < 1) workers = 1;
+    // Waves across all jobs.  With the atomicAdd flush every extra wave added a full set of atomics onto the same few addresses (Config-A
+    // train step: 8192 waves 60 ms, 1024 waves 41 ms), hence one wave per SIMD.  The partial-sum flush (round 2) costs one coalesced
+    // store per accumulator tile and wave, so the kernel is launched with three waves per SIMD (round 4:
+    // 1024 -> 3072 waves: 92 -> 64 us on Config B's 2D layers, 172 -> 90 us on Config A's strided / transposed ones, wgrad_reduce 5 -> 7
+    // us; four were slower again).  Falls back to one per SIMD when the partial sums of that many waves do not fit the scratch.
+    long per_simd = 3;        // (also where the LDS tiles admit fewer resident waves: the shorter work lists balance better -- measured)
+    long workers = 1;
+    for (; per_simd >= 1; --per_simd) {
+        workers = per_simd * 1024 / (jobs > 0 ? jobs : 1);
+        if (workers > groups) workers = groups;
+        if (workers < 1) workers = 1;
+        if (per_simd == 1 || drc_wgrad_scratch_fits(p, ((workers + WG_WAVES - 1) / WG_WAVES) * WG_WAVES * jobs, NT)) break;
+    }
     const size_t lds = (size_t)p.lds_bytes_per_wave * WG_WAVES;
     static bool attr_done = false;
     if (!attr_done) {
