@@ -393,9 +393,6 @@ __global__ __launch_bounds__(64 * T16_WAVES) void conv16s_kernel(const drc_tapco
 // s_waitcnt as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): the compiler's own wait-count pass
 // reads it.  Behind inline-asm waits it still believed the kernel's first loads (the weights) pending at the head of the od loop and
 // drained the queue before every step's first MFMA.
-#ifndef T16_DBG_N
-#define T16_DBG_N (NDMA + (RES ? 2 : 1) * NST)
-#endif
 #define T16_WAITCNT(vm, lgkm) (((vm) & 15) | (7 << 4) | ((lgkm) << 8) | (((vm) >> 4) << 14))
 #define T16_WAIT_BARRIER(imm) do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(imm); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -523,7 +520,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void conv16sp_kernel(const drc_tapc
             // in flight past this point: slice od+4 (NDMA), the next step's residual tile (NST if RES), the previous step's stores (NST)
             // -- all younger than slice od+3 and this step's residual tile.  (At od = 0 there are no stores yet and the prologue has
             // drained everything older: the wait is then simply weaker than it may be.)
-            __builtin_amdgcn_s_waitcnt(T16_WAITCNT(T16_DBG_N, 15));
+            __builtin_amdgcn_s_waitcnt(T16_WAITCNT(NDMA + (RES ? 2 : 1) * NST, 15));
             __builtin_amdgcn_sched_barrier(0);         // (the epilogue's register reads must not be scheduled above the wait)
             static_assert(NDMA + 2 * NST <= 63, "vmcnt is a 6-bit counter");
             // ---- epilogue of output slice od.  Buffer stores, the lanes without an output (j = 14, 15, columns past the map, g != 0 of the

@@ -1,4 +1,5 @@
-// conv16x.hip -- the fp16-storage STRIDE-2 and TRANSPOSED 3x3x3 convolutions with the input tile staged in LDS (gfx950 / CDNA4), round 4.
+// conv16x.hip -- the fp16-storage STRIDE-2, TRANSPOSED and (two input blocks / 64 couts) STRIDE-1 3x3x3 convolutions with the input tile staged
+// in LDS and ONE cout tile per wave; the fp16 cost volume folded into the first layer's stage addresses (gfx950 / CDNA4), round 4.
 //
 //   reference arithmetic: hourglass conv1 / conv3 (convbn_3d k3 s2 p1) and conv5 / conv6 (ConvTranspose3d k3 s2 p1 output_padding 1 + BN),
 //   stackhourglass.py:11-30,35-49; fp16 storage, fp32 accumulation on v_mfma_f32_16x16x32_f16 as in conv16.hip / conv16t.hip (the reference
@@ -7,12 +8,16 @@
 // Why: these twelve launches of the stress shape (BASELINE configs[3]) ran on conv16.hip's generic tap walk, which reads both MFMA operands
 // from global memory -- MFMA busy 6 %, 3.5 of the regressor's 8.6 ms (profiles/r4_stress16_*).  conv16t.hip's recipe (a block of four waves
 // stages the input rows of its output tile once per channel block with LDS-DMA, every tap reads its B fragment from LDS, weights through
-// the vector-memory path a few taps ahead) carries over with two changes:
+// the vector-memory path a few taps ahead) carries over with the changes below -- and with one it did not have: a wave owns ONE 16-channel cout
+// tile and seven rows (CW cout tiles x RG row groups per block).  With every wave on all cout tiles and two rows, the layer's whole weight
+// set went through L2 per two rows of output (2.65 GB per launch of conv6) and THAT bounded the kernels (see conv16u_kernel).
 //
 //   * stride 2 (conv16d_kernel): output column j of tap kw reads input column 2j + kw.  A staged input row is split into its even and odd
 //     columns -- two 1-KiB planes, one global_load_lds each (lane (g, v) fetches channels 8g..8g+7 of column 2v + plane: still one 64-byte
 //     line per four lanes) -- so that tap kw reads plane kw & 1 at entry j + (kw >> 1): unit stride over the lanes, no bank conflicts.
-//     Rows: output row r of tap kh reads staged row 2r + kh (2 TR + 1 rows per depth tap); depth taps are staged one at a time.
+//     Rows: output row r of tap kh reads staged row 2r + kh (2 TR + 1 rows per depth tap); (channel block, depth tap) stages are
+//     double-buffered.  The same kernel at stride 1 (ST = 1) serves the stride-1 layers conv16t.hip's depth-sliding walk does not take, and
+//     with CV = true it reads the cost volume's rows straight from the feature pair (drc_conv16_k3_costvol_fwd).
 //   * transposed (conv16u_kernel): the eight output-parity classes are stride-1 convolutions over the INPUT grid with 1, 2, 4 or 8 taps
 //     (o = 2i - 1 + k: an even output has the single tap k = 1 at i, an odd one k = 2 at i and k = 0 at i + 1).  A block stages the
 //     (TR + 1) x 16 input positions of its tile in the two depth slices i, i + 1 for ALL channel blocks once, then walks the classes:
@@ -36,7 +41,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define X16_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define X16_WAVES 4
 #define X16_COLS 14
-#define X16_WPF 4          // weight sets (taps) requested ahead of their MFMAs
 
 namespace {
 
