@@ -23,6 +23,47 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().drc_version()
 
 
+def test_round4_fp16_entries_reject_bad_arguments_without_launching():
+    """The conv16x.hip entries validate before they launch (no GPU needed): null block / pointers -> -1, empty grid -> -2, a parameter block
+    that is not the layer the entry implements -> -4 (`_supported` -> 0); an empty batch is a no-op (0)."""
+    from disprcnn_amd import _lib, engine as E
+    L = _lib.lib()
+    p = _lib.DrcTapconvParams()
+    for fn in (L.drc_conv16_k3s2_tile_fwd, L.drc_deconv16_k3s2_tile_fwd):
+        assert fn(None, None) == -1 and fn(ctypes.byref(p), None) == -1
+    assert L.drc_conv16_k3_costvol_fwd(None, 0, None) == -1 and L.drc_conv16_k3_costvol_fwd(ctypes.byref(p), 0, None) == -1
+    assert L.drc_conv16_k3s2_tile_supported(None) == 0 and L.drc_deconv16_k3s2_tile_supported(None) == 0
+    buf = (ctypes.c_float * 64)()
+    addr = ctypes.addressof(buf)
+    for f in ("x", "w", "y", "scale", "shift"):
+        setattr(p, f, addr)
+    p.N, p.OD, p.OH, p.OW = 1, 0, 4, 4
+    assert L.drc_conv16_k3s2_tile_fwd(ctypes.byref(p), None) == -2 and L.drc_deconv16_k3s2_tile_fwd(ctypes.byref(p), None) == -2
+    assert L.drc_conv16_k3_costvol_fwd(ctypes.byref(p), 0, None) == -2
+    p.OD = 4
+    p.N = 0
+    assert L.drc_conv16_k3s2_tile_fwd(ctypes.byref(p), None) == 0 and L.drc_conv16_k3_costvol_fwd(ctypes.byref(p), 0, None) == 0
+    p.N = 1                                                   # a zeroed class table is none of the three layers
+    assert L.drc_conv16_k3s2_tile_supported(ctypes.byref(p)) == 0 and L.drc_deconv16_k3s2_tile_supported(ctypes.byref(p)) == 0
+    assert L.drc_conv16_k3s2_tile_fwd(ctypes.byref(p), None) == -4 and L.drc_deconv16_k3s2_tile_fwd(ctypes.byref(p), None) == -4
+    assert L.drc_conv16_k3_costvol_fwd(ctypes.byref(p), 0, None) == -4
+    # the class tables the engine builds ARE recognised (stride-2 conv and transposed conv), and not by the other entry
+    def fill(classes, in_mul, out_mul, cb_in, cout_pad):
+        q = _lib.DrcTapconvParams()
+        q.n_classes, q.in_mul, q.out_mul, q.cb_in, q.cout_pad = len(classes), in_mul, out_mul, cb_in, cout_pad
+        for ci, c in enumerate(classes):
+            k = q.cls[ci]
+            k.nd, k.nh, k.nw = c["n"]; k.dd0, k.dh0, k.dw0 = c["first"]; k.sd, k.sh, k.sw = c["step"]
+            k.wbase = c["wbase"]; k.wsd, k.wsh, k.wsw = c["wstep"]; k.out_off_d, k.out_off_h, k.out_off_w = c["off"]
+        return q
+    down = fill(E.taps_conv((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1)), 2, 1, 1, 64)
+    up = fill(E.taps_deconv3d_k3s2(), 1, 2, 2, 32)
+    assert L.drc_conv16_k3s2_tile_supported(ctypes.byref(down)) == 1 and L.drc_deconv16_k3s2_tile_supported(ctypes.byref(down)) == 0
+    assert L.drc_deconv16_k3s2_tile_supported(ctypes.byref(up)) == 1 and L.drc_conv16_k3s2_tile_supported(ctypes.byref(up)) == 0
+    up.cb_in = 5                                              # more input blocks than the instantiated stages: conv16.hip keeps the layer
+    assert L.drc_deconv16_k3s2_tile_supported(ctypes.byref(up)) == 0
+
+
 def test_params_struct_matches_header_size():
     """sizeof(drc_tapconv_params) computed by gcc must equal the ctypes mirror."""
     import subprocess, tempfile
