@@ -584,6 +584,209 @@ int launch_slide_deep(const drc_tapconv_params& p, hipStream_t stream) {
     return p.res ? launch_slide_deep_mode<RW, 1, 1>(p, stream) : launch_slide_deep_mode<RW, 1, 0>(p, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16sw_kernel<RW,CW,SLOTS,RES,CV>: the depth walk for TWO input blocks (64 input channels: dres0[0] on the cost volume, hourglass
+// conv2 / conv4), one cout tile per wave (round 4).  conv16x.hip's conv16d_kernel re-stages three depth slices per output slice in six
+// (channel block, depth tap) stages -- six barriers and 63 MFMAs per stage and wave, bound by the DMA round trips (584 us for dres0[0],
+// MFMA floor 243).  Here, as in conv16sp_kernel: the block's four waves are CW cout tiles x RG = 4/CW row groups, a wave holds the 54
+// weight fragments of ITS cout tile in registers (216 VGPRs, one wave per SIMD), the block owns a (n, row tile, column tile) column and
+// walks od with a ring of SLOTS slices ([cb 2][TR + 2 rows][1 KiB] each): one new slice and one barrier per output slice, 378 MFMAs
+// per step and wave at RW = 7, no vector-memory instruction in the MFMA phase.  SLOTS = 5: slice od+4 is requested at step od and the
+// wait at its end is counted (see conv16sp_kernel); SLOTS = 4 (the 14-row tiles of dres0[0]: 32 KiB per slice): slice od+3, the wait
+// leaves only the next residual tile in flight -- enough for CV, whose source rows are L2-resident.
+// CV: p.x is the feature pair (see conv16x.hip's conv16d_kernel): slice d of the cost volume = the left rows where the shifted pixel
+// exists | the right rows moved by lo4 + d columns; lanes whose voxel is zero in the volume fetch column 0 of the row (the zero halo).
+// Rows must fill the tiles (OH % TR == 0), as for every counted-wait kernel.
+template <int RW, int CW, int SLOTS, bool RES, bool CV>
+__global__ __launch_bounds__(64 * T16_WAVES) void conv16sw_kernel(const drc_tapconv_params p, const int lo4) {
+    constexpr int RG = T16_WAVES / CW;
+    constexpr int TR = RW * RG;
+    constexpr int NR = TR + 2;                         // staged rows per slice and channel block
+    constexpr int SLOT = 2 * NR * 1024;
+    constexpr int AHEAD = SLOTS - 3;                   // slices in flight beyond the three a step reads
+    constexpr int NDMA = (2 * NR + T16_WAVES - 1) / T16_WAVES;
+    constexpr int NST = RW;                            // stores per step = residual loads per step (RES)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef const __attribute__((address_space(3))) volatile f16x8 lds_frag;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wave % CW, rg = wave / CW;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const _Float16* x = (const _Float16*)p.x;
+    const drc_tap_class cls = p.cls[0];
+    const int xh = (int)p.x_h_stride, xd = (int)p.x_d_stride, xc = (int)p.x_cb_stride;
+    const int yh = (int)p.y_h_stride, yd_ = (int)p.y_d_stride, yc = (int)p.y_cb_stride;
+    const int rh = (int)p.r_h_stride, rd_ = (int)p.r_d_stride, rc = (int)p.r_cb_stride;
+    const int n_ct = (p.OW + T16_COLS - 1) / T16_COLS, n_rt = p.OH / TR, n_cg = p.cout_pad / 16 / CW;
+    const unsigned columns = (unsigned)p.N * n_rt * n_ct * n_cg;
+    const int Wp = xh / 32;
+    const unsigned lane_b = (unsigned)(g * 256 + j * 16 + rg * RW * 1024);
+    const __attribute__((address_space(3))) char* ring = (const __attribute__((address_space(3))) char*)lds;
+
+    f32x4 acc[RW];
+    for (unsigned col = blockIdx.x; col < columns; col += gridDim.x) {
+        unsigned t = col, u;
+        u = t / (unsigned)n_cg; const int cg = (int)(t - u * (unsigned)n_cg); t = u;       // cout group fastest: neighbours share the input column in L2
+        u = t / (unsigned)n_ct; const int c0 = (int)(t - u * (unsigned)n_ct) * T16_COLS; t = u;
+        u = t / (unsigned)n_rt; const int r0 = (int)(t - u * (unsigned)n_rt) * TR;
+        const int n = (int)u;
+        const int cot = cg * CW + cw;
+        // this wave's cout tile: all 2 x 27 weight fragments -> registers (once per column; the columns of a block mostly share cg)
+        f16x8 wreg[2][27];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap)
+                wreg[cb][tap] = *(const f16x8*)((const _Float16*)p.w + (((long)tap * 2 + cb) * p.cout_pad + cot * 16 + j) * 32 + g * 8);
+        const f32x4 sc_ = *(const f32x4*)(p.scale + cot * 16 + g * 4), sh_ = *(const f32x4*)(p.shift + cot * 16 + g * 4);
+        int colE = c0 + cls.dw0 + j;
+        colE = colE < Wp ? colE : Wp - 1;
+        const _Float16* src0 = x + (long)n * p.x_n_stride + ((r0 + cls.dh0) * xh + g * 8);
+        auto stage = [&](int ps, int slot) __attribute__((always_inline)) {            // padded slice ps (clamped to the last one) -> ring slot
+            const int psc = ps < p.OD + 2 ? ps : p.OD + 1;
+            char* dst = lds + slot * SLOT;
+            int col0 = colE, col1 = colE;              // source column of this lane in channel block 0 / 1
+            if constexpr (CV) {
+                const int d = psc + cls.dd0 - 1, sft = lo4 + d, xw = colE - 1, xs = xw - sft, Wr = Wp - 2;
+                const bool ok = d >= 0 && d < p.OD && xw >= 0 && xw < Wr && xs >= 0 && xs < Wr;
+                col0 = ok ? colE : 0;
+                col1 = ok ? xs + 1 : 0;
+            }
+            const _Float16* sd = src0 + (CV ? 1 : psc + cls.dd0) * xd;
+#pragma unroll
+            for (int k = 0; k < NDMA; ++k) {
+                int i = k * T16_WAVES + wave;
+                i = i < 2 * NR ? i : 2 * NR - 1;
+                const int cb = i >= NR ? 1 : 0, rr = i - cb * NR;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(sd + (cb * xc + rr * xh + (cb ? col1 : col0) * 32)), LDS_PTR(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        const int col_ = c0 + j;
+        const bool col_ok = j < T16_COLS && col_ < p.OW;
+        const int col_c = col_ < p.OW ? col_ : p.OW - 1;
+        const int row0 = r0 + rg * RW;
+        const _Float16* res = (const _Float16*)p.res + p.r_off0 + (long)n * p.r_n_stride + ((cot >> 1) * rc + (cot & 1) * 16 + g * 4);
+        const __amdgpu_buffer_rsrc_t yr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((_Float16*)p.y + p.y_off0 + (long)n * p.y_n_stride), 0, 0x7FFFFF00, 0x00020000);
+        f16x4 rv[2][RW];
+        auto res_request = [&](int od, int set) __attribute__((always_inline)) {        // always NST loads (RES), whatever od
+            if constexpr (RES) {
+                const int odc = od < p.OD ? od : p.OD - 1;
+                const int rl = odc * rd_ + row0 * rh + col_c * 32;
+#pragma unroll
+                for (int r = 0; r < RW; ++r) rv[set][r] = *(const f16x4*)(res + rl + r * rh);
+            }
+        };
+        // every wave is done with the previous column's slots before they are overwritten
+        T16_WAIT_BARRIER(T16_WAITCNT(63, 0));
+#pragma unroll
+        for (int s_ = 0; s_ < SLOTS - 1; ++s_) stage(s_, s_);
+        res_request(0, 0);
+        T16_WAIT_BARRIER(T16_WAITCNT(0, 15));
+        int s0 = 0, sn = SLOTS - 1;                    // ring slots of padded slice od and of the slice requested at step od
+        auto step = [&](int od, auto SET) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET)::value;
+            stage(od + SLOTS - 1, sn);
+            res_request(od + 1, set ^ 1);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int s1 = s0 + 1 < SLOTS ? s0 + 1 : s0 + 1 - SLOTS, s2 = s0 + 2 < SLOTS ? s0 + 2 : s0 + 2 - SLOTS;
+            const __attribute__((address_space(3))) char* sl[3] = {ring + s0 * SLOT + lane_b, ring + s1 * SLOT + lane_b, ring + s2 * SLOT + lane_b};
+            f16x8 rowA[RW + 2], rowB[RW + 2];
+            // group = (channel block, depth tap, column tap): RW + 2 rows read once, 3 RW MFMAs
+            auto gfetch = [&](f16x8 (&rows)[RW + 2], int grp) __attribute__((always_inline)) {
+                const int cb = grp / 9, kd = (grp / 3) % 3, kw = grp % 3;
+#pragma unroll
+                for (int rr = 0; rr < RW + 2; ++rr) rows[rr] = *(lds_frag*)(sl[kd] + cb * NR * 1024 + kw * 16 + rr * 1024);
+            };
+            auto gmfma = [&](const f16x8 (&rows)[RW + 2], int grp) __attribute__((always_inline)) {
+                const int cb = grp / 9, kd = (grp / 3) % 3, kw = grp % 3;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[cb][(kd * 3 + kh) * 3 + kw], rows[r + kh], acc[r], 0, 0, 0);
+            };
+            gfetch(rowA, 0);
+#pragma unroll
+            for (int grp = 0; grp < 18; ++grp) {
+                if (grp + 1 < 18) { if (grp & 1) gfetch(rowA, grp + 1); else gfetch(rowB, grp + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp & 1) gmfma(rowB, grp); else gmfma(rowA, grp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // younger than the slice the next step needs and this step's residual tile: AHEAD - 1 stage requests (only the one of this
+            // step when AHEAD = 2), the next step's residual tile (RES), the previous step's stores when the requests of this step are
+            // allowed to stay (AHEAD = 2)
+            __builtin_amdgcn_s_waitcnt(T16_WAITCNT(AHEAD == 2 ? NDMA + (RES ? 2 : 1) * NST : (RES ? NST : 0), 15));
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned yo = col_ok ? (unsigned)((od * yd_ + row0 * yh + col_ * 32 + g * 4 + (cot >> 1) * yc + (cot & 1) * 16) * 2) : 0x80000000u;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                f32x4 v = acc[r] * sc_ + sh_;
+                if constexpr (RES) { v.x += (float)rv[set][r].x; v.y += (float)rv[set][r].y; v.z += (float)rv[set][r].z; v.w += (float)rv[set][r].w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                f16x4 hv;
+                hv.x = (_Float16)v.x; hv.y = (_Float16)v.y; hv.z = (_Float16)v.z; hv.w = (_Float16)v.w;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), yr, yo + (unsigned)(r * yh * 2), 0, 0);
+            }
+            T16_WAIT_BARRIER(T16_WAITCNT(63, 0));      // every wave's share of the awaited slice landed; everyone is done reading slice od's slot
+            s0 = s1;
+            sn = sn + 1 < SLOTS ? sn + 1 : 0;
+        };
+        for (int od = 0; od < p.OD; od += 2) {
+            step(od, std::integral_constant<int, 0>{});
+            if (od + 1 < p.OD) step(od + 1, std::integral_constant<int, 1>{});
+        }
+    }
+}
+
+template <int RW, int CW, bool RES, bool CV>
+int launch_walk2_mode(const drc_tapconv_params& p, hipStream_t stream, int lo4) {
+    constexpr int TR = RW * (T16_WAVES / CW);
+    constexpr int SLOTS = 5 * 2 * (TR + 2) * 1024 + 1024 <= 160 * 1024 ? 5 : 4;
+    constexpr size_t lds = (size_t)SLOTS * 2 * (TR + 2) * 1024 + 1024;
+    static_assert(lds <= 160 * 1024, "ring exceeds the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv16sw_kernel<RW, CW, SLOTS, RES, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const long columns = (long)p.N * (p.OH / TR) * ((p.OW + T16_COLS - 1) / T16_COLS) * (p.cout_pad / 16 / CW);
+    if (columns >= (1L << 31)) return -5;
+    long blocks = 256;                                   // one block per CU: the weights take the wave's register file
+    if (blocks > columns) blocks = columns;
+    hipLaunchKernelGGL((conv16sw_kernel<RW, CW, SLOTS, RES, CV>), dim3((unsigned)blocks), dim3(64 * T16_WAVES), lds, stream, p, lo4);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// The two-block depth walk for a stride-1 3x3x3 layer (cv: on the feature pair, see drc_conv16_k3_costvol_fwd).  Returns 1 when the
+// shape is not one it takes (the caller keeps conv16x.hip's staged kernel), else 0 / a hipError_t.  Callers have validated p.
+int drc_t16_conv3d_walk2_try(const drc_tapconv_params& p, hipStream_t s, bool cv, int lo4) {
+#ifndef T16_WALK2
+#define T16_WALK2 1
+#endif
+    if (!T16_WALK2 || p.cb_in != 2 || p.cls[0].nd != 3 || p.reserved == 1 || p.OD < 4) return 1;
+    if (cv && p.res) return 1;
+    const int ct = p.cout_pad / 16;
+    const bool res = p.res != nullptr;
+    if (ct % 4 == 0) {                                   // four cout tiles side by side, seven rows
+        if (p.OH % 7) return 1;
+        if (cv) return launch_walk2_mode<7, 4, false, true>(p, s, lo4);
+        return res ? launch_walk2_mode<7, 4, true, false>(p, s, 0) : launch_walk2_mode<7, 4, false, false>(p, s, 0);
+    }
+    if (ct % 2 == 0) {                                   // two cout tiles x two row groups: 14-row tiles
+        if (p.OH % 14) return 1;
+        if (cv) return launch_walk2_mode<7, 2, false, true>(p, s, lo4);
+        return res ? launch_walk2_mode<7, 2, true, false>(p, s, 0) : launch_walk2_mode<7, 2, false, false>(p, s, 0);
+    }
+    return 1;
+}
+
+namespace {
+
 template <int RW, int CT>
 int launch_slide(const drc_tapconv_params& p, hipStream_t stream) {
     constexpr int TR = RW * T16_WAVES;
@@ -675,6 +878,10 @@ extern "C" int drc_conv16_k3_tile_fwd(const drc_tapconv_params* pp, void* stream
         if (p.cout_pad == 32) return tall ? launch_slide<4, 2>(p, s) : launch_slide<2, 2>(p, s);
         return tall ? launch_slide<4, 1>(p, s) : launch_slide<2, 1>(p, s);
     }
-    if (T16_X3D && p.cls[0].nd == 3 && p.reserved != 1) return drc_x16_conv3d_s1_launch(p, s);      // conv16x.hip: cout-split waves, double-buffered stages (round 4)
+    if (T16_X3D && p.cls[0].nd == 3 && p.reserved != 1) {
+        const int st = drc_t16_conv3d_walk2_try(p, s, false, 0);                                   // two input blocks, full row tiles: the depth walk (round 4)
+        if (st != 1) return st;
+        return drc_x16_conv3d_s1_launch(p, s);      // conv16x.hip: cout-split waves, double-buffered stages (round 4)
+    }      // conv16x.hip: cout-split waves, double-buffered stages (round 4)
     return p.cls[0].nd == 3 ? pick<3>(p, s) : pick<1>(p, s);
 }

@@ -416,6 +416,8 @@ int drc_x16_conv3d_s1_launch(const drc_tapconv_params& p, hipStream_t s) {
     return launch_d<1, 1>(p, s);
 }
 
+int drc_t16_conv3d_walk2_try(const drc_tapconv_params& p, hipStream_t s, bool cv, int lo4);       // conv16t.hip
+
 extern "C" int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* pp, int mindisp4, void* stream) {
     if (!pp) return -1;
     const drc_tapconv_params& p = *pp;
@@ -430,6 +432,10 @@ extern "C" int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* pp, int mindi
     if (p.x_h_stride != (int64_t)(p.OW + 2) * 32 || p.x_d_stride != (int64_t)(p.OH + 2) * p.x_h_stride) return -4;   // the feature pair: halo 1
     if (int e = x16_check_sizes(p)) return e;
     hipStream_t s = (hipStream_t)stream;
+    {   // full row tiles: the depth walk with the weights in registers (conv16t.hip's conv16sw_kernel)
+        const int st = drc_t16_conv3d_walk2_try(p, s, true, mindisp4);
+        if (st != 1) return st;
+    }
     const int ct = p.cout_pad / 16;
     if (ct % 4 == 0) return launch_d<4, 1, true>(p, s, mindisp4);
     if (ct % 2 == 0) return launch_d<2, 1, true>(p, s, mindisp4);

@@ -1126,6 +1126,11 @@ def choose_tile16(OH, OW):
 C16_TILE = {"enabled": True}      # 3x3x3 / 3x3 fp16 layers on the LDS-tiled kernels (conv16t.hip: stride 1; conv16x.hip: stride 2 and transposed, round 4); False: conv16.hip as in round 2
 
 
+def walk2_takes(cb, OD, OH, cw):
+    """conv16t.hip's drc_t16_conv3d_walk2_try: two input blocks, depth >= 4, rows filling the 7-row (four cout tiles) / 14-row (two) tiles."""
+    return cb == 2 and OD >= 4 and cw in (2, 4) and OH % (7 * (4 // cw)) == 0
+
+
 def x16_rows(OH, cw, stride, cb=1):
     """Rows per wave of the conv16x.hip kernels (launch_d / launch_u there): the big tile unless it pads the map's rows by more than
     25 % over the small one's.  stride 0 = the transposed kernel (big = seven rows if its stage leaves two blocks per CU)."""
@@ -1180,6 +1185,8 @@ class ConvPlan16:
                     self.kname = "conv16sp_kernel<%d,%d>" % (7 if OH % 28 == 0 else 4, ct)
             elif classes[0]["n"][0] == 3 and not dense1:                                     # conv16x.hip, stride 1 (round 4)
                 self.kname = "conv16d_kernel<%d,%d,1>" % (x16_rows(OH, cw, 1), cw)
+                if walk2_takes(x.cb, OD, OH, cw):                                            # two input blocks, full row tiles: the depth walk
+                    self.kname = "conv16sw_kernel<7,%d>" % cw
             else:
                 self.kname = "conv16t_kernel<%d,%d,%d>" % (rw, cw, classes[0]["n"][0])
         self.costvol_lo4 = None          # plan_conv3d16_costvol: x is the feature pair, the cost volume is folded into the stage addresses
@@ -1250,6 +1257,8 @@ def plan_conv3d16_costvol(pair, y, lo4, cout, relu):
     ct = pl.p.cout_pad // 16
     cw = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
     pl.kname = "conv16d_kernel<%d,%d,1,cv>" % (x16_rows(y.H, cw, 1), cw)
+    if walk2_takes(2, y.D, y.H, cw):
+        pl.kname = "conv16sw_kernel<7,%d,cv>" % cw
     pl.flops = 2 * y.N * y.D * y.H * y.W * 27 * 64 * cout
     return pl
 

@@ -35,7 +35,8 @@ def _h(t):
     (40, 48, 2, False, (6, 10, 18), False), (32, 32, 1, False, (2, 56, 56), True),
     # one input block, <= 32 couts, depth >= 4: the depth-sliding walk (conv16s_kernel), incl. ragged rows / columns and 16 couts
     (32, 32, 1, False, (6, 28, 28), True), (32, 32, 1, False, (5, 20, 17), False), (24, 16, 1, False, (4, 9, 30), True),
-    (32, 32, 1, False, (9, 56, 56), True), (32, 32, 1, False, (5, 16, 20), True), (32, 32, 1, False, (4, 32, 14), False), (20, 16, 1, False, (7, 28, 30), True),
+    (32, 32, 1, False, (9, 56, 56), True), (64, 64, 1, False, (6, 28, 28), True), (64, 64, 1, False, (5, 14, 17), False), (64, 32, 1, False, (4, 28, 30), True),
+    (40, 64, 1, False, (7, 7, 14), False), (64, 32, 1, False, (6, 56, 56), False), (32, 32, 1, False, (5, 16, 20), True), (32, 32, 1, False, (4, 32, 14), False), (20, 16, 1, False, (7, 28, 30), True),
     # round 4 (conv16x.hip): the stress shape's stride-2 / transposed layers at full size, odd input extents, one row / column tiles
     (32, 64, 2, False, (8, 56, 56), True), (64, 32, 1, True, (4, 28, 28), True), (64, 64, 2, False, (5, 27, 31), False),
     (32, 16, 1, True, (2, 3, 5), False), (96, 32, 2, False, (4, 8, 8), True), (96, 64, 1, True, (2, 13, 15), True)])
@@ -61,9 +62,11 @@ def test_conv16_layer_vs_fp32_conv_of_rounded_operands(dev, cin, cout, stride, t
     assert plan.tile == (stride == 1 and not transposed)            # stride-1 layers: drc_conv16_k3_tile_fwd (conv16t.hip's entry)
     assert plan.tile_x == (None if plan.tile else ("drc_deconv16_k3s2_tile_fwd" if transposed else "drc_conv16_k3s2_tile_fwd"))    # round 4: conv16x.hip
     slide = plan.tile and cin <= 32 and cout <= 32 and dims[0] >= 4                  # conv16t.hip's depth-sliding walk; everything else: conv16x.hip
-    assert plan.kname.startswith("conv16u_kernel" if transposed else (("conv16s_kernel", "conv16sp_kernel") if slide else "conv16d_kernel")), plan.kname
+    cw = 4 if cp % 64 == 0 else (2 if cp % 32 == 0 else 1)
+    walk2 = plan.tile and not slide and E.walk2_takes((cin + 31) // 32, dims[0], dims[1], cw)           # two input blocks, full row tiles: conv16sw_kernel
+    assert plan.kname.startswith("conv16u_kernel" if transposed else (("conv16s_kernel", "conv16sp_kernel") if slide else ("conv16sw_kernel" if walk2 else "conv16d_kernel"))), plan.kname
     assert not slide or plan.kname.startswith("conv16sp_kernel") == (dims[1] % 28 == 0 or dims[1] % 16 == 0)      # full row tiles: the counted-wait walk
-    assert transposed or slide or plan.kname.endswith(",%d>" % stride), plan.kname
+    assert transposed or slide or walk2 or plan.kname.endswith(",%d>" % stride), plan.kname
     plan.run(xb, E.pack_weight16(w.to(dev), transposed), sc, sh, yb, rb)
     got = yb.to_dense().cpu()
     assert got.shape == ref.shape
@@ -97,7 +100,8 @@ def test_conv16_classifier_dense_head_and_cost_volume(dev):
         assert torch.equal(cv.to_dense().cpu(), _h(O.cost_volume(fl, fr, mx, mn)))
 
 
-@pytest.mark.parametrize("mx,mn,hw,cout", [(48, 0, (28, 28), 32), (48, -48, (56, 56), 32), (24, -24, (9, 30), 32), (16, 0, (5, 17), 64), (32, -16, (13, 16), 16)])
+@pytest.mark.parametrize("mx,mn,hw,cout", [(48, 0, (28, 28), 32), (48, -48, (56, 56), 32), (24, -24, (9, 30), 32), (16, 0, (5, 17), 64), (32, -16, (13, 16), 16),
+                                           (32, -16, (14, 30), 64), (16, 0, (14, 9), 32), (12, 0, (28, 28), 32)])
 def test_costvol_fused_first_layer_is_bit_identical(dev, mx, mn, hw, cout):
     """dres0[0] on the fp16 cost volume WITHOUT the volume (drc_conv16_k3_costvol_fwd: the stage addresses of conv16x.hip point at the feature
     pair, zero voxels at the zero halo) == the materialised volume (pinned above against the oracle's) through the same layer, bit for bit;
@@ -114,13 +118,14 @@ def test_costvol_fused_first_layer_is_bit_identical(dev, mx, mn, hw, cout):
     E.cost_volume16_blocked(fl.to(dev), fr.to(dev), cv, mn // 4, mx // 4, -1)
     y_ref = E.Blocked16(n, cout, D, *hw, 1, 1, 1, dev)
     ref_plan = E.plan_conv3d16(cv, y_ref, 1, cout, True)
-    assert ref_plan.kname.startswith("conv16d_kernel<") and ref_plan.kname.endswith(",1>")
+    assert ref_plan.kname.startswith(("conv16d_kernel<", "conv16sw_kernel<"))
     ref_plan.run(cv, w16, sc, sh, y_ref)
     pair = E.Blocked16(n, 64, 1, *hw, 1, 1, 1, dev)
     E.cost_volume16_blocked(fl.to(dev), fr.to(dev), pair, 0, 1, -1)
     y = E.Blocked16(n, cout, D, *hw, 1, 1, 1, dev)
     plan = E.plan_conv3d16_costvol(pair, y, mn // 4, cout, True)
-    assert plan.kname.endswith(",1,cv>") and plan.flops == ref_plan.flops
+    assert plan.kname.endswith(",cv>") and plan.flops == ref_plan.flops
+    assert plan.kname.startswith("conv16sw_kernel") == (D >= 4 and cout in (32, 64) and hw[0] % (14 if cout == 32 else 7) == 0), plan.kname
     plan.run(pair, w16, sc, sh, y)
     assert torch.equal(y.storage, y_ref.storage)                     # interior and (zero) halo alike
     assert y_ref.to_dense().abs().max().item() > 0.1

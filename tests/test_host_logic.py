@@ -320,8 +320,10 @@ def test_fp16_kernel_selection():
     assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16sp_kernel<7,2>"         # 56 rows = two full 28-row tiles: the counted-wait walk
     assert E.plan_conv3d16(geo(4, 32, 24, 20, 56), geo(4, 32, 24, 20, 56), 1, 32, True).kname == "conv16s_kernel<2,2>"          # ragged rows: conv16s
     assert E.plan_conv3d16(geo(4, 32, 24, 32, 56), geo(4, 32, 24, 32, 56), 1, 32, True).kname == "conv16sp_kernel<4,2>"
-    assert E.plan_conv3d16(geo(4, 64, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16d_kernel<7,2,1>"      # two input blocks
-    assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16d_kernel<7,4,1>"
+    assert E.plan_conv3d16(geo(4, 64, 24, 56, 56), geo(4, 32, 24, 56, 56), 1, 32, True).kname == "conv16sw_kernel<7,2>"       # two input blocks, 56 = 4 x 14 rows: the two-block depth walk
+    assert E.plan_conv3d16(geo(4, 64, 24, 20, 56), geo(4, 32, 24, 20, 56), 1, 32, True).kname == "conv16d_kernel<2,2,1>"      # ragged rows: staged kernel
+    assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16sw_kernel<7,4>"
+    assert E.plan_conv3d16(geo(4, 96, 12, 28, 28), geo(4, 64, 12, 28, 28), 1, 64, True).kname == "conv16d_kernel<7,4,1>"       # three input blocks
     assert E.plan_conv3d16(geo(4, 32, 3, 28, 28), geo(4, 32, 3, 28, 28), 1, 32, True).kname == "conv16d_kernel<7,2,1>"        # depth < 4
     assert E.plan_conv3d16(geo(4, 32, 24, 56, 56), geo(4, 64, 12, 28, 28), 2, 64, True).kname == "conv16d_kernel<7,4,2>"
     assert E.plan_conv3d16(geo(4, 64, 12, 28, 28), geo(4, 64, 6, 14, 14), 2, 64, True).kname == "conv16d_kernel<7,4,2>"
