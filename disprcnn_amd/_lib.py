@@ -130,6 +130,7 @@ _SIGS = {
     "drc_cost_volume16_from16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv16_k3_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
     "drc_conv16_k3_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
+    "drc_conv2d_k3s2_stem_fwd": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _I, _I, _I, _P]),
     "drc_conv16_k3_costvol_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv16_k3s2_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
     "drc_conv16_k3s2_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),

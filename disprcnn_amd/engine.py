@@ -331,6 +331,35 @@ def pack_weight_deconv_direct(w, transposed=True, flip=False):
     return t16.index_select(0, order).permute(1, 0, 2, 3).contiguous()
 
 
+STEM_DIRECT = {"enabled": True}      # eval: firstconv[0] straight from the dense image (stemconv.hip, round 4) instead of layout conversion + downdirect
+
+
+def pack_weight_stem(w):
+    """Conv2d(3 -> cout, 3x3) weight [cout,3,3,3] -> [7][cout_pad][4]: k = channel * 9 + tap in steps of four, zero past k = 26 (stemconv.hip)."""
+    cout = w.shape[0]
+    if tuple(w.shape[1:]) != (3, 3, 3):
+        raise ValueError("pack_weight_stem expects a [cout,3,3,3] weight")
+    cp = cout_pad_of(cout)
+    wp = torch.zeros(cp, 28, dtype=torch.float32, device=w.device)
+    wp[:cout, :27] = w.detach().float().reshape(cout, 27)
+    return wp.view(cp, 7, 4).permute(1, 0, 2).contiguous()
+
+
+def stem_conv(images, w_packed, scale, shift, y, relu=True):
+    """images fp32 NCHW [N,3,H,W] (dense) -> y: Blocked [N,cout,1,(H+1)//2,(W+1)//2]: Conv2d k3 s2 p1 + folded BN (+ReLU), reference
+    submodule.py:65-66.  No layout conversion of the image."""
+    require_gpu(images, "stem_conv")
+    if images.dim() != 4 or images.shape[1] != 3 or images.dtype != torch.float32:
+        raise ValueError("stem_conv expects a float32 [N,3,H,W] image batch")
+    N, _, H, W = images.shape
+    if (y.N, y.D, y.H, y.W) != (N, 1, (H + 1) // 2, (W + 1) // 2):
+        raise ValueError("stem_conv: output geometry does not match a 3x3 stride-2 pad-1 convolution of the input")
+    x = images.contiguous()
+    st = _lib.lib().drc_conv2d_k3s2_stem_fwd(_ptr(x), N, H, W, _ptr(w_packed), w_packed.shape[1], _ptr(scale), _ptr(shift), _ptr(y.storage),
+                                             y.n_stride, y.cb_stride, y.h_stride, y.interior_off, y.H, y.W, int(relu), _stream_ptr(y.device))
+    _lib.check(st, "drc_conv2d_k3s2_stem_fwd")
+
+
 def pack_conv_weight(w, transposed=False):
     """The packing the engine's plan for this convolution expects (pointwise for 1x1 Conv2d, tap layout otherwise)."""
     return pack_weight_pw(w) if is_pointwise(w.shape, transposed) else pack_weight(w, transposed)

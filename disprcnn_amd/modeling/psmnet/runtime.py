@@ -47,6 +47,7 @@ class _Conv:
         else:
             self.w, self.w16 = E.pack_weight(w, transposed), (E.pack_weight_t16(w, transposed) if need16 else None)
         self._ww = None
+        self._stem = None                   # firstconv[0] only: the packing of stemconv.hip, built on first use
         cout_pad = E.cout_pad_of(self.cout)
         self.cout_pad, self.device = cout_pad, device
         self.bn = bn
@@ -625,12 +626,20 @@ class PSMNetRuntime:
         t, p = ws["t"], ws["p"]
         lib = _lib.lib()
         sp = E._stream_ptr(self.device)
-        t["img"].from_dense(images)
 
         def run(plan, wname, x, y, res=None):
             self._site(ws, W, plan, wname, x, y, res)
 
-        run("fe.firstconv.0", "fe.firstconv.0", "img", "f0")
+        c0 = W["fe.firstconv.0"]
+        if (E.STEM_DIRECT["enabled"] and not self._training and c0.cout_pad in (16, 32) and images.dtype == torch.float32 and images.shape[1] == 3
+                and t["f0"].D == 1):
+            # eval: the first layer reads the dense image (stemconv.hip): no 16-channel-blocked copy of a 3-channel image
+            if c0._stem is None:
+                c0._stem = E.pack_weight_stem(c0.conv.weight.detach().to(device=self.device, dtype=torch.float32))
+            E.stem_conv(images, c0._stem, c0.scale, c0.shift, t["f0"], True)
+        else:
+            t["img"].from_dense(images)
+            run("fe.firstconv.0", "fe.firstconv.0", "img", "f0")
         run("fe.firstconv.2", "fe.firstconv.2", "f0", "f1")
         run("fe.firstconv.4", "fe.firstconv.4", "f1", "f2")
         for plan, wname, x, y, res in ws["sched"]:

@@ -220,6 +220,13 @@ int drc_conv2d_k3_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void
  * (the 2D instantiation of drc_conv3d_k3s2_direct_fwd; stride = in_mul, dilation = tap spacing of the class).  Weights packed
  * [9][cb_in][cout_pad][16] (engine.pack_weight_t16). */
 int drc_conv2d_k3_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+/* The feature CNN's first layer straight from the dense image (stemconv.hip, round 4): x fp32 NCHW [N,3,H,W], Conv2d(3 -> cout, 3x3,
+ * stride 2, pad 1) + folded BN (+ReLU) -> y in the channel-blocked fp32 layout (strides in floats, y_off0 = offset of the interior's first
+ * element).  w_packed = [7 k-steps][cout_pad][4] floats, k = channel * 9 + tap, zero past k = 26 (engine.pack_weight_stem); cout_pad 16 or 32.
+ * Replaces firstconv[0] of disprcnn/modeling/psmnet/submodule.py:65-66 together with the image's layout conversion. */
+int drc_conv2d_k3s2_stem_fwd(const float* x, int N, int H, int W, const float* w_packed, int cout_pad, const float* scale, const float* shift,
+                             float* y, int64_t y_n_stride, int64_t y_cb_stride, int64_t y_h_stride, int64_t y_off0, int OH, int OW, int relu,
+                             void* stream);
 
 /* Conv2d(k1, stride 1 or 2, pad 0) (+BN/bias, +residual, +ReLU) as a register-blocked MFMA GEMM with both operands read
  * straight from global memory (no LDS): the 1x1 convolutions of ResNet-50-FPN (backbone/resnet.py, backbone/fpn.py) and of the

@@ -409,6 +409,39 @@ def test_winograd_weight_transform_vs_oracle(dev):
         assert (got.double() - ref).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("n,cout,hw", [(3, 32, (224, 224)), (2, 32, (30, 52)), (2, 20, (17, 35)), (1, 16, (6, 4)), (2, 32, (375, 1242))])
+def test_stem_conv_from_dense_image_vs_oracle(dev, n, cout, hw):
+    """stemconv.hip: Conv2d(3 -> cout, 3x3, stride 2, pad 1) + folded BN + ReLU read straight from the dense NCHW image, contraction over
+    (channel, tap) = 27 (reference: feature_extraction.firstconv[0], submodule.py:65-66) -- against the oracle convolution; even and odd
+    sizes, ragged 16-pixel tiles, cout 16 / 20 (padded) / 32; the halo of the blocked output stays zero."""
+    from disprcnn_amd import engine as E
+    x = synth.hash_uniform(f"ST{n}{hw}:x", (n, 3) + hw, -1.0, 1.0)
+    w = synth.hash_uniform(f"ST{cout}:w", (cout, 3, 3, 3), -0.5, 0.5)
+    scale = synth.hash_uniform("ST:s", (cout,), 0.5, 1.5)
+    shift = synth.hash_uniform("ST:b", (cout,), -0.5, 0.5)
+    ref = F.relu(F.conv2d(x, w, None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    oh, ow = ref.shape[2:]
+    cp = E.cout_pad_of(cout)
+    sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)
+    sc[:cout] = scale.to(dev); sh[:cout] = shift.to(dev)
+    yb = E.Blocked(n, cout, 1, oh, ow, 0, 1, 1, dev)
+    wp = E.pack_weight_stem(w.to(dev))
+    assert tuple(wp.shape) == (7, cp, 4) and wp[6, :, 3].abs().sum().item() == 0          # k = 27 is padding
+    E.stem_conv(x.to(dev), wp, sc, sh, yb, True)
+    got = yb.to_dense().cpu()[:, :, 0]
+    assert got.shape == ref.shape
+    _close(got, ref)
+    v = yb.view6()
+    assert v[:, :, :, 0].abs().sum() == 0 and v[:, :, :, -1].abs().sum() == 0 and v[:, :, :, :, 0].abs().sum() == 0 and v[:, :, :, :, -1].abs().sum() == 0
+    # the generic path (layout conversion + stride-2 direct kernel) agrees to summation order
+    xb = E.Blocked(n, 3, 1, hw[0], hw[1], 0, 1, 1, dev).from_dense(x.to(dev).unsqueeze(2))
+    y2 = E.Blocked(n, cout, 1, oh, ow, 0, 1, 1, dev)
+    if hw[0] % 2 == 0 and hw[1] % 2 == 0:
+        plan = E.plan_conv2d(xb, y2, 3, 2, 1, 1, cout, True)
+        plan.run(xb, E.pack_weight(w.to(dev)), sc, sh, y2, None, w16=plan.pack16(w.to(dev), False))
+        assert (y2.to_dense().cpu()[:, :, 0] - got).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+
+
 @pytest.mark.parametrize("cin,cout,dims", [(64, 64, (3, 7, 7)), (64, 32, (6, 14, 14)), (16, 48, (2, 5, 9)), (24, 16, (3, 9, 30)), (64, 64, (1, 4, 4))])
 def test_deconv_lds_staged_variant_vs_oracle(dev, cin, cout, dims):
     """tapdeconv.hip (LDS-staged fused transposed conv, the round-1 default) stays selectable with engine.DECONV_DIRECT off; the
