@@ -331,6 +331,7 @@ def pack_weight_deconv_direct(w, transposed=True, flip=False):
     return t16.index_select(0, order).permute(1, 0, 2, 3).contiguous()
 
 
+SPP_NESTED = {"enabled": True}       # eval: the coarser SPP pools are pooled from the finest pool's cells (one pass over the 128-channel map instead of four)
 STEM_DIRECT = {"enabled": True}      # eval: firstconv[0] straight from the dense image (stemconv.hip, round 4) instead of layout conversion + downdirect
 
 

@@ -647,10 +647,24 @@ class PSMNetRuntime:
         skip = t[ws["skip"]]
         H4, W4 = ws["dims"]
         cat = t["cat"]
-        for name, k, oh, ow, cb_off in ws["spp"]:
-            pool, conv = t[name + ".pool"], t[name + ".conv"]
-            st = self._avgpool_slice(lib, skip, pool, k, oh, ow, sp)
+        # SPP pools.  Eval: every window of the reference's pools (56, 32, 16, 8 on the 56-wide map, floor mode) is a union of the finest
+        # pool's 8x8 cells, and a mean of equally sized cells' means is the window's mean -- so only the finest pool reads the 128-channel
+        # map (205 MB for the stress shape's 128 crops), the others read its 7x7 result (round 4: four passes over the map were 4 x 53 us).
+        # Training keeps one pass per branch (the reverse pass spreads each branch's gradient over its own windows).
+        fine = min(ws["spp"], key=lambda e: e[1])
+        nested = (not self._training and E.SPP_NESTED["enabled"] and
+                  all(e[1] % fine[1] == 0 and e[2] * (e[1] // fine[1]) <= fine[2] and e[3] * (e[1] // fine[1]) <= fine[3] for e in ws["spp"]))
+        for name, k, oh, ow, cb_off in ([fine] + [e for e in ws["spp"] if e is not fine] if nested else ws["spp"]):
+            pool = t[name + ".pool"]
+            if nested and name != fine[0]:
+                src = t[fine[0] + ".pool"]
+                st = lib.drc_avgpool2d_blocked_slice(E._ptr(src.storage), E._ptr(pool.storage), src.N, src.cb, src.H, src.W, src.ph, k // fine[1], oh, ow, 0,
+                                                     src.cb, 0, sp)
+            else:
+                st = self._avgpool_slice(lib, skip, pool, k, oh, ow, sp)
             _lib.check(st, "drc_avgpool2d_blocked")
+        for name, k, oh, ow, cb_off in ws["spp"]:
+            conv = t[name + ".conv"]
             run("fe." + name, "fe." + name, name + ".pool", name + ".conv")
             st = lib.drc_bilinear_up_blocked(E._ptr(conv.storage), E._ptr(cat.storage), cat.N, 2, oh, ow, 0, H4, W4, cat.ph,
                                              cat.cb, cb_off, sp)
