@@ -346,18 +346,19 @@ def pack_weight_stem(w):
     return wp.view(cp, 7, 4).permute(1, 0, 2).contiguous()
 
 
-def stem_conv(images, w_packed, scale, shift, y, relu=True):
-    """images fp32 NCHW [N,3,H,W] (dense) -> y: Blocked [N,cout,1,(H+1)//2,(W+1)//2]: Conv2d k3 s2 p1 + folded BN (+ReLU), reference
-    submodule.py:65-66.  No layout conversion of the image."""
+def stem_conv(images, w_packed, scale, shift, y, relu=True, unit0=0):
+    """images fp32 NCHW [n,3,H,W] (dense) -> units unit0 .. unit0+n of y: Blocked [N,cout,1,(H+1)//2,(W+1)//2]: Conv2d k3 s2 p1 + folded BN
+    (+ReLU), reference submodule.py:65-66.  No layout conversion of the image (and, with unit0, no concatenation of the two views)."""
     require_gpu(images, "stem_conv")
     if images.dim() != 4 or images.shape[1] != 3 or images.dtype != torch.float32:
         raise ValueError("stem_conv expects a float32 [N,3,H,W] image batch")
-    N, _, H, W = images.shape
-    if (y.N, y.D, y.H, y.W) != (N, 1, (H + 1) // 2, (W + 1) // 2):
+    n, _, H, W = images.shape
+    if (y.D, y.H, y.W) != (1, (H + 1) // 2, (W + 1) // 2) or unit0 < 0 or unit0 + n > y.N:
         raise ValueError("stem_conv: output geometry does not match a 3x3 stride-2 pad-1 convolution of the input")
     x = images.contiguous()
-    st = _lib.lib().drc_conv2d_k3s2_stem_fwd(_ptr(x), N, H, W, _ptr(w_packed), w_packed.shape[1], _ptr(scale), _ptr(shift), _ptr(y.storage),
-                                             y.n_stride, y.cb_stride, y.h_stride, y.interior_off, y.H, y.W, int(relu), _stream_ptr(y.device))
+    st = _lib.lib().drc_conv2d_k3s2_stem_fwd(_ptr(x), n, H, W, _ptr(w_packed), w_packed.shape[1], _ptr(scale), _ptr(shift), _ptr(y.storage),
+                                             y.n_stride, y.cb_stride, y.h_stride, y.interior_off + unit0 * y.n_stride, y.H, y.W, int(relu),
+                                             _stream_ptr(y.device))
     _lib.check(st, "drc_conv2d_k3s2_stem_fwd")
 
 

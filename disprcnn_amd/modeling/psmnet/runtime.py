@@ -631,14 +631,18 @@ class PSMNetRuntime:
             self._site(ws, W, plan, wname, x, y, res)
 
         c0 = W["fe.firstconv.0"]
-        if (E.STEM_DIRECT["enabled"] and not self._training and c0.cout_pad in (16, 32) and images.dtype == torch.float32 and images.shape[1] == 3
-                and t["f0"].D == 1):
-            # eval: the first layer reads the dense image (stemconv.hip): no 16-channel-blocked copy of a 3-channel image
+        views = images if isinstance(images, (tuple, list)) else (images,)      # (left, right): stacked along the batch, left units first
+        if (E.STEM_DIRECT["enabled"] and not self._training and c0.cout_pad in (16, 32) and t["f0"].D == 1 and
+                all(v.dtype == torch.float32 and v.dim() == 4 and v.shape[1] == 3 for v in views)):
+            # eval: the first layer reads the dense image(s) (stemconv.hip): no 16-channel-blocked copy of a 3-channel image, no torch.cat
             if c0._stem is None:
                 c0._stem = E.pack_weight_stem(c0.conv.weight.detach().to(device=self.device, dtype=torch.float32))
-            E.stem_conv(images, c0._stem, c0.scale, c0.shift, t["f0"], True)
+            unit0 = 0
+            for v in views:
+                E.stem_conv(v, c0._stem, c0.scale, c0.shift, t["f0"], True, unit0=unit0)
+                unit0 += v.shape[0]
         else:
-            t["img"].from_dense(images)
+            t["img"].from_dense(images if len(views) == 1 else torch.cat(tuple(views), 0))
             run("fe.firstconv.0", "fe.firstconv.0", "img", "f0")
         run("fe.firstconv.2", "fe.firstconv.2", "f0", "f1")
         run("fe.firstconv.4", "fe.firstconv.4", "f1", "f2")
@@ -802,7 +806,7 @@ class PSMNetRuntime:
                 return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
             ws2 = self._ws2d(2 * N, H, W)
             self._stamp(ws3, ws2)
-            feat = self._features(ws2, Wt, torch.cat((left, right), 0))
+            feat = self._features(ws2, Wt, (left, right))
             fv = feat.storage
             self._costvol16(ws3, mn, mx, fv, fv[N * feat.n_stride:], feat.ph)
             return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
@@ -821,7 +825,7 @@ class PSMNetRuntime:
         else:
             ws2 = self._ws2d(2 * N, H, W)
             self._stamp(ws3, ws2)
-            feat = self._features(ws2, Wt, torch.cat((left, right), 0))
+            feat = self._features(ws2, Wt, (left, right))
             if self._fuse_costvol(ws3, training):
                 cv = (feat, (feat, N), mn // 4)
             else:
