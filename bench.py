@@ -32,6 +32,7 @@ DEFAULT_ROIS = 1024                  # ROI pairs per step and GPU: 64 images x 1
 FLOPS_PER_VOXEL_3D = 644544          # conv FLOPs (2*MAC) of dres0..classif3 per cost-volume voxel
 FLOPS_2D_PER_IMAGE = 22192734208     # feature_extraction conv FLOPs per 224x224 image
 FLOPS_BACKBONE_PAIR = 250.3e9        # R-50-FPN on one 2x3x375x1242 stereo pair
+PEAK_F16_TFLOPS = 2500.0             # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md); the split-f16 kernels spend 3 products per fp32 product
 PEAK_F32_TFLOPS = 157.3              # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -103,11 +104,15 @@ def max_over_ranks(elapsed, world, dev):
     return elapsed
 
 
+DTYPE = ("f32 (full-resolution stride-1 3x3x3 layers: split-f16, 3 f16-MFMA products per fp32 product, f32 accumulate -- fp32-class error, "
+         "tests/test_hip_s16.py; all other layers: f32 MFMA)")
+
+
 def headline(total_rois, elapsed, args, world, N, roofline, cpu, extra):
     return {
         "metric": "ROI cost-volumes/sec (112x112x48)", "value": round(total_rois / elapsed, 1), "unit": "ROI cost-volumes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "Config A: per ROI pair, features [32,28,28]x2 -> concat cost volume [64,12,28,28] (folded into the first "
                                "3D layer's loads, never written) -> 3D stacked-hourglass regressor -> trilinear x4 + softmax + soft-argmin -> disparity [112,112]",
                    "rois_per_step_per_gpu": N, "maxdisp": 48, "mindisp": 0, "parallelism": f"roi-shard x{world} (no collective)",
@@ -220,7 +225,7 @@ def main():
         # HBM bytes per launch of the same kernel from the committed PMC pass of this command (profiles/collect.sh):
         # FETCH_SIZE (x2: gfx950 128-B request correction) + WRITE_SIZE; null if that profile is absent
         traffic, traffic_src = None, "no committed PMC pass"
-        for prof in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for prof in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 key = [k for k in tj if k.replace(" ", "") == dom.replace(" ", "")]
@@ -236,15 +241,24 @@ def main():
         # that is what is compared with the MFMA peak (frac <= 1).  The direct-convolution-equivalent rate (the layer's
         # algorithmic flops / time, which may exceed the peak) is reported separately and never as `frac`.
         exec_ratio = 64.0 / 216.0 if dom.startswith("wino3d") else 1.0
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved * exec_ratio, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved * exec_ratio / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+        s16_dom = dom.startswith("convs16")
+        # split-f16 kernel (convs16.hip): every fp32 product is three f16 MFMA products, so the roofline it is priced against is the f16
+        # MFMA peak / 3 in fp32-equivalent flops (frac = executed f16 flops / 2.5 PF, the same number)
+        peak = PEAK_F16_TFLOPS / 3.0 if s16_dom else PEAK_F32_TFLOPS
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved * exec_ratio, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(achieved * exec_ratio / peak, 4), "traffic": traffic,
                     "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC, separate pass; {traffic_src})",
                     "calls_per_step": calls // args.steps, "avg_launch_us": round(secs / calls * 1e6, 2),
                     "executed_flops_per_launch": flops / calls * exec_ratio,
                     "direct_conv_equivalent_tflops": round(achieved, 2),
                     "direct_conv_equivalent_flops_per_launch": flops / calls,
-                    "note": ("achieved/frac = executed MFMA flops (Winograd: 64/216 of the direct convolution's) vs the fp32 MFMA peak; "
-                             "direct_conv_equivalent_* = SURVEY 8d's algorithmic conv flops / time, not a roofline fraction")}
+                    "note": (("achieved = the layer's algorithmic fp32 flops (SURVEY 8d: 2*27*Cin*Cout per voxel) / launch time; the kernel spends three "
+                              "v_mfma_f32_32x32x16_f16 products per fp32 product (hi*hi + lo*hi + hi*lo, fp32 accumulate), so peak = 2500 TFLOP/s dense f16 "
+                              "MFMA / 3; 12.5 % of the issued MFMA columns (lanes 28..31 of a 28-voxel row) are idle on top") if s16_dom else
+                             ("achieved/frac = executed MFMA flops (Winograd: 64/216 of the direct convolution's) vs the fp32 MFMA peak; "
+                              "direct_conv_equivalent_* = SURVEY 8d's algorithmic conv flops / time, not a roofline fraction"))}
+        if s16_dom:
+            roofline["executed_f16_mfma_tflops"] = round(3 * achieved, 1)
         extra["kernels"] = {k: {"calls_per_step": v[0] // args.steps, "avg_us": round(v[1] / v[0] * 1e6, 2),
                                 "tflops": round(v[2] / v[1] / 1e12, 2)} for k, v in agg.items()}
         step_flops = FLOPS_PER_VOXEL_3D * 12 * 28 * 28 * N
@@ -258,7 +272,7 @@ def main():
                     continue
                 with torch.no_grad():
                     tb_ = _time(lambda: model.forward_from_features(fl[:nb], fr[:nb], (112, 112)), 2, 5)
-                plans = model._rt._ws[("3d", nb, 12, 28, 28)]["p"]          # the launch heuristics depend on the batch: name what ran
+                plans = (model._rt._ws.get(("3ds16", nb, 12, 28, 28)) or model._rt._ws[("3d", nb, 12, 28, 28)])["p"]   # the launch heuristics depend on the batch: name what ran
                 bs[str(nb)] = {"roi_pairs_per_s": round(nb / tb_, 1), "ms_per_step": round(tb_ * 1e3, 3),
                                "kernels": {k: plans[k].kname for k in ("dres1.0", "hg1.conv1", "hg1.conv2", "hg1.conv4", "hg1.conv5")}}
             extra["batch_sensitivity_rois_per_step"] = bs

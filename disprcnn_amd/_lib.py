@@ -45,6 +45,13 @@ class DrcCostvolSrc(C.Structure):
                 ("cbi", C.c_int32), ("pad", C.c_int32), ("lo4", C.c_int32), ("Wp", C.c_int32)]
 
 
+class DrcS16ConvParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("res", C.c_void_p),
+                ("y16", C.c_void_p), ("y32", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
+                ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("lo4", C.c_int32)]
+
+
 class DrcFpnPyramid(C.Structure):
     _fields_ = [("feat", C.c_void_p * 8), ("H", C.c_int32 * 8), ("W", C.c_int32 * 8), ("scale", C.c_float * 8), ("n_levels", C.c_int32)]
 
@@ -137,6 +144,12 @@ _SIGS = {
     "drc_deconv16_k3s2_tile_supported": (_I, [C.POINTER(DrcTapconvParams)]),
     "drc_deconv16_k3s2_tile_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_cost_volume16_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_conv3d_k3_s16_supported": (_I, [_I, _I, _I, _I, _I]),
+    "drc_conv3d_k3_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
+    "drc_rs16_from_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_rs16_from_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_rs16_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_deconv3d_k3s2_direct_s16_fwd": (_I, [C.POINTER(DrcTapconvParams), _P, _P]),
     "drc_nms_sorted_fwd": (_I, [_P, _I, C.c_float, _I, _P, _P, _P]),
     "drc_nms_sorted_batch_fwd": (_I, [_P, _I, _I, C.c_float, _I, _P, _P, _P]),
     "drc_nms_sorted_pair_joint_fwd": (_I, [_P, _I, C.c_float, _I, _I, _P, _P, _P]),

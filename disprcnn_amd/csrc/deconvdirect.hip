@@ -23,6 +23,7 @@
 #include "../../include/disprcnn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define DD_WAVES 4
 #ifndef DD_AHEAD
@@ -58,8 +59,10 @@ constexpr ComboTable kTab = make_table();
 
 // (Measured and rejected: one cout tile per wave, 292 registers: 83-91 TFLOP/s against 91-102 for two; the same forced to two
 // waves per SIMD with amdgpu_waves_per_eu(2,2), 29 spills: 79-84.  Occupancy is not what this kernel lacks.)
-template <int VT, int CT>
-__global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_tapconv_params p) {
+// S16 (round 5): the result (also) goes out as an RS16 tensor (convs16.hip's input layout): lane (voxel j, g) of cout tile t holds couts
+// 16t + 4g .. +3 = half a chunk: chunk (s = t & 1, g' = g & 1) of the 32-channel block t >> 1, bytes (g >> 1)*8 .. -- 8 B hi + 8 B lo.
+template <int VT, int CT, bool S16 = false>
+__global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_tapconv_params p, char* y16) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -85,8 +88,11 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
 
         // per-lane byte offsets of input voxel slot (vt, j) at shift (0,0,0) (padded coordinates = logical + 1) and of its even-corner
         // output / residual voxel
-        unsigned lane_vo[VT], yv[VT], rv[VT];
+        unsigned lane_vo[VT], yv[VT], rv[VT], y16v[S16 ? VT : 1];
         bool valid[VT];
+        // RS16 output geometry (bytes): halfs [N][cout/32][2OD+2][2OH+2][8][2OW+2][8]
+        const long s_chunkB = (long)(2 * p.OW + 2) * 16, s_rowB = 8 * s_chunkB, s_planeB = (long)(2 * p.OH + 2) * s_rowB,
+                   s_cbB = (long)(2 * p.OD + 2) * s_planeB, s_nB = (long)(p.cout_pad / 32) * s_cbB;
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) {
             long q = tile * (VT * 16) + vt * 16 + j;
@@ -99,6 +105,8 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
             lane_vo[vt] = (unsigned)((n * p.x_n_stride + (int64_t)(id + 1) * p.x_d_stride + (int64_t)(r + 1) * p.x_h_stride + (c + 1) * 16 + g * 4) * 4);
             yv[vt] = (unsigned)((n * p.y_n_stride + (int64_t)(2 * id) * p.y_d_stride + (int64_t)(2 * r) * p.y_h_stride + 2 * c * 16 + g * 4) * 4);
             rv[vt] = (unsigned)((n * p.r_n_stride + (int64_t)(2 * id) * p.r_d_stride + (int64_t)(2 * r) * p.r_h_stride + 2 * c * 16 + g * 4) * 4);
+            if constexpr (S16)
+                y16v[vt] = (unsigned)(n * s_nB + (long)(2 * id + 1) * s_planeB + (long)(2 * r + 1) * s_rowB + (long)(g & 1) * s_chunkB + (2 * c + 1) * 16 + (g >> 1) * 8);
         }
         const char* xs = (const char*)p.x;
         const unsigned wlane = (unsigned)(((ct0 * 16 + j) * 16 + g * 4) * 4);      // this lane's byte offset inside a combination's weights
@@ -188,7 +196,21 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
                             f32x4 v_ = acc[q.cls][vt][ct] * bn_sc[ct] + bn_sh[ct];
                             if (p.res) v_ += resq[vt][ct];
                             if (p.relu) { v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); }
-                            *(f32x4*)(y_base(q.cls, ct) + yv[vt]) = v_;
+                            if (!S16 || p.y) *(f32x4*)(y_base(q.cls, ct) + yv[vt]) = v_;
+                            if constexpr (S16) {
+                                f16x4 hi, lo;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float x_ = fminf(fmaxf(v_[e], -65504.f), 65504.f);
+                                    hi[e] = (_Float16)x_;
+                                    lo[e] = (_Float16)(x_ - (float)hi[e]);
+                                }
+                                const int tile = ct0 + ct;
+                                char* b16 = y16 + (long)(tile >> 1) * s_cbB + (long)((tile & 1) * 2) * s_chunkB + (long)(q.cls >> 2) * s_planeB +
+                                            (long)((q.cls >> 1) & 1) * s_rowB + (q.cls & 1) * 16;
+                                *(f16x4*)(b16 + y16v[vt]) = hi;
+                                *(f16x4*)(b16 + 4 * s_chunkB + y16v[vt]) = lo;
+                            }
                         }
                     }
                 }
@@ -210,15 +232,15 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
     }
 }
 
-template <int VT, int CT>
-int launch(const drc_tapconv_params& p, hipStream_t stream) {
+template <int VT, int CT, bool S16 = false>
+int launch(const drc_tapconv_params& p, hipStream_t stream, char* y16 = nullptr) {
     const long voxels = (long)p.N * p.OD * p.OH * p.OW;
     const long items = ((voxels + VT * 16 - 1) / (VT * 16)) * (p.cout_pad / 16 / CT);
     long workers = 256L * DD_WAVES;                      // one wave per SIMD (the two B sets + 8 accumulator classes fill the file)
     if (workers > items) workers = items;
     if (workers < 1) workers = 1;
     dim3 grid((unsigned)((workers + DD_WAVES - 1) / DD_WAVES), 1, 1);
-    hipLaunchKernelGGL((deconvdirect_kernel<VT, CT>), grid, dim3(64 * DD_WAVES), 0, stream, p);
+    hipLaunchKernelGGL((deconvdirect_kernel<VT, CT, S16>), grid, dim3(64 * DD_WAVES), 0, stream, p, y16);
     return (int)hipGetLastError();
 }
 
@@ -240,4 +262,19 @@ extern "C" int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* pp, int co
     if (CT == 2 && ct % 2 == 0) return launch<2, 2>(p, s);
     if (CT == 1) return launch<2, 1>(p, s);
     return -2;
+}
+
+extern "C" int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* pp, void* y16, void* stream) {
+    if (!pp || !y16) return -1;
+    const drc_tapconv_params& p = *pp;
+    if (!p.x || !p.w || !p.scale || !p.shift) return -1;
+    if (p.N < 0 || p.OD <= 0 || p.OH <= 0 || p.OW <= 0) return -2;
+    if (p.N == 0) return 0;
+    if (p.cout_pad <= 0 || (p.cout_pad & 31) || p.cb_in <= 0) return -2;
+    if (p.n_classes != 8 || p.in_mul != 1 || p.out_mul != 2) return -4;
+    const int64_t unit16 = (int64_t)(p.cout_pad / 32) * (2 * p.OD + 2) * (2 * p.OH + 2) * (2 * p.OW + 2) * 128;
+    if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32) || (p.y && (int64_t)p.N * p.y_n_stride * 4 >= (1LL << 32)) ||
+        (p.res && (int64_t)p.N * p.r_n_stride * 4 >= (1LL << 32)) || (int64_t)p.N * unit16 >= (1LL << 32))
+        return -5;
+    return launch<2, 2, true>(p, (hipStream_t)stream, (char*)y16);
 }

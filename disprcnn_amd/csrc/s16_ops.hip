@@ -1,0 +1,138 @@
+// s16_ops.hip -- layout converters of the split-f16 path (RS16 tensors, see convs16.hip / include/disprcnn_hip.h), gfx950.
+//
+//   RS16: halfs [N][C/32][D+2pd][H+2][8 chunks][W+2][8]; chunk q = p*4 + s*2 + g (p: 0 hi / 1 lo), element e of chunk (s, g) =
+//   channel 4g + 8(2s + (e>>2)) + (e&3) of the 32-channel block; hi = fp16(v), lo = fp16(v - hi).
+// Pure data movement (HBM-bound): one thread per (voxel, chunk pair): 8 channels in, 16 B hi + 16 B lo out.
+// Replaces nothing in the reference (its tensors are NCHW fp32); these sit where the reference hands features to
+// PSMNet.forward's concat loop, stackhourglass.py:112-128.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ inline void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+        hi[e] = (_Float16)x;
+        lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+}
+
+// dense [N,C,D,H,W] fp32 -> RS16 (interior only; the halo stays as allocated: zero)
+__global__ void rs16_from_dense_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int N, int C, int D, int H, int W, int pd) {
+    const long total = (long)N * (C / 32) * D * H * 4 * W;
+    const int Wp = W + 2, Hp = H + 2, Dp = D + 2 * pd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int xw = (int)(t % W); t /= W;
+        const int sg = (int)(t % 4); t /= 4;
+        const int yh = (int)(t % H); t /= H;
+        const int z = (int)(t % D); t /= D;
+        const int cb = (int)(t % (C / 32));
+        const int n = (int)(t / (C / 32));
+        const int s = sg >> 1, g = sg & 1;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cb * 32 + 4 * g + 8 * (2 * s + (e >> 2)) + (e & 3);
+            v[e] = x[((((long)n * C + c) * D + z) * H + yh) * W + xw];
+        }
+        f16x8 hi, lo;
+        split8(v, hi, lo);
+        _Float16* row = y + (((((long)n * (C / 32) + cb) * Dp + z + pd) * Hp + yh + 1) * 8) * (long)Wp * 8;
+        *(f16x8*)(row + ((long)sg * Wp + xw + 1) * 8) = hi;
+        *(f16x8*)(row + ((long)(4 + sg) * Wp + xw + 1) * 8) = lo;
+    }
+}
+
+// blocked fp32 [units][CB16 total][D+2pdi][H+2phi][W+2pwi][16] (channel blocks cb16_off .. of it) -> RS16
+__global__ void rs16_from_blocked_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int N, int C, int D, int H, int W, int pdi, int phi,
+                                         int pwi, int cb16_total, int cb16_off, int pd) {
+    const long total = (long)N * (C / 32) * D * H * 4 * W;
+    const int Wp = W + 2, Hp = H + 2, Dp = D + 2 * pd;
+    const long xw_ = W + 2 * pwi, xh_ = H + 2 * phi, xd_ = D + 2 * pdi;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int sg = (int)(t % 4); t /= 4;                 // consecutive threads: the 4 chunk pairs of one voxel (64 contiguous bytes x 2 blocks)
+        const int xw = (int)(t % W); t /= W;
+        const int yh = (int)(t % H); t /= H;
+        const int z = (int)(t % D); t /= D;
+        const int cb = (int)(t % (C / 32));
+        const int n = (int)(t / (C / 32));
+        const int s = sg >> 1, g = sg & 1;
+        // channels 4g + 16s + 8j + i: 16-channel block 2cb + s, floats 4g + 8j .. +3
+        const float* src = x + (((((long)n * cb16_total + cb16_off + 2 * cb + s) * xd_ + z + pdi) * xh_ + yh + phi) * xw_ + xw + pwi) * 16 + 4 * g;
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 8);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        f16x8 hi, lo;
+        split8(v, hi, lo);
+        _Float16* row = y + (((((long)n * (C / 32) + cb) * Dp + z + pd) * Hp + yh + 1) * 8) * (long)Wp * 8;
+        *(f16x8*)(row + ((long)sg * Wp + xw + 1) * 8) = hi;
+        *(f16x8*)(row + ((long)(4 + sg) * Wp + xw + 1) * 8) = lo;
+    }
+}
+
+// RS16 -> dense fp32 [N,C,D,H,W]
+__global__ void rs16_to_dense_kernel(const _Float16* __restrict__ y, float* __restrict__ x, int N, int C, int D, int H, int W, int pd) {
+    const long total = (long)N * (C / 32) * D * H * 4 * W;
+    const int Wp = W + 2, Hp = H + 2, Dp = D + 2 * pd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int xw = (int)(t % W); t /= W;
+        const int sg = (int)(t % 4); t /= 4;
+        const int yh = (int)(t % H); t /= H;
+        const int z = (int)(t % D); t /= D;
+        const int cb = (int)(t % (C / 32));
+        const int n = (int)(t / (C / 32));
+        const int s = sg >> 1, g = sg & 1;
+        const _Float16* row = y + (((((long)n * (C / 32) + cb) * Dp + z + pd) * Hp + yh + 1) * 8) * (long)Wp * 8;
+        const f16x8 hi = *(const f16x8*)(row + ((long)sg * Wp + xw + 1) * 8);
+        const f16x8 lo = *(const f16x8*)(row + ((long)(4 + sg) * Wp + xw + 1) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cb * 32 + 4 * g + 8 * (2 * s + (e >> 2)) + (e & 3);
+            x[((((long)n * C + c) * D + z) * H + yh) * W + xw] = (float)hi[e] + (float)lo[e];
+        }
+    }
+}
+
+inline unsigned grid_for(long total) {
+    long b = (total + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 256 * 32 ? 256 * 32 : b));
+}
+
+}  // namespace
+
+extern "C" int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, int W, int pd, void* stream) {
+    if (!x || !y16) return -1;
+    if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1) return -2;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(rs16_from_dense_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y16, N, C, D, H, W, pd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int drc_rs16_from_blocked(const float* xb, void* y16, int N, int C, int D, int H, int W, int pd_in, int ph_in, int pw_in, int cb16_total,
+                                     int cb16_off, int pd, void* stream) {
+    if (!xb || !y16) return -1;
+    if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1 || pd_in < 0 || ph_in < 0 || pw_in < 0 || cb16_off < 0 ||
+        cb16_off + C / 16 > cb16_total)
+        return -2;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(rs16_from_blocked_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, xb, (_Float16*)y16, N, C, D,
+                       H, W, pd_in, ph_in, pw_in, cb16_total, cb16_off, pd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int drc_rs16_to_dense(const void* y16, float* x, int N, int C, int D, int H, int W, int pd, void* stream) {
+    if (!x || !y16) return -1;
+    if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1) return -2;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(rs16_to_dense_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)y16, x, N, C, D, H, W, pd);
+    return (int)hipGetLastError();
+}

@@ -147,6 +147,17 @@ class WorkspacePool:
             raise ValueError(f"WorkspacePool: tensor {name!r} requested with another geometry")
         return Blocked16(N, C_, D, H, W, pd, ph, pw, self.device, storage=full.storage)
 
+    def rs16(self, name, N, C_, D, H, W, pd=1):
+        """split-f16 tensor (RS16) of the pool."""
+        if N > self.cap:
+            raise ValueError("WorkspacePool: more units than the pool was sized for")
+        full = self.full.get(name)
+        if full is None:
+            full = self.full[name] = RS16(self.cap, C_, D, H, W, pd, self.device)
+        elif not isinstance(full, RS16) or (full.C, full.D, full.H, full.W, full.pd) != (C_, D, H, W, pd):
+            raise ValueError(f"WorkspacePool: tensor {name!r} requested with another geometry")
+        return RS16(N, C_, D, H, W, pd, self.device, storage=full.storage)
+
     def dense(self, name, N, *shape):
         full = self.flat.get(name)
         if full is None:
@@ -562,8 +573,12 @@ class ConvPlan:
             return pack_layouts(w, transposed, flip, want_tap=False)[1]
         return None
 
-    def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None):
+    def run(self, x, w, scale, shift, y, res=None, relu=None, w16=None, y16=None):
+        """y16 (an RS16 tensor; transposed-conv plans on the LDS-free kernel only): the result is (also) written in the split-f16
+        layout for a drc_conv3d_k3_s16_fwd consumer; y may then be None."""
         p = self.p
+        if y16 is not None and not self.deconv_direct:
+            raise ValueError("y16: only the LDS-free transposed convolution writes RS16")
         if self.needs_t16:
             points = (16 if self.c2d else 64) if self.wino else (9 if self.c2d else 27)
             if w16 is None or w16.shape[1 if self.deconv_direct else 0] != points:
@@ -572,12 +587,13 @@ class ConvPlan:
         relu_saved = p.relu
         if relu is not None:
             p.relu = int(relu)
-        p.x, p.y = _base_ptr(x), _base_ptr(y)
+        p.x, p.y = _base_ptr(x), (_base_ptr(y) if y is not None else None)
         # strides come from the tensors actually passed (same logical shape as at plan time; e.g. a train-mode raw buffer
         # instead of a concat slice)
         p.x_n_stride, p.x_cb_stride, p.x_d_stride, p.x_h_stride = x.n_stride, x.cb_stride, x.d_stride, x.h_stride
-        p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
-        p.y_off0 = y.interior_off
+        if y is not None:
+            p.y_n_stride, p.y_cb_stride, p.y_d_stride, p.y_h_stride = y.n_stride, y.cb_stride, y.d_stride, y.h_stride
+            p.y_off0 = y.interior_off
         p.w, p.scale, p.shift = w.data_ptr(), scale.data_ptr(), shift.data_ptr()
         if res is not None:
             p.res = _base_ptr(res)
@@ -620,6 +636,9 @@ class ConvPlan:
         elif self.down:
             st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_fwd")
+        elif self.deconv_direct and y16 is not None:
+            st = _lib.lib().drc_deconv3d_k3s2_direct_s16_fwd(C.byref(p), _ptr(y16.storage), _stream_ptr(self.device))
+            _lib.check(st, "drc_deconv3d_k3s2_direct_s16_fwd")
         elif self.deconv_direct:
             st = _lib.lib().drc_deconv3d_k3s2_direct_fwd(C.byref(p), self.deconv_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_deconv3d_k3s2_direct_fwd")
@@ -1308,3 +1327,101 @@ def cost_volume16_blocked(left, right, out, lo4, hi4, in_blocked_pad=-1):
     st = _lib.lib().drc_cost_volume16_blocked_fwd(_ptr(left), _ptr(right), _ptr(out.storage), out.N, out.C // 2, out.D, out.H, out.W,
                                                   lo4, hi4, in_blocked_pad, _stream_ptr(out.device))
     _lib.check(st, "drc_cost_volume16_blocked_fwd")
+
+
+# ------------------------------------------------------------------------------------------- split-f16 ("f16x2") path, round 5
+S16 = {"enabled": True}       # eval: the stride-1 3x3x3 layers at full resolution on the f16 matrix cores in split arithmetic (convs16.hip)
+
+
+class RS16:
+    """Split-f16 tensor halfs [N][C/32][D+2pd][H+2][8 chunks][W+2][8], zero halo (include/disprcnn_hip.h, drc_s16conv_params)."""
+
+    def __init__(self, N, C_, D, H, W, pd, device, storage=None):
+        if C_ % 32:
+            raise ValueError("RS16: channels must be a multiple of 32")
+        self.N, self.C, self.D, self.H, self.W, self.pd = N, C_, D, H, W, pd
+        self.cb = C_ // 32
+        self.unit = self.cb * (D + 2 * pd) * (H + 2) * 8 * (W + 2) * 8          # halfs per unit
+        self.numel = N * self.unit
+        if storage is None:
+            self.storage = torch.zeros(self.numel + 4096, dtype=torch.float16, device=device)
+        else:
+            if storage.numel() < self.numel + 4096:
+                raise ValueError("RS16: the given storage is too small for this geometry")
+            self.storage = storage.narrow(0, 0, self.numel + 4096)
+        self.device = device
+
+    def view7(self):
+        return self.storage[: self.numel].view(self.N, self.cb, self.D + 2 * self.pd, self.H + 2, 8, self.W + 2, 8)
+
+    def from_dense(self, dense):
+        """dense [N,C,D,H,W] or [N,C,H,W] fp32 -> interior (HIP kernel)."""
+        require_gpu(dense, "RS16.from_dense")
+        dense = dense.contiguous()
+        if self.N:
+            st = _lib.lib().drc_rs16_from_dense(_ptr(dense), _ptr(self.storage), self.N, self.C, self.D, self.H, self.W, self.pd, _stream_ptr(self.device))
+            _lib.check(st, "drc_rs16_from_dense")
+        return self
+
+    def from_blocked(self, blk, first_unit=0):
+        """units [first_unit, first_unit + N) of a blocked fp32 tensor (or channel slice) of the same logical shape -> interior."""
+        base = getattr(blk, "base", blk)
+        if (blk.C, blk.D, blk.H, blk.W) != (self.C, self.D, self.H, self.W) or base.N < first_unit + self.N:
+            raise ValueError("RS16.from_blocked: shapes differ")
+        if self.N:
+            src = C.c_void_p(base.storage.data_ptr() + 4 * first_unit * base.n_stride)
+            st = _lib.lib().drc_rs16_from_blocked(src, _ptr(self.storage), self.N, self.C, self.D, self.H, self.W, base.pd, base.ph, base.pw, base.cb,
+                                                  getattr(blk, "cb_off", 0), self.pd, _stream_ptr(self.device))
+            _lib.check(st, "drc_rs16_from_blocked")
+        return self
+
+    def to_dense(self):
+        shape = (self.N, self.C, self.D, self.H, self.W)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if self.N:
+            st = _lib.lib().drc_rs16_to_dense(_ptr(self.storage), _ptr(out), self.N, self.C, self.D, self.H, self.W, self.pd, _stream_ptr(self.device))
+            _lib.check(st, "drc_rs16_to_dense")
+        return out
+
+
+def s16_supported(cin, cout, D, H, W):
+    return bool(S16["enabled"] and _lib.lib().drc_conv3d_k3_s16_supported(cin, cout, D, H, W))
+
+
+class ConvPlanS16:
+    """One launch of drc_conv3d_k3_s16_fwd: stride-1 3x3x3 conv (+BN, +residual, +ReLU) on RS16 tensors; cv: the cost volume of the
+    left / right 2D feature maps is the (virtual) input (reference stackhourglass.py:115-130)."""
+
+    def __init__(self, N, cin, cout, D, H, W, relu, cv=False, device=None):
+        if not _lib.lib().drc_conv3d_k3_s16_supported(cin, cout, D, H, W) or (cv and cin != 64):
+            raise ValueError("ConvPlanS16: unsupported shape")
+        self.N, self.cin, self.cout, self.D, self.H, self.W, self.relu, self.cv, self.device = N, cin, cout, D, H, W, bool(relu), cv, device
+        self.flops = 2 * N * D * H * W * 27 * cin * cout
+        self.kname = "convs16_kernel<%d,%s>" % (cin // 16, "true" if cv else "false")
+
+    def run(self, x16, w16, scale, shift, y16=None, y32=None, res=None, left=None, right=None, lo4=0):
+        from ._lib import DrcS16ConvParams
+        for t_ in (x16, y16, res):
+            if t_ is not None and (t_.N < self.N or (t_.D, t_.H, t_.W, t_.pd) != (self.D, self.H, self.W, 1)):
+                raise ValueError("ConvPlanS16.run: tensor geometry differs from the plan")
+        if y32 is not None and ((y32.C, y32.D, y32.H, y32.W, y32.pd, y32.ph, y32.pw) != (self.cout, self.D, self.H, self.W, 1, 1, 1) or getattr(y32, "cb_off", 0)):
+            raise ValueError("ConvPlanS16.run: the blocked fp32 output must be a whole tensor with halo 1")
+        if self.cv:
+            for f in (left, right):
+                if f is None or (f.C, f.D, f.H, f.W, f.pd) != (32, 1, self.H, self.W, 0) or f.N < self.N:
+                    raise ValueError("ConvPlanS16.run: the cost-volume variant reads two RS16 2D maps [N,32,H,W]")
+        elif x16 is None or x16.C != self.cin:
+            raise ValueError("ConvPlanS16.run: input missing")
+        p = DrcS16ConvParams(_ptr(x16.storage) if x16 is not None else None, _ptr(w16), _ptr(scale), _ptr(shift),
+                             _ptr(res.storage) if res is not None else None, _ptr(y16.storage) if y16 is not None else None,
+                             _ptr(y32.storage) if y32 is not None else None, _ptr(left.storage) if self.cv else None,
+                             _ptr(right.storage) if self.cv else None, self.N, self.D, self.H, self.W, self.cin, self.cout, int(self.relu), int(lo4))
+        dev = self.device
+        if TIMING is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+        st = _lib.lib().drc_conv3d_k3_s16_fwd(C.byref(p), _stream_ptr(dev))
+        _lib.check(st, "drc_conv3d_k3_s16_fwd")
+        if TIMING is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            TIMING.append((self.kname, self.flops, e0, e1))

@@ -53,6 +53,7 @@ class PSMNet(nn.Module):
         # "f32" (the reference's precision, default) or "f16": cost volume + 3D regressor on fp16-storage tensors with fp32
         # accumulation (inference only; BASELINE configs[3]).  Not a constructor argument: the reference signature is kept.
         self.regressor_storage = "f32"
+        self.regressor_math = "auto"          # "f32": every 3D layer on the fp32 MFMA; "auto"/"f16x2": eval runs the full-resolution stride-1 layers in split-f16 (runtime._use_s16)
         self.feature_storage = "f32"          # "f16" (with regressor_storage "f16"): the 2D feature CNN in fp16 storage as well
 
     # ------------------------------------------------------------------ engine plumbing

@@ -153,6 +153,10 @@ int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_w
  * [cb_in][27][cout_pad][16]: the t16 layout of the ConvTranspose weight [Cin,Cout,3,3,3] re-ordered channel-block-major with the
  * taps in the kernel's use order i = (a*3 + b)*3 + c -> tap ((K[a]*3 + K[b])*3 + K[c]), K = {1, 2, 0} (engine.pack_weight_deconv_direct). */
 int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
+/* The same launch writing its result (also) as an RS16 tensor halfs [N][cout/32][2*OD+2][2*OH+2][8][2*OW+2][8] (round 5: the
+ * consumer is the split-f16 convolution drc_conv3d_k3_s16_fwd); p->y may be NULL (RS16 output only); cout_pad % 32 == 0, two cout
+ * tiles per wave. */
+int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* p, void* y16, void* stream);
 
 /* The stride-1 3x3x3 convolution of drc_tapconv3d_direct_fwd (same parameter block; R, WT and lds_bytes_per_wave ignored) as
  * Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: 64 instead of 216 multiplies per (cin, cout) pair and 2x2x2 output tile.
@@ -343,6 +347,43 @@ int drc_conv16_k3_tile_fwd(const drc_tapconv_params* p, void* stream);
  * drc_cost_volume16_* followed by drc_conv16_k3_tile_fwd.  Replaces the concat loop of disprcnn/modeling/psmnet/stackhourglass.py:115-128
  * plus dres0[0] (:63-66) in the fp16-storage mode. */
 int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* p, int mindisp4, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a2-a6 (round 5).  The stride-1 3x3x3 convbn_3d layers in SPLIT-f16 arithmetic (convs16.hip): fp32 values carried as
+ * hi + lo fp16 pairs, three v_mfma_f32_32x32x16_f16 products per fp32 product, fp32 accumulate -- fp32-class results
+ * (error against fp64 of the size of the fp32 FMA chain's own) on the 2.5 PF f16 matrix cores instead of the 157 TF fp32 MFMA.
+ * Replaces nn.Conv3d + BatchNorm3d (+ add, + ReLU) of disprcnn/modeling/psmnet/submodule.py:19-22 at the call sites
+ * stackhourglass.py:63-70 (dres0, dres1), :78-88 (classif*[0]), :9-20 (hourglass conv2 / conv4); with left/right set also the
+ * concat loop stackhourglass.py:115-128 in front of dres0[0].
+ *
+ * "RS16" tensors: halfs [N][C/32][D+2pd][H+2][8 chunks][W+2][8], zero halo stored (pd = 1 for volumes, 0 for 2D maps);
+ * chunk q = p*4 + s*2 + g (p = 0 hi / 1 lo), element e of chunk (s, g) = channel 4g + 8(2s + (e>>2)) + (e&3) of the 32-channel block.
+ * value = (float)hi + (float)lo, hi = fp16(value) (round to nearest), lo = fp16(value - hi); |value| <= 65504.
+ * Weights: drc_s16_pack_weights layout [cout/32][cin/16][27 taps kd*9+kh*3+kw][hi, lo][64 lanes][8 halfs], pre-scaled by 2^wexp
+ * (the caller folds 2^-wexp into scale).  cin, cout in {32, 64}; D % 3 == 0, W % 28 == 0, H % 2 == 0 (cin 32). */
+typedef struct drc_s16conv_params {
+    const void* x;       /* RS16 input [N][cin/32][D+2][H+2][8][W+2][8]; ignored when left/right are given */
+    const void* w;       /* packed split weights */
+    const float* scale;  /* [cout] folded BN scale * 2^-wexp */
+    const float* shift;  /* [cout] folded BN shift */
+    const void* res;     /* optional RS16 residual, geometry of y16 (may be NULL) */
+    void* y16;           /* RS16 output [N][cout/32][D+2][H+2][8][W+2][8] (may be NULL) */
+    float* y32;          /* blocked fp32 output float[N][cout/16][D+2][H+2][W+2][16] (may be NULL); at least one output */
+    const void* left;    /* cost-volume variant (cin = 64): RS16 2D maps [N][1][H+2][8][W+2][8] */
+    const void* right;
+    int32_t N, D, H, W;
+    int32_t cin, cout, relu;
+    int32_t lo4;         /* cost-volume variant: disparity of volume slice 0 (mindisp/4) */
+} drc_s16conv_params;
+int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int W);
+int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
+/* RS16 converters (s16_ops.hip): interior only, the zero halo is the allocator's.  dense = NCDHW fp32 (D = 1, pd = 0 for 2D maps);
+ * blocked = the engine's fp32 blocked tensor, channel blocks [cb16_off, cb16_off + C/16) of a tensor with cb16_total blocks and halos
+ * (pd_in, ph_in, pw_in).  They stand where the reference hands fp32 NCHW features to the concat loop, stackhourglass.py:112-128. */
+int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, int W, int pd, void* stream);
+int drc_rs16_from_blocked(const float* xb, void* y16, int N, int C, int D, int H, int W, int pd_in, int ph_in, int pw_in, int cb16_total,
+                          int cb16_off, int pd, void* stream);
+int drc_rs16_to_dense(const void* y16, float* x, int N, int C, int D, int H, int W, int pd, void* stream);
 /* Round 4: the same recipe for the stride-2 and the transposed 3x3x3 layers of the fp16-storage regressor (conv16x.hip; hourglass conv1 /
  * conv3 and conv5 / conv6, stackhourglass.py:11-30): drc_conv16_k3s2_tile_* takes the single-class stride-2 grid (in_mul = 2, canonical
  * weight order), drc_deconv16_k3s2_tile_* the eight output-parity classes of ConvTranspose3d(k3, s2, p1, op1) (out_mul = 2, the classes in

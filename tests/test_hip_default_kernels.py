@@ -26,11 +26,29 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _model(dev, case, mx, mn):
+def _model(dev, case, mx, mn, math="f32"):
+    """math = "f32": every 3D layer on the fp32 MFMA kernels (rounds 1-4); "auto": the round-5 default, the full-resolution stride-1
+    layers in split-f16 arithmetic (convs16.hip)."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
     m = PSMNet(mx, mn)
     m.load_state_dict(state_for(case), strict=True)
+    m.regressor_math = math
     return m.to(dev).eval()
+
+
+S16_LAYERS = {"dres0.0": "convs16_kernel<4,true>", "dres0.2": "convs16_kernel<2,false>", "dres1.0": "convs16_kernel<2,false>",
+              "dres1.2": "convs16_kernel<2,false>", "classif1.0": "convs16_kernel<2,false>", "classif2.0": "convs16_kernel<2,false>",
+              "classif3.0": "convs16_kernel<2,false>"}
+
+
+def _assert_bench_kernels_s16(ws):
+    p = ws["p"]
+    for name, kname in S16_LAYERS.items():
+        assert p[name].kname == kname, (name, p[name].kname)
+    for k in (1, 2, 3):
+        assert p[f"hg{k}.conv1"].kname.startswith("downdirect_kernel") and p[f"hg{k}.conv3"].kname.startswith("downdirect_kernel")
+        assert p[f"hg{k}.conv5"].deconv_direct and p[f"hg{k}.conv6"].deconv_direct
+    return {n: pl.kname for n, pl in p.items()}
 
 
 def _assert_bench_kernels(ws):
@@ -44,23 +62,29 @@ def _assert_bench_kernels(ws):
     return {n: pl.kname for n, pl in p.items()}
 
 
+@pytest.mark.parametrize("math", ["f32", "auto"])
 @pytest.mark.parametrize("case,mx,mn", [("A", 48, 0), ("At", 48, 0), ("A2", 24, -24)])
-def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn):
+def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn, math):
     """The bench's batch (bench.DEFAULT_ROIS ROI pairs per step) = the recorded 2-ROI input replicated: the bench's plans (Winograd
     on the ten even stride-1 layers, LDS-free direct / stride-2 kernels, LDS-free fused transposed conv) reproduce the reference's
     recorded disparities and sampled intermediates in EVERY replica."""
     import bench
     z = golden_npz()
-    m = _model(dev, "At" if case == "At" else "A", mx, mn)
+    m = _model(dev, "At" if case == "At" else "A", mx, mn, math)
     fl, fr = synth.synth_features(2, 32, 28, 28, tag="caseA")
     N = bench.DEFAULT_ROIS
     fl, fr = fl.repeat(N // 2, 1, 1, 1).to(dev), fr.repeat(N // 2, 1, 1, 1).to(dev)
     with torch.no_grad():
         pred = m.forward_from_features(fl, fr, (112, 112)).cpu()
     Dp = (mx - mn) // 4
-    ws = m._rt._ws[("3d", N, Dp, 28, 28)]
-    names = _assert_bench_kernels(ws)
-    assert names["hg1.conv1"] == "downdirect_kernel<7,4>" and names["dres1.0"] == "wino3d_rb_kernel<14>" and names["hg1.conv2"] == "wino3d_rb_kernel<7>", names
+    if math == "f32":
+        ws = m._rt._ws[("3d", N, Dp, 28, 28)]
+        names = _assert_bench_kernels(ws)
+        assert names["hg1.conv1"] == "downdirect_kernel<7,4>" and names["dres1.0"] == "wino3d_rb_kernel<14>" and names["hg1.conv2"] == "wino3d_rb_kernel<7>", names
+    else:
+        ws = m._rt._ws[("3ds16", N, Dp, 28, 28)]
+        names = _assert_bench_kernels_s16(ws)
+        assert names["hg1.conv1"] == "downdirect_kernel<7,4>" and names["hg1.conv2"] == "wino3d_rb_kernel<7>", names
     ref = torch.from_numpy(z[f"{case}_pred"])
     err = (pred.view(N // 2, 2, 112, 112) - ref[None]).abs()
     print(case, f"N={N} mean/max err px", err.mean().item(), err.max().item())
@@ -72,24 +96,28 @@ def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn):
     idx = torch.from_numpy(z[f"{case}_cost3_idx"]); val = torch.from_numpy(z[f"{case}_cost3_val"])
     for rep in (0, 63, N // 2 - 1):
         assert (cost3[rep][idx] - val).abs().max().item() < 1e-3 * max(1.0, val.abs().max().item())
-    out3 = ws["t"]["out3"].to_dense().cpu().reshape(N // 2, -1)
+    out3 = ws["t"]["out3" if math == "f32" else "out3s"].to_dense().cpu().reshape(N // 2, -1)
     idx = torch.from_numpy(z[f"{case}_out3_idx"]); val = torch.from_numpy(z[f"{case}_out3_val"])
     for rep in (0, 63, N // 2 - 1):
         assert (out3[rep][idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4
 
 
-def test_config_a_bench_batch_distinct_rois_vs_oracle_subset(dev):
+@pytest.mark.parametrize("math", ["f32", "auto"])
+def test_config_a_bench_batch_distinct_rois_vs_oracle_subset(dev, math):
     """One bench-sized step on DISTINCT synthetic ROI pairs (the bench's own inputs, bench.DEFAULT_ROIS of them); 64 ROIs spread over the
     batch are checked against the CPU oracle (pinned to the reference by tests/test_oracle_golden.py).  The round-1 batch of 256
     is checked the same way: the launch heuristics depend on the batch."""
     import bench
     sd = state_for("A")
-    m = _model(dev, "A", 48, 0)
+    m = _model(dev, "A", 48, 0, math)
     for N in (bench.DEFAULT_ROIS, 256):
         fl, fr = synth.synth_features(N, 32, 28, 28, tag="bench0")
         with torch.no_grad():
             pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
-        _assert_bench_kernels(m._rt._ws[("3d", N, 12, 28, 28)])
+        if math == "f32":
+            _assert_bench_kernels(m._rt._ws[("3d", N, 12, 28, 28)])
+        else:
+            _assert_bench_kernels_s16(m._rt._ws[("3ds16", N, 12, 28, 28)])
         pick = sorted({int(i) for i in torch.linspace(0, N - 1, 64).round().tolist()} | {0, 37, N // 2, N - 1})
         with torch.no_grad():
             ref = O.psmnet_from_features(sd, fl[pick], fr[pick], 48, 0, 112, 112)

@@ -573,17 +573,21 @@ def test_upsample_softargmin_sharp_costs(dev):
 
 
 # ------------------------------------------------------------------------------------------------ whole path
-def _model(dev, case, mx, mn):
+def _model(dev, case, mx, mn, math="auto"):
+    """math: PSMNet.regressor_math -- "auto" (round-5 default: the full-resolution stride-1 3D layers in split-f16 arithmetic where the shape
+    allows) or "f32" (every 3D layer on the fp32 MFMA kernels)."""
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
     m = PSMNet(mx, mn)
     m.load_state_dict(state_for(case), strict=True)
+    m.regressor_math = math
     return m.to(dev).eval()
 
 
+@pytest.mark.parametrize("math", ["f32", "auto"])
 @pytest.mark.parametrize("case,mx,mn", [("A", 48, 0), ("At", 48, 0), ("A2", 24, -24)])
-def test_config_a_vs_golden(dev, case, mx, mn):
+def test_config_a_vs_golden(dev, case, mx, mn, math):
     z = golden_npz()
-    m = _model(dev, "At" if case == "At" else "A", mx, mn)
+    m = _model(dev, "At" if case == "At" else "A", mx, mn, math)
     fl, fr = synth.synth_features(2, 32, 28, 28, tag="caseA")
     with torch.no_grad():
         pred = m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112)).cpu()
@@ -593,18 +597,19 @@ def test_config_a_vs_golden(dev, case, mx, mn):
     assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
     # intermediates: cost3 of the HIP path vs the oracle (sampled by the golden file too)
     rt = m._rt
-    ws = rt._ws[("3d", 2, (mx - mn) // 4, 28, 28)]
+    ws = rt._ws[("3d" if math == "f32" else "3ds16", 2, (mx - mn) // 4, 28, 28)]
     cost3 = ws["t"]["costk3"].cpu().reshape(-1)
     idx = torch.from_numpy(z[f"{case}_cost3_idx"]); val = torch.from_numpy(z[f"{case}_cost3_val"])
     assert (cost3[idx] - val).abs().max().item() < 1e-3 * max(1.0, val.abs().max().item())
-    out3 = ws["t"]["out3"].to_dense().cpu().reshape(-1)
+    out3 = ws["t"]["out3" if math == "f32" else "out3s"].to_dense().cpu().reshape(-1)
     idx = torch.from_numpy(z[f"{case}_out3_idx"]); val = torch.from_numpy(z[f"{case}_out3_val"])
     assert (out3[idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4
 
 
-def test_config_b_vs_golden(dev):
+@pytest.mark.parametrize("math", ["f32", "auto"])
+def test_config_b_vs_golden(dev, math):
     z = golden_npz()
-    m = _model(dev, "B", 48, -48)
+    m = _model(dev, "B", 48, -48, math)
     left, right = synth.synth_images(2, 224, 224, tag="caseB")
     with torch.no_grad():
         pred = m((left.to(dev), right.to(dev))).cpu()
