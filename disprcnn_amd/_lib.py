@@ -146,6 +146,10 @@ _SIGS = {
     "drc_cost_volume16_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv3d_k3_s16_supported": (_I, [_I, _I, _I, _I, _I]),
     "drc_conv3d_k3_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
+    "drc_conv3d_k3s2_s16_supported": (_I, [_I, _I, _I, _I, _I]),
+    "drc_conv3d_k3s2_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
+    "drc_deconv3d_k3s2_s16_supported": (_I, [_I, _I, _I, _I, _I]),
+    "drc_deconv3d_k3s2_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
     "drc_rs16_from_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "drc_rs16_from_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_rs16_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

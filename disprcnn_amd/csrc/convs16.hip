@@ -53,24 +53,27 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TX = 28;          // output columns per tile
-constexpr int SX = 30;          // staged columns (TX + halo)
 constexpr int PV = 128;         // voxels per chunk plane of a slab (>= (rows + 2) * SX + the 4 columns lanes 28..31 over-read)
 constexpr int CPB = PV * 16;    // bytes per chunk plane
 constexpr int RING = 3;
 
-template <int KW, bool CV>
+// RT rows x WT columns of the map make one 32-voxel MFMA tile: 1 x 28 (full-resolution maps, tiles along x), 2 x 14 and 4 x 7 (the
+// hourglass' half- and quarter-resolution maps: 28 of 32 lanes busy there as well).
+template <int KW, bool CV, int RT = 1, int WT = 28>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convs16_kernel(const drc_s16conv_params p) {
-    constexpr int RPW = 4 / KW;                 // output rows per workgroup
+    constexpr int TX = WT;                      // output columns per tile
+    constexpr int SX = WT + 2;                  // staged columns (TX + halo)
+    constexpr int RPW = 4 / KW;                 // MFMA tiles per workgroup (RPW * RT output rows)
     constexpr int CBI = KW / 2;                 // 32-channel input blocks
-    constexpr int SROWS = RPW + 2;
+    constexpr int SROWS = RPW * RT + 2;
+    static_assert(RT * WT <= 32 && (RT == 1 || !CV), "tile shape");
     constexpr int SLAB = CBI * 8 * CPB;
     constexpr int NL = CBI * 8 * (PV / 64) / 4; // LDS-DMA instructions per wave and slab
     constexpr int OWN = 16 / KW;                // accumulator registers (couts per lane) a wave finishes
     constexpr int XW = 4096;                    // bytes a wave publishes per plane: its 16 accumulator registers
     constexpr int NR = 2;                       // residual loads per step (hi, lo), always issued
     constexpr int NS = 4;                       // stores per step (RS16 hi, lo + blocked fp32 x2), always issued (dropped when unused)
-    static_assert(SROWS * SX + 4 <= PV, "slab plane too small");
+    static_assert(RT == 1 ? SROWS * SX + 4 <= PV : (SROWS + 1) * SX + 4 <= PV, "slab plane too small (incl. the rows / columns the idle lanes over-read)");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ring = lds;
     char* xchg = lds + RING * SLAB;             // [2 parities][4 waves][XW]
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int n_ = lane & 31, g = lane >> 5;
-    const int r = wave / KW, k = wave % KW;     // row of the tile, K slice
+    const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;      // this lane's voxel inside the MFMA tile (lanes >= RT*WT idle)
+    const int r = wave / KW, k = wave % KW;     // MFMA tile of the workgroup, K slice
     const int ct = blockIdx.y;                  // cout tile of 32
 
     const int D = p.D, H = p.H, W = p.W;
@@ -123,11 +127,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         srcrow[h] = rr;
         srcx[h] = srcok[h] ? v - rr * SX : 0;
     }
-    const unsigned bfrag = (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + (r * SX + n_) * 16);     // hi; lo at + 4*CPB
+    const unsigned bfrag = (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + ((r * RT + rl) * SX + xl) * 16);     // hi; lo at + 4*CPB
     const __attribute__((address_space(3))) char* ringl = (const __attribute__((address_space(3))) char*)ring;
     typedef const __attribute__((address_space(3))) f16x8 lds_frag;
 
-    const int n_xt = W / TX, n_yt = H / RPW;
+    const int n_xt = W / TX, n_yt = (H + RPW * RT - 1) / (RPW * RT);
     // XCD-aware order: block b runs on XCD b % 8; the 32 blocks of an XCD take 32 consecutive columns of the units n % 8 == xcd, so that the
     // row tiles sharing halo rows meet in one L2
     const unsigned xcd = blockIdx.x & 7, qx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (n >= (unsigned)p.N) break;
         const unsigned rem = j - nl * cols_unit;
         const int yb = (int)(rem / n_xt), xt = (int)(rem - (unsigned)yb * n_xt);
-        const int y0 = yb * RPW, x0 = xt * TX;
+        const int y0 = yb * RPW * RT, x0 = xt * TX;
 
         // source bases
         const char* xcol = CV ? nullptr : (const char*)p.x + (long)n * xnB + (long)y0 * rowB + (long)x0 * 16;
@@ -170,18 +174,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc(p.y16 ? (void*)((char*)p.y16 + (long)n * ynB) : (void*)p.w, 0, p.y16 ? 0x7FFFFF00 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t y32r = __builtin_amdgcn_make_buffer_rsrc(p.y32 ? (void*)((char*)p.y32 + (long)n * b_nB) : (void*)p.w, 0, p.y32 ? 0x7FFFFF00 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(p.res ? (void*)((const char*)p.res + (long)n * ynB) : (void*)p.w, 0, p.res ? 0x7FFFFF00 : 0, 0x00020000);
-        const bool lane_ok = n_ < TX;
-        // byte offsets of this lane's output voxel (row y0 + r, column x0 + n_) in plane 0 (padded coordinates + 1)
+        const int yl = y0 + r * RT + rl;                                  // this lane's output row
+        const bool lane_ok = n_ < RT * TX && yl < H;
+        // byte offsets of this lane's output voxel (row yl, column x0 + xl) in plane 0 (padded coordinates + 1)
         unsigned o16, o32;
         if constexpr (KW == 2) {
             // own registers 8k..8k+7 = chunk (s = k, g) complete: 16 B hi at chunk k*2+g, lo at 4 + k*2 + g
-            o16 = (unsigned)((long)ct * xcbB + planeB + (long)(y0 + r + 1) * rowB + (long)(k * 2 + g) * (Wp * 16) + (long)(x0 + n_ + 1) * 16);
+            o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)(k * 2 + g) * (Wp * 16) + (long)(x0 + xl + 1) * 16);
             // blocked fp32: block 2ct + k, channels 4g..4g+3 and 8+4g..
-            o32 = (unsigned)((long)(2 * ct + k) * b_cbB + b_planeB + (long)(y0 + r + 1) * b_rowB + (long)(x0 + n_ + 1) * 64 + g * 16);
+            o32 = (unsigned)((long)(2 * ct + k) * b_cbB + b_planeB + (long)(yl + 1) * b_rowB + (long)(x0 + xl + 1) * 64 + g * 16);
         } else {
             // own registers 4k..4k+3 = couts 8k + 4g + e: half a chunk: chunk (s = k>>1, g), bytes (k&1)*8..
-            o16 = (unsigned)((long)ct * xcbB + planeB + (long)(y0 + r + 1) * rowB + (long)((k >> 1) * 2 + g) * (Wp * 16) + (long)(x0 + n_ + 1) * 16 + (k & 1) * 8);
-            o32 = (unsigned)((long)(2 * ct + (k >> 1)) * b_cbB + b_planeB + (long)(y0 + r + 1) * b_rowB + (long)(x0 + n_ + 1) * 64 + (k & 1) * 32 + g * 16);
+            o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)((k >> 1) * 2 + g) * (Wp * 16) + (long)(x0 + xl + 1) * 16 + (k & 1) * 8);
+            o32 = (unsigned)((long)(2 * ct + (k >> 1)) * b_cbB + b_planeB + (long)(yl + 1) * b_rowB + (long)(x0 + xl + 1) * 64 + (k & 1) * 32 + g * 16);
         }
         const unsigned lo_off = (unsigned)(4 * Wp * 16);
         const float relu_lo = p.relu ? 0.f : -3.0e38f;
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (KW == 2) { rh = __builtin_bit_cast(f16x8, resv[0])[e]; rl = __builtin_bit_cast(f16x8, resv[1])[e]; }
                 else { rh = __builtin_bit_cast(f16x8, resv[0])[e]; rl = __builtin_bit_cast(f16x8, resv[1])[e]; }
                 x_ += (float)rh + (float)rl;
-                x_ = fmaxf(x_, relu_lo);
+                x_ = fminf(fmaxf(x_, relu_lo), 65504.f);            // (fp16 range of the hi part; relu_lo = -3e38 without ReLU, then the
+                x_ = fmaxf(x_, -65504.f);                              //  lower clamp applies)
                 v[e] = x_;
                 vh[e] = (_Float16)x_;
                 vl[e] = (_Float16)(x_ - (float)vh[e]);
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template <int KW, bool CV>
+template <int KW, bool CV, int RT = 1, int WT = 28>
 int launch(const drc_s16conv_params& p, hipStream_t stream) {
     constexpr int CBI = KW / 2;
     constexpr int SLAB = CBI * 8 * CPB;
@@ -370,14 +376,15 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)convs16_kernel<KW, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)convs16_kernel<KW, CV, RT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const long columns = (long)p.N * (p.H / (4 / KW)) * (p.W / TX);
+    constexpr int rows = (4 / KW) * RT;
+    const long columns = (long)p.N * ((p.H + rows - 1) / rows) * (p.W / WT);
     // one block per CU (the weights take the register file); a multiple of 8 so that every XCD runs the same number
     long blocks = 256;
     while (blocks > 8 && blocks / 2 >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16_kernel<KW, CV>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -387,8 +394,10 @@ extern "C" int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int 
     if (cin != 32 && cin != 64) return 0;
     if (cout != 32 && cout != 64) return 0;
     if (D <= 0 || D % 3) return 0;
-    if (W <= 0 || W % TX) return 0;
-    if (H <= 0 || H % (cin == 32 ? 2 : 1)) return 0;
+    if (H <= 0) return 0;
+    if (W == 14 || W == 7) return 1;                 // 2 x 14 and 4 x 7 tiles (ragged last row tile masked)
+    if (W <= 0 || W % 28) return 0;
+    if (H % (cin == 32 ? 2 : 1)) return 0;
     return 1;
 }
 
@@ -400,11 +409,14 @@ extern "C" int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* pp, void* stream)
     if (cv ? (!p.left || !p.right || p.cin != 64) : !p.x) return -1;
     if (p.N < 0) return -2;
     if (!drc_conv3d_k3_s16_supported(p.cin, p.cout, p.D, p.H, p.W)) return -4;
+    if (cv && p.W % 28) return -4;
     if (p.N == 0) return 0;
     // 32-bit offsets inside one unit
     const long unit16 = (long)(p.cout / 32) * (p.D + 2) * (p.H + 2) * (p.W + 2) * 128;
     if (unit16 >= 0x7FFFFF00L / 2) return -5;
     hipStream_t s = (hipStream_t)stream;
     if (cv) return launch<4, true>(p, s);
+    if (p.W == 14) return p.cin == 32 ? launch<2, false, 2, 14>(p, s) : launch<4, false, 2, 14>(p, s);
+    if (p.W == 7) return p.cin == 32 ? launch<2, false, 4, 7>(p, s) : launch<4, false, 4, 7>(p, s);
     return p.cin == 32 ? launch<2, false>(p, s) : launch<4, false>(p, s);
 }

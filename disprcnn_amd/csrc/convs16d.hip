@@ -1,0 +1,331 @@
+// convs16d.hip -- 3x3x3 STRIDE-2 convolution (+BN, +ReLU) in split-f16 arithmetic on the f16 matrix cores (gfx950 / CDNA4), round 5.
+//
+//   reference: hourglass conv1 / conv3, stackhourglass.py:9-12,17-19 (convbn_3d k3 s2 p1 + ReLU), fp32 (config/defaults.py:22).
+//
+// The arithmetic, the RS16 tensor layout, the K split over the workgroup's waves and the publish / finalize pipeline are those of
+// convs16.hip (read its header first).  What differs:
+//   * output voxel o reads input 2o + k - 1: a B fragment's 32 lanes read every second voxel of the staged rows (lane base
+//     (2*row*SXI + 2*col) * 16 B, the tap (kh, kw) is still a uniform immediate), the slab of one input plane is 2*rows + 1 input rows x
+//     2*WT + 2 columns;
+//   * depth: output plane zo takes input planes 2zo-1 (kd 0), 2zo (kd 1), 2zo+1 (kd 2).  The walk is over INPUT planes: an even plane
+//     (9 taps, 27 MFMAs) feeds one accumulator, an odd plane (18 taps, 54 MFMAs) finishes it and opens the next; a pair of planes = one
+//     output plane = 81 MFMAs per wave, published after the odd step and finalized in the shadow of the next even step's MFMAs.
+//   * no residual (the reference's stride-2 layers have none).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/disprcnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define S16_WAITCNT(vm, lgkm) (((vm) & 15) | (7 << 4) | ((lgkm) << 8) | (((vm) >> 4) << 14))
+
+namespace {
+
+// KW = cin / 16 K slices; RT x WT OUTPUT voxels per MFMA tile (1 x 28, 2 x 14, 4 x 7); RING slots of one input-plane slab
+template <int KW, int RT, int WT, int RING>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convs16d_kernel(const drc_s16conv_params p) {
+    constexpr int RPW = 4 / KW;                 // MFMA tiles per workgroup
+    constexpr int CBI = KW / 2;
+    constexpr int SXI = 2 * WT + 2;             // staged input columns
+    constexpr int SROWS = 2 * RPW * RT + 1;     // staged input rows
+    constexpr int PV = ((SROWS + 1) * SXI + 8 + 63) / 64 * 64;     // voxels per chunk plane (+ what the idle lanes over-read)
+    constexpr int CPB = PV * 16;
+    constexpr int SLAB = CBI * 8 * CPB;
+    constexpr int NPI = PV / 64;                // LDS-DMA instructions per chunk plane
+    constexpr int NL = CBI * 8 * NPI / 4;       // ... per wave and slab
+    static_assert(NL == CBI * 2 * NPI, "DMA split: each wave stages every fourth chunk plane");
+    constexpr int OWN = 16 / KW;
+    constexpr int XW = 4096;
+    constexpr int NS = 2;                       // stores per finalize (RS16 hi, lo)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* ring = lds;
+    char* xchg = lds + RING * SLAB;             // [2 parities][4 waves][XW]
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int n_ = lane & 31, g = lane >> 5;
+    const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;
+    const int r = wave / KW, k = wave % KW;
+    const int ct = blockIdx.y;
+
+    // input geometry (p.D, p.H, p.W) -> output (D/2, H/2, W/2)
+    const int Di = p.D, Hi = p.H, Wi = p.W;
+    const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
+    const int Wpi = Wi + 2, Hpi = Hi + 2;
+    const long i_rowB = (long)Wpi * 128, i_planeB = (long)Hpi * i_rowB, i_cbB = (long)(Di + 2) * i_planeB, i_nB = (long)CBI * i_cbB;
+    const int Wpo = Wo + 2, Hpo = Ho + 2;
+    const long o_rowB = (long)Wpo * 128, o_planeB = (long)Hpo * o_rowB, o_cbB = (long)(Do + 2) * o_planeB, o_nB = (long)(p.cout / 32) * o_cbB;
+
+    f16x8 wh[27], wl[27];
+    {
+        const char* wb = (const char*)p.w + ((long)(ct * KW + k) * 54) * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            wh[t] = *(const f16x8*)(wb + (t * 2) * 1024);
+            wl[t] = *(const f16x8*)(wb + (t * 2 + 1) * 1024);
+        }
+    }
+    float sc[OWN], sh[OWN];
+#pragma unroll
+    for (int e = 0; e < OWN; ++e) {
+        const int reg = k * OWN + e;
+        const int co = ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
+        sc[e] = p.scale[co];
+        sh[e] = p.shift[co];
+    }
+    // LDS-DMA: instruction id = wave*NL + i -> (cb, chunk, piece of the plane); lane -> staged voxel v = piece*64 + lane -> (row, column)
+    unsigned srcoff[NPI];
+#pragma unroll
+    for (int h = 0; h < NPI; ++h) {
+        const int v = h * 64 + lane;
+        const bool ok = v < SROWS * SXI;
+        const int rr = ok ? v / SXI : 0;
+        const int xx = ok ? v - rr * SXI : 0;
+        srcoff[h] = (unsigned)(rr * i_rowB + xx * 16);
+    }
+    const unsigned bfrag = (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + ((2 * (r * RT + rl)) * SXI + 2 * xl) * 16);     // hi; lo at + 4*CPB
+    const __attribute__((address_space(3))) char* ringl = (const __attribute__((address_space(3))) char*)ring;
+    typedef const __attribute__((address_space(3))) f16x8 lds_frag;
+
+    const int n_xt = Wo / WT, n_yt = (Ho + RPW * RT - 1) / (RPW * RT);
+    const unsigned xcd = blockIdx.x & 7, qx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned cols_unit = (unsigned)n_yt * n_xt;
+    const float relu_lo = p.relu ? 0.f : -3.0e38f;
+
+    for (unsigned it = 0;; ++it) {
+        const unsigned j = it * per_xcd + qx;
+        const unsigned nl = j / cols_unit;
+        const unsigned n = nl * 8 + xcd;
+        if (n >= (unsigned)p.N) break;
+        const unsigned rem = j - nl * cols_unit;
+        const int yb = (int)(rem / n_xt), xt = (int)(rem - (unsigned)yb * n_xt);
+        const int y0 = yb * RPW * RT, x0 = xt * WT;          // output tile origin
+
+        // staged input rows start at input row 2*y0 - 1 = padded row 2*y0, columns at padded column 2*x0
+        const char* xcol = (const char*)p.x + (long)n * i_nB + (long)(2 * y0) * i_rowB + (long)(2 * x0) * 16;
+        auto stage = [&](int plane, int slot) __attribute__((always_inline)) {       // logical input plane (clamped) -> ring slot
+            const int pl = plane < Di ? plane : Di - 1;
+            char* dst = ring + slot * SLAB;
+#pragma unroll
+            for (int ci = 0; ci < CBI * 2; ++ci) {
+                const int cc = ci * 4 + wave;                            // this wave's chunk planes (cb*8 + c): every fourth
+                const int cb = cc >> 3, c = cc & 7;
+                const char* src = xcol + (long)cb * i_cbB + (long)(pl + 1) * i_planeB + (long)c * (Wpi * 16);
+#pragma unroll
+                for (int h = 0; h < NPI; ++h)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + srcoff[h]), LDS_PTR(dst + cc * CPB + h * 1024), 16, 0, 0);
+            }
+        };
+        const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y16 + (long)n * o_nB), 0, 0x7FFFFF00, 0x00020000);
+        const int yl = y0 + r * RT + rl;
+        const bool lane_ok = n_ < RT * WT && yl < Ho;
+        unsigned o16;
+        if constexpr (KW == 2)
+            o16 = (unsigned)((long)ct * o_cbB + o_planeB + (long)(yl + 1) * o_rowB + (long)(k * 2 + g) * (Wpo * 16) + (long)(x0 + xl + 1) * 16);
+        else
+            o16 = (unsigned)((long)ct * o_cbB + o_planeB + (long)(yl + 1) * o_rowB + (long)((k >> 1) * 2 + g) * (Wpo * 16) + (long)(x0 + xl + 1) * 16 + (k & 1) * 8);
+        const unsigned lo_off = (unsigned)(4 * Wpo * 16);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(S16_WAITCNT(63, 0));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s_ = 0; s_ + 1 < RING; ++s_) stage(s_, s_);
+        int slot = 0;                                         // ring slot of the current input plane
+
+        // one input plane.  ODD = false: plane 2zo, taps kd = 1 into acc[A]; finalizes output plane zo-1 meanwhile.
+        //                   ODD = true : plane 2zo+1, taps kd = 2 into acc[A] (complete: published) and kd = 0 into acc[B] (plane zo+1).
+        auto step = [&](int zi, int zo, auto AT, auto ODDT, auto COMPT) __attribute__((always_inline)) {
+            constexpr int A = decltype(AT)::value, B = A ^ 1;
+            constexpr bool ODD = decltype(ODDT)::value, COMPUTE = decltype(COMPT)::value;
+            // the slab of plane zi landed: in flight behind it may be the RING-2 younger slabs and the previous step's stores
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(S16_WAITCNT((RING - 2) * NL + (ODD ? NS : 0), 0));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                int ns = slot + RING - 1; ns = ns >= RING ? ns - RING : ns;
+                stage(zi + RING - 1, ns);                    // the slot of plane zi-1: free since the barrier
+            }
+            const __attribute__((address_space(3))) char* sb = ringl + slot * SLAB + bfrag;
+            if constexpr (!ODD) {
+                // ---- finalize plane zo-1 (partial sums of the K slices, this wave's couts) in the shadow of the 27 MFMAs
+                f32x4 part[4];
+                const char* xb = xchg + ((zo - 1) & 1) * (4 * XW) + (r * KW) * XW + lane * 16;
+                if constexpr (KW == 2) {
+                    part[0] = *(const f32x4*)(xb + (k * 2) * 1024);
+                    part[1] = *(const f32x4*)(xb + XW + (k * 2) * 1024);
+                    part[2] = *(const f32x4*)(xb + (k * 2 + 1) * 1024);
+                    part[3] = *(const f32x4*)(xb + XW + (k * 2 + 1) * 1024);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) part[q] = *(const f32x4*)(xb + q * XW + k * 1024);
+                }
+                _Float16 vh[OWN], vl[OWN];
+                auto fin = [&](int e) __attribute__((always_inline)) {
+                    float s_;
+                    if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
+                    else s_ = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+                    float x_ = fmaxf(s_ * sc[e] + sh[e], relu_lo);
+                    x_ = fminf(x_, 65504.f);
+                    vh[e] = (_Float16)x_;
+                    vl[e] = (_Float16)(x_ - (float)vh[e]);
+                };
+                f16x8 bh[2], bl[2];
+                if constexpr (COMPUTE) {
+                    bh[0] = *(lds_frag*)(sb);
+                    bl[0] = *(lds_frag*)(sb + 4 * CPB);
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    if constexpr (COMPUTE) {
+                        const int kh = q / 3, kw = q - kh * 3;
+                        if (q + 1 < 9) {
+                            const int kh1 = (q + 1) / 3, kw1 = (q + 1) - kh1 * 3;
+                            bh[(q + 1) & 1] = *(lds_frag*)(sb + (kh1 * SXI + kw1) * 16);
+                            bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + (kh1 * SXI + kw1) * 16);
+                        }
+                        const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
+                        const int t1 = 9 + kh * 3 + kw;
+                        acc[A] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A], 0, 0, 0);
+                        acc[A] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], l_, acc[A], 0, 0, 0);
+                        acc[A] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A], 0, 0, 0);
+                    }
+                    if (q < OWN) fin(q);
+                    if (q == OWN || (OWN == 8 && q == 8)) {
+                        const bool ok = lane_ok && zo >= 1;
+                        const unsigned po = ok ? (unsigned)((long)(zo - 1) * o_planeB) : 0x80000000u;
+                        if constexpr (KW == 2) {
+                            f16x8 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { hi[e] = vh[e]; lo[e] = vl[e]; }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), y16r, o16 + po, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), y16r, o16 + lo_off + po, 0, 0);
+                        } else {
+                            f16x4 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hi[e] = vh[e]; lo[e] = vl[e]; }
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), y16r, o16 + po, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), y16r, o16 + lo_off + po, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                f16x8 bh[2], bl[2];
+                bh[0] = *(lds_frag*)(sb);
+                bl[0] = *(lds_frag*)(sb + 4 * CPB);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int kh = q / 3, kw = q - kh * 3;
+                    if (q + 1 < 9) {
+                        const int kh1 = (q + 1) / 3, kw1 = (q + 1) - kh1 * 3;
+                        bh[(q + 1) & 1] = *(lds_frag*)(sb + (kh1 * SXI + kw1) * 16);
+                        bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + (kh1 * SXI + kw1) * 16);
+                    }
+                    const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
+                    const int t0 = kh * 3 + kw, t2 = 18 + t0;
+                    acc[A] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], h_, acc[A], 0, 0, 0);
+                    acc[B] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[B], 0, 0, 0);
+                    acc[A] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], l_, acc[A], 0, 0, 0);
+                    acc[B] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], l_, acc[B], 0, 0, 0);
+                    acc[A] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A], 0, 0, 0);
+                    acc[B] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t0], h_, acc[B], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // output plane zo complete: publish, clear
+                const f32x16 a = acc[A];
+                char* xb = xchg + (zo & 1) * (4 * XW) + wave * XW + lane * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(xb + q * 1024) = (f32x4){a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[A][e] = 0.f;
+            }
+            slot = slot + 1 == RING ? 0 : slot + 1;
+        };
+        using F = std::false_type;
+        using T = std::true_type;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        int zo = 0;
+#pragma unroll 1
+        for (; zo + 1 < Do; zo += 2) {
+            step(2 * zo, zo, I0{}, F{}, T{});
+            step(2 * zo + 1, zo, I0{}, T{}, T{});
+            step(2 * zo + 2, zo + 1, I1{}, F{}, T{});
+            step(2 * zo + 3, zo + 1, I1{}, T{}, T{});
+        }
+        if (zo < Do) {
+            step(2 * zo, zo, I0{}, F{}, T{});
+            step(2 * zo + 1, zo, I0{}, T{}, T{});
+            ++zo;
+        }
+        // drain: finalize the last plane (an even step without MFMAs)
+        step(2 * zo, zo, I0{}, F{}, F{});
+    }
+}
+
+template <int KW, int RT, int WT, int RING>
+int launch(const drc_s16conv_params& p, hipStream_t stream) {
+    constexpr int RPW = 4 / KW, CBI = KW / 2, SXI = 2 * WT + 2, SROWS = 2 * RPW * RT + 1;
+    constexpr int PV = ((SROWS + 1) * SXI + 8 + 63) / 64 * 64;
+    constexpr size_t lds = (size_t)RING * CBI * 8 * PV * 16 + 2 * 4 * 4096;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)convs16d_kernel<KW, RT, WT, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const long columns = (long)p.N * ((Ho + RPW * RT - 1) / (RPW * RT)) * (Wo / WT);
+    long blocks = 256;
+    while (blocks > 8 && blocks / 2 >= columns) blocks /= 2;
+    hipLaunchKernelGGL((convs16d_kernel<KW, RT, WT, RING>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// D, H, W = the INPUT dims (all even); the output is (D/2, H/2, W/2)
+extern "C" int drc_conv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W) {
+    if (cin != 32 && cin != 64) return 0;
+    if (cout != 32 && cout != 64) return 0;
+    if (D <= 0 || H <= 0 || W <= 0 || (D & 1) || (H & 1) || (W & 1)) return 0;
+    const int Wo = W / 2;
+    return Wo == 14 || Wo == 7 || Wo % 28 == 0;
+}
+
+extern "C" int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const drc_s16conv_params& p = *pp;
+    if (!p.x || !p.w || !p.scale || !p.shift || !p.y16) return -1;
+    if (p.res || p.y32 || p.left || p.right) return -4;
+    if (p.N < 0) return -2;
+    if (!drc_conv3d_k3s2_s16_supported(p.cin, p.cout, p.D, p.H, p.W)) return -4;
+    if (p.N == 0) return 0;
+    const long unit_in = (long)(p.cin / 32) * (p.D + 2) * (p.H + 2) * (p.W + 2) * 128;
+    if (unit_in >= 0x7FFFFF00L) return -5;
+    hipStream_t s = (hipStream_t)stream;
+    const int Wo = p.W / 2;
+    // (ring depth by what fits the 160 KiB LDS next to the 32 KiB exchange buffers)
+    if (Wo == 14) return p.cin == 32 ? launch<2, 2, 14, 3>(p, s) : launch<4, 2, 14, 2>(p, s);
+    if (Wo == 7) return p.cin == 32 ? launch<2, 4, 7, 3>(p, s) : launch<4, 4, 7, 2>(p, s);
+    return p.cin == 32 ? launch<2, 1, 28, 2>(p, s) : launch<4, 1, 28, 2>(p, s);
+}

@@ -1384,33 +1384,51 @@ class RS16:
         return out
 
 
-def s16_supported(cin, cout, D, H, W):
-    return bool(S16["enabled"] and _lib.lib().drc_conv3d_k3_s16_supported(cin, cout, D, H, W))
+def s16_supported(cin, cout, D, H, W, kind="s1"):
+    """kind: "s1" stride-1 conv, "s2" stride-2 conv, "up" transposed conv (D, H, W = the layer's INPUT dims)."""
+    fn = {"s1": "drc_conv3d_k3_s16_supported", "s2": "drc_conv3d_k3s2_s16_supported", "up": "drc_deconv3d_k3s2_s16_supported"}[kind]
+    return bool(S16["enabled"] and getattr(_lib.lib(), fn)(cin, cout, D, H, W))
 
 
 class ConvPlanS16:
-    """One launch of drc_conv3d_k3_s16_fwd: stride-1 3x3x3 conv (+BN, +residual, +ReLU) on RS16 tensors; cv: the cost volume of the
-    left / right 2D feature maps is the (virtual) input (reference stackhourglass.py:115-130)."""
+    """One launch of the split-f16 3x3x3 kernels on RS16 tensors (+BN, +residual, +ReLU): kind "s1" drc_conv3d_k3_s16_fwd (cv: the cost
+    volume of the left / right 2D feature maps is the virtual input, reference stackhourglass.py:115-130), "s2" drc_conv3d_k3s2_s16_fwd,
+    "up" drc_deconv3d_k3s2_s16_fwd.  D, H, W = the INPUT dims."""
 
-    def __init__(self, N, cin, cout, D, H, W, relu, cv=False, device=None):
-        if not _lib.lib().drc_conv3d_k3_s16_supported(cin, cout, D, H, W) or (cv and cin != 64):
+    def __init__(self, N, cin, cout, D, H, W, relu, cv=False, device=None, kind="s1"):
+        if not s16_supported(cin, cout, D, H, W, kind) or (cv and (cin != 64 or kind != "s1" or W % 28)):
             raise ValueError("ConvPlanS16: unsupported shape")
-        self.N, self.cin, self.cout, self.D, self.H, self.W, self.relu, self.cv, self.device = N, cin, cout, D, H, W, bool(relu), cv, device
-        self.flops = 2 * N * D * H * W * 27 * cin * cout
-        self.kname = "convs16_kernel<%d,%s>" % (cin // 16, "true" if cv else "false")
+        self.N, self.cin, self.cout, self.D, self.H, self.W, self.relu, self.cv, self.device, self.kind = N, cin, cout, D, H, W, bool(relu), cv, device, kind
+        self.out_dhw = {"s1": (D, H, W), "s2": (D // 2, H // 2, W // 2), "up": (2 * D, 2 * H, 2 * W)}[kind]
+        vox = D * H * W if kind != "s2" else (D // 2) * (H // 2) * (W // 2)
+        self.flops = 2 * N * vox * 27 * cin * cout
+        rt, wt = (1, 28)
+        nw = {"s1": W, "s2": W // 2, "up": W}[kind]
+        if nw in (14, 7):
+            rt, wt = (2, 14) if nw == 14 else (4, 7)
+        if kind == "s1":
+            self.kname = "convs16_kernel<%d,%s,%d,%d>" % (cin // 16, "true" if cv else "false", rt, wt)
+        elif kind == "s2":
+            self.kname = "convs16d_kernel<%d,%d,%d>" % (cin // 16, rt, wt)
+        else:
+            self.kname = "convs16u_kernel<%d,%d>" % (rt, wt)
 
     def run(self, x16, w16, scale, shift, y16=None, y32=None, res=None, left=None, right=None, lo4=0):
         from ._lib import DrcS16ConvParams
-        for t_ in (x16, y16, res):
-            if t_ is not None and (t_.N < self.N or (t_.D, t_.H, t_.W, t_.pd) != (self.D, self.H, self.W, 1)):
-                raise ValueError("ConvPlanS16.run: tensor geometry differs from the plan")
-        if y32 is not None and ((y32.C, y32.D, y32.H, y32.W, y32.pd, y32.ph, y32.pw) != (self.cout, self.D, self.H, self.W, 1, 1, 1) or getattr(y32, "cb_off", 0)):
-            raise ValueError("ConvPlanS16.run: the blocked fp32 output must be a whole tensor with halo 1")
+        if x16 is not None and (x16.N < self.N or (x16.C, x16.D, x16.H, x16.W, x16.pd) != (self.cin, self.D, self.H, self.W, 1)):
+            raise ValueError("ConvPlanS16.run: input geometry differs from the plan")
+        for t_ in (y16, res):
+            if t_ is not None and (t_.N < self.N or (t_.C, t_.D, t_.H, t_.W, t_.pd) != (self.cout,) + self.out_dhw + (1,)):
+                raise ValueError("ConvPlanS16.run: output / residual geometry differs from the plan")
+        if y32 is not None and (self.kind != "s1" or (y32.C, y32.D, y32.H, y32.W, y32.pd, y32.ph, y32.pw) != (self.cout, self.D, self.H, self.W, 1, 1, 1) or getattr(y32, "cb_off", 0)):
+            raise ValueError("ConvPlanS16.run: the blocked fp32 output (stride-1 kernel only) must be a whole tensor with halo 1")
+        if self.kind != "s1" and (y16 is None or (res is not None and self.kind == "s2")):
+            raise ValueError("ConvPlanS16.run: the stride-2 / transposed kernels write RS16 (the stride-2 one takes no residual)")
         if self.cv:
             for f in (left, right):
                 if f is None or (f.C, f.D, f.H, f.W, f.pd) != (32, 1, self.H, self.W, 0) or f.N < self.N:
                     raise ValueError("ConvPlanS16.run: the cost-volume variant reads two RS16 2D maps [N,32,H,W]")
-        elif x16 is None or x16.C != self.cin:
+        elif x16 is None:
             raise ValueError("ConvPlanS16.run: input missing")
         p = DrcS16ConvParams(_ptr(x16.storage) if x16 is not None else None, _ptr(w16), _ptr(scale), _ptr(shift),
                              _ptr(res.storage) if res is not None else None, _ptr(y16.storage) if y16 is not None else None,
@@ -1420,8 +1438,9 @@ class ConvPlanS16:
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        st = _lib.lib().drc_conv3d_k3_s16_fwd(C.byref(p), _stream_ptr(dev))
-        _lib.check(st, "drc_conv3d_k3_s16_fwd")
+        fn = {"s1": "drc_conv3d_k3_s16_fwd", "s2": "drc_conv3d_k3s2_s16_fwd", "up": "drc_deconv3d_k3s2_s16_fwd"}[self.kind]
+        st = getattr(_lib.lib(), fn)(C.byref(p), _stream_ptr(dev))
+        _lib.check(st, fn)
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(dev))
             TIMING.append((self.kname, self.flops, e0, e1))

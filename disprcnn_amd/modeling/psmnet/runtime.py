@@ -88,7 +88,8 @@ class _Conv:
         """(packed split-f16 weights, epilogue scale = folded BN scale * 2^-wexp) for drc_conv3d_k3_s16_fwd."""
         from ... import s16 as S
         if self._s16 is None:
-            self._s16 = S.pack_weight_s16(self.conv.weight.detach().to(device=self.device, dtype=torch.float32))
+            w = self.conv.weight.detach().to(device=self.device, dtype=torch.float32)
+            self._s16 = S.pack_weight_s16(w.transpose(0, 1).contiguous() if self.transposed else w)     # ConvTranspose [Cin,Cout,..]: out = 2i - 1 + k, no flip
         if self._s16_scale is None or self._s16_scale[0] is not self.scale:
             self._s16_scale = (self.scale, (self.scale * (2.0 ** -self._s16[1])).contiguous())
         return self._s16[0], self._s16_scale[1]
@@ -391,16 +392,26 @@ class PSMNetRuntime:
         return t["costk1"], t["costk2"], t["costk3"]
 
     # ------------------------------------------------------------------ split-f16 regressor (round 5; eval only)
+    @staticmethod
+    def _s16_layers(Dp, Hp, Wp):
+        """(kind, cin, cout, input dims) of every 3x3x3 layer of the regressor but the three cout-1 heads."""
+        full = (Dp, Hp, Wp)
+        half = tuple(s // 2 for s in full)
+        quart = tuple(s // 2 for s in half)
+        return [("s1", 64, 32, full), ("s1", 32, 32, full), ("s2", 32, 64, full), ("s1", 64, 64, half), ("s2", 64, 64, half),
+                ("s1", 64, 64, quart), ("up", 64, 64, quart), ("up", 64, 32, half)]
+
     def _use_s16(self, training, Dp, Hp, Wp):
-        """Eval: the full-resolution stride-1 3x3x3 layers (dres0, dres1, classif*[0]) run in split-f16 arithmetic on the f16 matrix cores
-        (convs16.hip: fp32-class results) when the volume's shape is one the kernel takes; PSMNet.regressor_math = "f32"
-        keeps every layer on the fp32 MFMA kernels."""
+        """Eval: every 3x3x3 layer of the regressor but the cout-1 heads runs in split-f16 arithmetic on the f16 matrix cores (convs16*.hip:
+        fp32-class results) when the volume's shape is one the kernels take; PSMNet.regressor_math = "f32" keeps the fp32 MFMA
+        kernels of rounds 1-4."""
         mode = getattr(self.model, "regressor_math", "auto")
         if mode not in ("auto", "f32", "f16x2"):
             raise ValueError("PSMNet.regressor_math must be 'auto', 'f32' or 'f16x2'")
-        ok = (not training and self._tape is None and E.s16_supported(64, 32, Dp, Hp, Wp) and E.s16_supported(32, 32, Dp, Hp, Wp))
+        ok = (not training and self._tape is None and Dp % 4 == 0 and Hp % 4 == 0 and Wp % 4 == 0 and
+              all(E.s16_supported(ci, co, *dims, kind=kind) for kind, ci, co, dims in self._s16_layers(Dp, Hp, Wp)))
         if mode == "f16x2" and not ok:
-            raise RuntimeError("PSMNet.regressor_math = 'f16x2': eval only, volume dims D' % 3 == 0, W' % 28 == 0, H' even")
+            raise RuntimeError("PSMNet.regressor_math = 'f16x2': eval only; volume dims D' % 12 == 0, W' = 28 or a multiple of 56, H' % 4 == 0")
         return ok and mode != "f32"
 
     def _ws3d_s16(self, N, Dp, Hp, Wp):
@@ -410,80 +421,67 @@ class PSMNetRuntime:
             return ws
         pool = self._pool_for(self._slotted(("3ds16", Dp, Hp, Wp)), N)
         full = (Dp, Hp, Wp)
-        half = tuple(-(-s // 2) for s in full)
-        quart = tuple(-(-s // 2) for s in half)
-        if tuple(2 * s for s in half) != full or tuple(2 * s for s in quart) != half:
-            raise ValueError(f"cost-volume dims {full} must be divisible by 4 (D,H,W multiples of 16; SURVEY 8)")
+        half = tuple(s // 2 for s in full)
+        quart = tuple(s // 2 for s in half)
         t = {}
-
-        def B(name, c, d, h, w):
-            t[name] = pool.blocked(name, N, c, d, h, w, 1, 1, 1)
 
         def S(name, c, d, h, w, pd=1):
             t[name] = pool.rs16(name, N, c, d, h, w, pd)
 
         S("featL", 32, 1, Hp, Wp, 0); S("featR", 32, 1, Hp, Wp, 0)
-        for n in ("d0a", "cost0a", "d1a", "out1s", "out2s", "out3s"):
+        for n in ("d0a", "cost0a", "d1a", "cost0", "out1", "out2", "out3"):
             S(n, 32, *full)
-        for n in ("cost0", "out1", "out2", "cls_t1", "cls_t2", "cls_t3"):            # fp32 consumers: the hourglass kernels, the cout-1 head
-            B(n, 32, *full)
         for k in (1, 2, 3):
-            B(f"hg{k}.c1", 64, *half); B(f"hg{k}.pre", 64, *half); B(f"hg{k}.post", 64, *half)
-            B(f"hg{k}.c3", 64, *quart); B(f"hg{k}.c4", 64, *quart)
+            S(f"hg{k}.c1", 64, *half); S(f"hg{k}.pre", 64, *half); S(f"hg{k}.post", 64, *half)
+            S(f"hg{k}.c3", 64, *quart); S(f"hg{k}.c4", 64, *quart)
+            t[f"cls_t{k}"] = pool.blocked(f"cls_t{k}", N, 32, *full, 1, 1, 1)        # fp32: the cout-1 head reads it
             t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
-        p = {}
         dev = self.device
-        p["dres0.0"] = E.ConvPlanS16(N, 64, 32, *full, True, cv=True, device=dev)
-        p["dres0.2"] = E.ConvPlanS16(N, 32, 32, *full, True, device=dev)
-        p["dres1.0"] = E.ConvPlanS16(N, 32, 32, *full, True, device=dev)
-        p["dres1.2"] = E.ConvPlanS16(N, 32, 32, *full, False, device=dev)
-        out_geom = E.Blocked.geometry(N, 32, *full, 1, 1, 1, dev)
+        P = lambda kind, ci, co, dims, relu, cv=False: E.ConvPlanS16(N, ci, co, *dims, relu, cv=cv, device=dev, kind=kind)
+        p = {}
+        p["dres0.0"] = P("s1", 64, 32, full, True, cv=True)
+        p["dres0.2"] = P("s1", 32, 32, full, True)
+        p["dres1.0"] = P("s1", 32, 32, full, True)
+        p["dres1.2"] = P("s1", 32, 32, full, False)
         for k in (1, 2, 3):
-            src = t["cost0"] if k == 1 else t[f"out{k - 1}"]
-            p[f"hg{k}.conv1"] = E.plan_conv3d(src, t[f"hg{k}.c1"], 2, 64, True)
-            p[f"hg{k}.conv2"] = E.plan_conv3d(t[f"hg{k}.c1"], t[f"hg{k}.pre"], 1, 64, True)
-            p[f"hg{k}.conv3"] = E.plan_conv3d(t[f"hg{k}.pre"], t[f"hg{k}.c3"], 2, 64, True)
-            p[f"hg{k}.conv4"] = E.plan_conv3d(t[f"hg{k}.c3"], t[f"hg{k}.c4"], 1, 64, True)
-            p[f"hg{k}.conv5"] = E.plan_deconv3d(t[f"hg{k}.c4"], t[f"hg{k}.post"], 64, True)
-            p[f"hg{k}.conv6"] = E.plan_deconv3d(t[f"hg{k}.post"], t[f"out{k}"] if k < 3 else out_geom, 32, False)
-            if not p[f"hg{k}.conv6"].deconv_direct:
-                raise RuntimeError("the split-f16 regressor needs the LDS-free transposed convolution (engine.DECONV_DIRECT)")
-            p[f"classif{k}.0"] = E.ConvPlanS16(N, 32, 32, *full, True, device=dev)
+            p[f"hg{k}.conv1"] = P("s2", 32, 64, full, True)
+            p[f"hg{k}.conv2"] = P("s1", 64, 64, half, True)
+            p[f"hg{k}.conv3"] = P("s2", 64, 64, half, True)
+            p[f"hg{k}.conv4"] = P("s1", 64, 64, quart, True)
+            p[f"hg{k}.conv5"] = P("up", 64, 64, quart, True)
+            p[f"hg{k}.conv6"] = P("up", 64, 32, half, False)
+            p[f"classif{k}.0"] = P("s1", 32, 32, full, True)
         ws = dict(t=t, p=p, pool=pool, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
         return self._ws_put(key, ws)
 
     def _regress_s16(self, ws, W, lo4):
-        """The schedule of _regress with the full-resolution stride-1 layers in split-f16 arithmetic; ws['t']['featL'/'featR'] hold the
-        feature maps (RS16 2D).  The hourglass interiors stay on the fp32 kernels; conv6 writes out_k in both layouts."""
+        """The schedule of _regress on RS16 tensors, every layer but the cout-1 heads in split-f16 arithmetic; ws['t']['featL'/'featR'] hold
+        the feature maps (RS16 2D).  Reference: stackhourglass.py:115-144."""
         t, p = ws["t"], ws["p"]
 
-        def run(plan, wname, x, y, res=None):
-            self._site(ws, W, plan, wname, x, y, res)
-
-        def run16(plan, wname, x16, y16=None, y32=None, res=None, **kw):
+        def run(plan, wname, x, y16=None, y32=None, res=None, **kw):
             w16, sc16 = W[wname].s16()
-            p[plan].run(t[x16] if x16 else None, w16, sc16, W[wname].shift, y16=t[y16] if y16 else None, y32=t[y32] if y32 else None,
+            p[plan].run(t[x] if x else None, w16, sc16, W[wname].shift, y16=t[y16] if y16 else None, y32=t[y32] if y32 else None,
                         res=t[res] if res else None, **kw)
 
-        run16("dres0.0", "dres0.0", None, y16="d0a", left=t["featL"], right=t["featR"], lo4=lo4)
-        run16("dres0.2", "dres0.2", "d0a", y16="cost0a")
-        run16("dres1.0", "dres1.0", "cost0a", y16="d1a")
-        run16("dres1.2", "dres1.2", "d1a", y32="cost0", res="cost0a")             # dres1(cost0)+cost0, no relu
+        run("dres0.0", "dres0.0", None, y16="d0a", left=t["featL"], right=t["featR"], lo4=lo4)
+        run("dres0.2", "dres0.2", "d0a", y16="cost0a")
+        run("dres1.0", "dres1.0", "cost0a", y16="d1a")
+        run("dres1.2", "dres1.2", "d1a", y16="cost0", res="cost0a")             # dres1(cost0)+cost0, no relu
         for k, hg in ((1, "dres2"), (2, "dres3"), (3, "dres4")):
             src = "cost0" if k == 1 else f"out{k - 1}"
-            postsqu = None if k == 1 else f"hg{k - 1}.post"
-            presqu = f"hg{k}.pre" if k == 1 else "hg1.pre"
-            run(f"hg{k}.conv1", hg + ".conv1", src, f"hg{k}.c1")
-            run(f"hg{k}.conv2", hg + ".conv2", f"hg{k}.c1", f"hg{k}.pre", res=postsqu)
-            run(f"hg{k}.conv3", hg + ".conv3", f"hg{k}.pre", f"hg{k}.c3")
-            run(f"hg{k}.conv4", hg + ".conv4", f"hg{k}.c3", f"hg{k}.c4")
-            run(f"hg{k}.conv5", hg + ".conv5", f"hg{k}.c4", f"hg{k}.post", res=presqu)
-            c, pl = W[hg + ".conv6"], p[f"hg{k}.conv6"]                               # out_k = conv6 + cost0: RS16 (+ fp32 for the next hourglass)
-            pl.run(t[f"hg{k}.post"], c.w, c.scale, c.shift, t[f"out{k}"] if k < 3 else None, t["cost0"], w16=c.w16_for(pl), y16=t[f"out{k}s"])
+            postsqu = None if k == 1 else f"hg{k - 1}.post"                      # dres3(.., post1), dres4(.., post2)
+            presqu = f"hg{k}.pre" if k == 1 else "hg1.pre"                       # pre1 reused by dres3 AND dres4 (:136,:139)
+            run(f"hg{k}.conv1", hg + ".conv1", src, y16=f"hg{k}.c1")
+            run(f"hg{k}.conv2", hg + ".conv2", f"hg{k}.c1", y16=f"hg{k}.pre", res=postsqu)      # relu(conv2 + postsqu)
+            run(f"hg{k}.conv3", hg + ".conv3", f"hg{k}.pre", y16=f"hg{k}.c3")
+            run(f"hg{k}.conv4", hg + ".conv4", f"hg{k}.c3", y16=f"hg{k}.c4")
+            run(f"hg{k}.conv5", hg + ".conv5", f"hg{k}.c4", y16=f"hg{k}.post", res=presqu)      # relu(conv5 + presqu|pre)
+            run(f"hg{k}.conv6", hg + ".conv6", f"hg{k}.post", y16=f"out{k}", res="cost0")       # out_k = conv6 + cost0
         prev = None
         for k in (1, 2, 3):
-            run16(f"classif{k}.0", f"classif{k}.0", f"out{k}s", y32=f"cls_t{k}")
-            E.conv3d_cout1(t[f"cls_t{k}"], W[f"classif{k}.2"], prev, t[f"costk{k}"])
+            run(f"classif{k}.0", f"classif{k}.0", f"out{k}", y32=f"cls_t{k}")
+            E.conv3d_cout1(t[f"cls_t{k}"], W[f"classif{k}.2"], prev, t[f"costk{k}"])            # cumulative heads
             prev = t[f"costk{k}"]
         return t["costk1"], t["costk2"], t["costk3"]
 

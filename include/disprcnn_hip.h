@@ -360,7 +360,8 @@ int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* p, int mindisp4, void* s
  * chunk q = p*4 + s*2 + g (p = 0 hi / 1 lo), element e of chunk (s, g) = channel 4g + 8(2s + (e>>2)) + (e&3) of the 32-channel block.
  * value = (float)hi + (float)lo, hi = fp16(value) (round to nearest), lo = fp16(value - hi); |value| <= 65504.
  * Weights: drc_s16_pack_weights layout [cout/32][cin/16][27 taps kd*9+kh*3+kw][hi, lo][64 lanes][8 halfs], pre-scaled by 2^wexp
- * (the caller folds 2^-wexp into scale).  cin, cout in {32, 64}; D % 3 == 0, W % 28 == 0, H % 2 == 0 (cin 32). */
+ * (the caller folds 2^-wexp into scale).  cin, cout in {32, 64}; D % 3 == 0; W % 28 == 0 (1x28 MFMA tiles; H even for cin 32), or W = 14 /
+ * W = 7 (2x14 / 4x7 tiles: the hourglass' half- and quarter-resolution maps). */
 typedef struct drc_s16conv_params {
     const void* x;       /* RS16 input [N][cin/32][D+2][H+2][8][W+2][8]; ignored when left/right are given */
     const void* w;       /* packed split weights */
@@ -377,6 +378,18 @@ typedef struct drc_s16conv_params {
 } drc_s16conv_params;
 int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
+/* The hourglass' other 3x3x3 layers in the same arithmetic and layout (x, y16, res: RS16; no blocked fp32 output, no cost-volume form):
+ *   drc_conv3d_k3s2_s16_fwd   -- Conv3d k3 s2 p1 + BN + ReLU (convs16d.hip; reference hourglass conv1 / conv3, stackhourglass.py:9-12,17-19).
+ *                                D, H, W = the INPUT dims (even); y16 has (D/2, H/2, W/2); no residual.
+ *   drc_deconv3d_k3s2_s16_fwd -- ConvTranspose3d k3 s2 p1 output_padding 1 + BN (+ residual, + ReLU) (convs16u.hip; reference hourglass
+ *                                conv5 / conv6, stackhourglass.py:22-30,44-49).  D, H, W = the INPUT dims; y16 and res have (2D, 2H, 2W);
+ *                                cin = 64; weights: drc_s16 packing of the ConvTranspose weight with its first two axes swapped
+ *                                ([Cout, Cin, 3,3,3], tap kd*9+kh*3+kw of o = 2i - 1 + k, no flip).
+ * Shapes: the narrower map of the layer is 7, 14 or a multiple of 28 voxels wide (4x7, 2x14, 1x28 MFMA tiles). */
+int drc_conv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W);
+int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* p, void* stream);
+int drc_deconv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W);
+int drc_deconv3d_k3s2_s16_fwd(const drc_s16conv_params* p, void* stream);
 /* RS16 converters (s16_ops.hip): interior only, the zero halo is the allocator's.  dense = NCDHW fp32 (D = 1, pd = 0 for 2D maps);
  * blocked = the engine's fp32 blocked tensor, channel blocks [cb16_off, cb16_off + C/16) of a tensor with cb16_total blocks and halos
  * (pd_in, ph_in, pw_in).  They stand where the reference hands fp32 NCHW features to the concat loop, stackhourglass.py:112-128. */

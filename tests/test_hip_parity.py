@@ -601,7 +601,7 @@ def test_config_a_vs_golden(dev, case, mx, mn, math):
     cost3 = ws["t"]["costk3"].cpu().reshape(-1)
     idx = torch.from_numpy(z[f"{case}_cost3_idx"]); val = torch.from_numpy(z[f"{case}_cost3_val"])
     assert (cost3[idx] - val).abs().max().item() < 1e-3 * max(1.0, val.abs().max().item())
-    out3 = ws["t"]["out3" if math == "f32" else "out3s"].to_dense().cpu().reshape(-1)
+    out3 = ws["t"]["out3"].to_dense().cpu().reshape(-1)
     idx = torch.from_numpy(z[f"{case}_out3_idx"]); val = torch.from_numpy(z[f"{case}_out3_val"])
     assert (out3[idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4
 

@@ -123,6 +123,72 @@ def test_conv3d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, D, H, W, r
     assert not b.any()
 
 
+def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):
+    """One launch of the kind's kernel against fp64 next to the fp32 chain (torch CPU); D, H, W = the input dims."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, cin, D, H, W, generator=g)
+    if kind == "up":
+        w = torch.randn(cin, cout, 3, 3, 3, generator=g) * (2.0 / (27 * cin / 8)) ** 0.5
+        od = (2 * D, 2 * H, 2 * W)
+    else:
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5
+        od = (D, H, W) if kind == "s1" else (D // 2, H // 2, W // 2)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(N, cout, *od, generator=g) if with_res else None
+
+    def chain(dt):
+        if kind == "up":
+            y = F.conv_transpose3d(x.to(dt), w.to(dt), stride=2, padding=1, output_padding=1)
+        else:
+            y = F.conv3d(x.to(dt), w.to(dt), padding=1, stride=1 if kind == "s1" else 2)
+        y = y * scale.to(dt).view(1, -1, 1, 1, 1) + shift.to(dt).view(1, -1, 1, 1, 1)
+        if with_res:
+            y = y + res.to(dt)
+        return y.clamp_min(0) if relu else y
+    ref = chain(torch.float64)
+    e32 = (chain(torch.float32).double() - ref).abs().max().item()
+    wd = w.to(dev)
+    wp, wexp = s16.pack_weight_s16(wd.transpose(0, 1).contiguous() if kind == "up" else wd)
+    sc = (scale * (2.0 ** -wexp)).to(dev).contiguous()
+    y16 = E.RS16(N, cout, *od, 1, dev)
+    plan = E.ConvPlanS16(N, cin, cout, D, H, W, relu, device=dev, kind=kind)
+    r16 = E.RS16(N, cout, *od, 1, dev).from_dense(res.to(dev)) if with_res else None
+    plan.run(E.RS16(N, cin, D, H, W, 1, dev).from_dense(x.to(dev)), wp, sc, shift.to(dev), y16=y16, res=r16)
+    got = y16.to_dense().cpu()
+    m = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"{plan.kname}: max|err| {err:.3e} (fp32 chain {e32:.3e}), max|ref| {m:.3f}")
+    assert err <= 2e-5 * m + 1e-5
+    assert err <= 2.0 * e32 + 1e-6 * m, (err, e32)
+    v = y16.view7().clone()
+    v[:, :, 1:od[0] + 1, 1:od[1] + 1, :, 1:od[2] + 1] = 0
+    assert not v.any()                   # the halo stays zero
+
+
+@pytest.mark.parametrize("kind,N,cin,cout,D,H,W,relu,with_res", [
+    ("s1", 3, 64, 64, 6, 14, 14, True, True),        # hourglass conv2 (2 x 14 tiles)
+    ("s1", 5, 64, 64, 3, 7, 7, True, False),         # hourglass conv4 (4 x 7 tiles, ragged last row tile)
+    ("s1", 2, 32, 32, 3, 6, 14, False, True),
+    ("s1", 2, 32, 64, 6, 5, 7, True, False),
+    ("s2", 3, 32, 64, 12, 28, 28, True, False),      # hourglass conv1, Config A
+    ("s2", 3, 64, 64, 6, 14, 14, True, False),       # hourglass conv3, Config A (ragged 4 x 7 row tile)
+    ("s2", 2, 64, 64, 12, 28, 28, True, False),      # hourglass conv3, Config B
+    ("s2", 1, 32, 64, 24, 56, 56, True, False),      # hourglass conv1, Config B
+    ("s2", 2, 64, 32, 2, 14, 14, False, False),
+    ("s2", 2, 32, 32, 6, 14, 14, True, False),
+    ("s2", 1, 64, 64, 4, 8, 56, True, False),
+    ("up", 3, 64, 64, 3, 7, 7, True, True),          # hourglass conv5, Config A
+    ("up", 3, 64, 32, 6, 14, 14, False, True),       # hourglass conv6, Config A
+    ("up", 1, 64, 32, 12, 28, 28, False, True),      # hourglass conv6, Config B
+    ("up", 2, 64, 64, 6, 14, 14, True, False),       # hourglass conv5, Config B
+    ("up", 2, 64, 64, 1, 3, 7, False, False),
+    ("up", 2, 64, 32, 2, 5, 56, True, True),
+])
+def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, cout, D, H, W, relu, with_res):
+    _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
+
+
 def test_conv3d_s16_small_activations_keep_an_absolute_error_floor(dev):
     """Activations of 1e-3: the lo parts are subnormal fp16 numbers (absolute resolution 2^-25).  The f16 MFMA does not flush them: the
     error stays ~1e-7 absolute (it would be ~5e-5 relative with flushing)."""
