@@ -59,7 +59,9 @@ constexpr int RING = 3;
 
 // RT rows x WT columns of the map make one 32-voxel MFMA tile: 1 x 28 (full-resolution maps, tiles along x), 2 x 14 and 4 x 7 (the
 // hourglass' half- and quarter-resolution maps: 28 of 32 lanes busy there as well).
-template <int KW, bool CV, int RT = 1, int WT = 28>
+// RES: a residual tensor is added; Y32: the output is the blocked fp32 tensor (cout-1 head's input) instead of RS16.  Template flags, not
+// run-time ones: a step issues exactly the loads / stores it needs (the counted waits depend on the numbers) and no dropped ones.
+template <int KW, bool CV, int RT = 1, int WT = 28, bool RES = false, bool Y32 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convs16_kernel(const drc_s16conv_params p) {
     constexpr int TX = WT;                      // output columns per tile
     constexpr int SX = WT + 2;                  // staged columns (TX + halo)
@@ -71,8 +73,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NL = CBI * 8 * (PV / 64) / 4; // LDS-DMA instructions per wave and slab
     constexpr int OWN = 16 / KW;                // accumulator registers (couts per lane) a wave finishes
     constexpr int XW = 4096;                    // bytes a wave publishes per plane: its 16 accumulator registers
-    constexpr int NR = 2;                       // residual loads per step (hi, lo), always issued
-    constexpr int NS = 4;                       // stores per step (RS16 hi, lo + blocked fp32 x2), always issued (dropped when unused)
+    constexpr int NR = RES ? 2 : 0;             // residual loads per step (hi, lo)
+    constexpr int NS = 2;                       // stores per step (RS16 hi, lo | blocked fp32 x2)
+    static_assert(!(Y32 && (KW != 2 || RES)), "the blocked fp32 output exists for the 32-channel layers without residual");
     static_assert(RT == 1 ? SROWS * SX + 4 <= PV : (SROWS + 1) * SX + 4 <= PV, "slab plane too small (incl. the rows / columns the idle lanes over-read)");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ring = lds;
@@ -137,238 +140,317 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned xcd = blockIdx.x & 7, qx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
 
-    for (unsigned it = 0;; ++it) {
+    // ---- the columns of this workgroup, in order; the pipeline below runs through them WITHOUT draining at a column's end: the first two
+    // steps of a column publish / finalize the last planes of the previous one, the last two stage the first slabs of the next one.
+    struct Col { unsigned n; int y0, x0; bool valid; };
+    auto col_of = [&](unsigned it) __attribute__((always_inline)) {
         const unsigned j = it * per_xcd + qx;
         const unsigned nl = j / cols_unit;
-        const unsigned n = nl * 8 + xcd;
-        if (n >= (unsigned)p.N) break;
         const unsigned rem = j - nl * cols_unit;
         const int yb = (int)(rem / n_xt), xt = (int)(rem - (unsigned)yb * n_xt);
-        const int y0 = yb * RPW * RT, x0 = xt * TX;
-
-        // source bases
-        const char* xcol = CV ? nullptr : (const char*)p.x + (long)n * xnB + (long)y0 * rowB + (long)x0 * 16;
-        const char* lcol = CV ? (const char*)p.left + (long)n * mapnB + (long)y0 * rowB : nullptr;
-        const char* rcol = CV ? (const char*)p.right + (long)n * mapnB + (long)y0 * rowB : nullptr;
-        auto stage = [&](int plane, int slot) __attribute__((always_inline)) {       // logical input plane (clamped) -> ring slot
-            const int pl = plane < D ? plane : D - 1;
-            char* dst = ring + slot * SLAB;
+        Col c;
+        c.n = nl * 8 + xcd;
+        c.valid = c.n < (unsigned)p.N;
+        c.y0 = yb * RPW * RT;
+        c.x0 = xt * TX;
+        return c;
+    };
+    // staging source of a column: the unit's input (CV: its left / right maps) as buffer bases + this lane's byte offsets of its two
+    // staged voxels (h = 0, 1); the plane / channel-block / chunk offset of an instruction is a scalar (soffset)
+    struct Src { const char* a; const char* b; unsigned v0, v1; int x0; };
+    auto src_of = [&](const Col& c) __attribute__((always_inline)) {
+        Src q;
+        if constexpr (CV) {
+            q.a = (const char*)p.left + (long)c.n * mapnB;
+            q.b = (const char*)p.right + (long)c.n * mapnB;
+            q.v0 = (unsigned)((long)(c.y0 + srcrow[0]) * rowB);
+            q.v1 = (unsigned)((long)(c.y0 + srcrow[1]) * rowB);
+        } else {
+            q.a = (const char*)p.x + (long)c.n * xnB;
+            q.b = nullptr;
+            q.v0 = (unsigned)((long)(c.y0 + srcrow[0]) * rowB + (long)(c.x0 + srcx[0]) * 16);
+            q.v1 = (unsigned)((long)(c.y0 + srcrow[1]) * rowB + (long)(c.x0 + srcx[1]) * 16);
+        }
+        q.x0 = c.x0;
+        return q;
+    };
+    auto stage = [&](const Src& q, int pl, int slot) __attribute__((always_inline)) {       // input plane pl of a column -> ring slot
+        char* dst = ring + slot * SLAB;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)q.a, 0, 0x7FFFFF00, 0x00020000);
+        unsigned va[2] = {q.v0, q.v1}, vb[2] = {q.v0, q.v1};
+        if constexpr (CV) {
+            const int ish = p.lo4 + pl;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int id = wave * NL + i;
-                const int cb = id >> 4, c = (id >> 1) & 7, h = id & 1;
-                const char* src;
-                if constexpr (CV) {
-                    const int ish = p.lo4 + pl;
-                    const int xl = x0 + srcx[h] - 1;                                   // logical column
-                    const bool ok = srcok[h] && xl >= 0 && xl < W && xl - ish >= 0 && xl - ish < W;
-                    const int col = ok ? (cb ? x0 + srcx[h] - ish : x0 + srcx[h]) : 0;   // column 0 = the zero halo
-                    src = (cb ? rcol : lcol) + (long)srcrow[h] * rowB + (long)c * (Wp * 16) + (long)col * 16;
-                } else {
-                    src = xcol + (long)cb * xcbB + (long)(pl + 1) * planeB + (long)srcrow[h] * rowB + (long)c * (Wp * 16) + (long)srcx[h] * 16;
-                }
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + (cb * 8 + c) * CPB + h * 1024), 16, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                const int xlog = q.x0 + srcx[h] - 1;                                   // logical column
+                const bool ok = srcok[h] && xlog >= 0 && xlog < W && xlog - ish >= 0 && xlog - ish < W;
+                va[h] += ok ? (unsigned)((q.x0 + srcx[h]) * 16) : 0u;                  // column 0 = the zero halo
+                vb[h] += ok ? (unsigned)((q.x0 + srcx[h] - ish) * 16) : 0u;
             }
-        };
-        // outputs / residual of this unit as buffers (dropped lanes point past the range)
-        const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc(p.y16 ? (void*)((char*)p.y16 + (long)n * ynB) : (void*)p.w, 0, p.y16 ? 0x7FFFFF00 : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t y32r = __builtin_amdgcn_make_buffer_rsrc(p.y32 ? (void*)((char*)p.y32 + (long)n * b_nB) : (void*)p.w, 0, p.y32 ? 0x7FFFFF00 : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(p.res ? (void*)((const char*)p.res + (long)n * ynB) : (void*)p.w, 0, p.res ? 0x7FFFFF00 : 0, 0x00020000);
-        const int yl = y0 + r * RT + rl;                                  // this lane's output row
-        const bool lane_ok = n_ < RT * TX && yl < H;
-        // byte offsets of this lane's output voxel (row yl, column x0 + xl) in plane 0 (padded coordinates + 1)
-        unsigned o16, o32;
+        }
+        const __amdgpu_buffer_rsrc_t rb = CV ? __builtin_amdgcn_make_buffer_rsrc((void*)q.b, 0, 0x7FFFFF00, 0x00020000) : ra;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int id = wave * NL + i;
+            const int cb = id >> 4, c = (id >> 1) & 7, h = id & 1;
+            if constexpr (CV) {
+                const int so = c * (Wp * 16);
+                if (cb) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(dst + (cb * 8 + c) * CPB + h * 1024), 16, vb[h], so, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(dst + (cb * 8 + c) * CPB + h * 1024), 16, va[h], so, 0, 0);
+            } else {
+                const int so = (int)((long)cb * xcbB + (long)(pl + 1) * planeB + (long)c * (Wp * 16));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(dst + (cb * 8 + c) * CPB + h * 1024), 16, va[h], so, 0, 0);
+            }
+        }
+    };
+    // output context of a column: unit bases + this lane's voxel offsets (plane 0, padded coordinates + 1)
+    struct Ctx { char* y16b; char* y32b; const char* resb; unsigned o16, o32; bool ok; };
+    auto ctx_of = [&](const Col& c) __attribute__((always_inline)) {
+        Ctx q;
+        q.y16b = p.y16 ? (char*)p.y16 + (long)c.n * ynB : (char*)p.w;
+        q.y32b = p.y32 ? (char*)p.y32 + (long)c.n * b_nB : (char*)p.w;
+        q.resb = p.res ? (const char*)p.res + (long)c.n * ynB : (const char*)p.w;
+        const int yl = c.y0 + r * RT + rl;                                  // this lane's output row
+        q.ok = n_ < RT * TX && yl < H;
         if constexpr (KW == 2) {
             // own registers 8k..8k+7 = chunk (s = k, g) complete: 16 B hi at chunk k*2+g, lo at 4 + k*2 + g
-            o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)(k * 2 + g) * (Wp * 16) + (long)(x0 + xl + 1) * 16);
+            q.o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)(k * 2 + g) * (Wp * 16) + (long)(c.x0 + xl + 1) * 16);
             // blocked fp32: block 2ct + k, channels 4g..4g+3 and 8+4g..
-            o32 = (unsigned)((long)(2 * ct + k) * b_cbB + b_planeB + (long)(yl + 1) * b_rowB + (long)(x0 + xl + 1) * 64 + g * 16);
+            q.o32 = (unsigned)((long)(2 * ct + k) * b_cbB + b_planeB + (long)(yl + 1) * b_rowB + (long)(c.x0 + xl + 1) * 64 + g * 16);
         } else {
             // own registers 4k..4k+3 = couts 8k + 4g + e: half a chunk: chunk (s = k>>1, g), bytes (k&1)*8..
-            o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)((k >> 1) * 2 + g) * (Wp * 16) + (long)(x0 + xl + 1) * 16 + (k & 1) * 8);
-            o32 = (unsigned)((long)(2 * ct + (k >> 1)) * b_cbB + b_planeB + (long)(yl + 1) * b_rowB + (long)(x0 + xl + 1) * 64 + (k & 1) * 32 + g * 16);
+            q.o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)((k >> 1) * 2 + g) * (Wp * 16) + (long)(c.x0 + xl + 1) * 16 + (k & 1) * 8);
+            q.o32 = (unsigned)((long)(2 * ct + (k >> 1)) * b_cbB + b_planeB + (long)(yl + 1) * b_rowB + (long)(c.x0 + xl + 1) * 64 + (k & 1) * 32 + g * 16);
         }
-        const unsigned lo_off = (unsigned)(4 * Wp * 16);
-        const float relu_lo = p.relu ? 0.f : -3.0e38f;
+        return q;
+    };
+    const unsigned lo_off = (unsigned)(4 * Wp * 16);
+    const float relu_lo = p.relu ? 0.f : -65504.f;
+    const unsigned n16 = p.y16 ? 0x7FFFFF00u : 0u, n32 = p.y32 ? 0x7FFFFF00u : 0u, nres = p.res ? 0x7FFFFF00u : 0u;
 
-        f32x16 acc[3];
-        u32x4 resv[2];           // residual (hi, lo) of the plane finalized next step (KW == 4: low 8 bytes used)
+    Col ccur = col_of(0);
+    if (!ccur.valid) return;
+    Src s_cur = src_of(ccur), s_next = s_cur;
+    Ctx cx_cur = ctx_of(ccur), cx_prev = cx_cur;
+    cx_prev.ok = false;
 
-        // every wave is done with the previous column's slots and exchange buffers
+    f32x16 acc[3];
+    u32x4 resv[2];           // residual (hi, lo) of the plane finalized next step (KW == 4: low 8 bytes used)
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a_][e] = 0.f;
+    resv[0] = resv[1] = (u32x4){0u, 0u, 0u, 0u};
+    stage(s_cur, 0, 0);
+    stage(s_cur, 1 < D ? 1 : 0, 1);
+    __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));      // plane 0 landed (step 0's own wait assumes a full previous step)
+    unsigned gs = 0;                                       // steps so far: parity of the exchange buffer
+
+    // one step of the pipeline.  KIND 0: input plane t of the current column into the accumulators of output planes t-1, t, t+1;
+    // 1: t = 0 (no plane t-1: those taps are skipped); 2: t = D-1 (no plane t+1); 3: drain, no input plane (t = D, D+1 after the last column).
+    // Every step publishes output plane t-1 (t = 0: the previous column's plane D-1) and finalizes plane t-2 (t < 2: the previous column's
+    // D-2+t).  Straight-line code (no branch between the barrier and the publish): the finalize is spread over the tap groups, so its
+    // VALU / LDS / store instructions issue in the shadow of the MFMAs.
+    auto step = [&](int t, auto JT, auto KT) __attribute__((always_inline)) {
+        constexpr int J = decltype(JT)::value;              // t mod 3 (D % 3 == 0: continuous across columns)
+        constexpr int KIND = decltype(KT)::value;
+        constexpr bool COMPUTE = KIND != 3;
+        constexpr int A0 = (J + 1) % 3, A1 = J, A2 = (J + 2) % 3;    // accumulators of output planes t+1 (kd 0), t (kd 1), t-1 (kd 2)
+        // slab t landed (everything but the previous step's requests may be waited for: vmcnt retires in order); lgkmcnt: my exchange
+        // writes are visible before the barrier
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(S16_WAITCNT(63, 0));
+        __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL + NS + NR, 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        stage(0, 0);
-        stage(1, 1);
-        __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));      // plane 0 landed (step 0's own wait assumes a full previous step)
+        {   // slab t+2 (of the next column behind this one's last plane) into the slot of plane t-1: free since the barrier
+            const int tp = t + 2;
+            const bool nxt = tp >= D;
+            Src q;
+            q.a = nxt ? s_next.a : s_cur.a;
+            q.b = nxt ? s_next.b : s_cur.b;
+            q.x0 = nxt ? s_next.x0 : s_cur.x0;
+            q.v0 = nxt ? s_next.v0 : s_cur.v0;
+            q.v1 = nxt ? s_next.v1 : s_cur.v1;
+            int pl = nxt ? tp - D : tp;
+            pl = pl < D ? pl : D - 1;
+            stage(q, pl, (J + 2) % 3);
+        }
+        // contexts of the planes finalized / published in this step
+        const bool fcur = t >= 2, pcur = t >= 1;
+        const int qf = fcur ? t - 2 : D - 2 + t, qp = pcur ? t - 1 : D - 1;
+        const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc(fcur ? cx_cur.y16b : cx_prev.y16b, 0, n16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t y32r = __builtin_amdgcn_make_buffer_rsrc(fcur ? cx_cur.y32b : cx_prev.y32b, 0, n32, 0x00020000);
+        const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc((void*)(pcur ? cx_cur.resb : cx_prev.resb), 0, nres, 0x00020000);
+        const unsigned f_o16 = fcur ? cx_cur.o16 : cx_prev.o16, f_o32 = fcur ? cx_cur.o32 : cx_prev.o32;
+        const bool f_ok = (fcur ? cx_cur.ok : cx_prev.ok) && qf >= 0 && qf < D;
+        const unsigned p_o16 = pcur ? cx_cur.o16 : cx_prev.o16;
+        const bool p_ok = (pcur ? cx_cur.ok : cx_prev.ok) && qp >= 0 && qp < D;
+        // the K-split partial sums of the plane to finalize (published in the previous step), this wave's couts: registers k*OWN .. of
+        // every K slice
+        f32x4 part[4];
+        {
+            const char* xb = xchg + ((gs - 1) & 1) * (4 * XW) + (r * KW) * XW + lane * 16;
+            if constexpr (KW == 2) {
+                part[0] = *(const f32x4*)(xb + (k * 2) * 1024);
+                part[1] = *(const f32x4*)(xb + XW + (k * 2) * 1024);
+                part[2] = *(const f32x4*)(xb + (k * 2 + 1) * 1024);
+                part[3] = *(const f32x4*)(xb + XW + (k * 2 + 1) * 1024);
+            } else {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
-        resv[0] = resv[1] = (u32x4){0u, 0u, 0u, 0u};
-
-        // one step: input plane t (COMPUTE) -> accumulators of output planes t-1, t, t+1; publish plane t-1; finalize plane t-2.
-        // Straight-line code (no branch between the barrier and the publish): the finalize of plane t-2 is spread over the tap groups, so its
-        // VALU / LDS / store instructions issue in the shadow of the MFMAs.
-        auto step = [&](int t, auto JT, auto CT_) __attribute__((always_inline)) {
-            constexpr int J = decltype(JT)::value;              // t mod 3
-            constexpr bool COMPUTE = decltype(CT_)::value;
-            constexpr int A0 = (J + 1) % 3, A1 = J, A2 = (J + 2) % 3;    // accumulators of output planes t+1 (kd 0), t (kd 1), t-1 (kd 2)
-            // slab t landed (everything but the previous step's requests may be waited for: vmcnt retires in order); lgkmcnt: my exchange
-            // writes are visible before the barrier
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL + NS + NR, 0));
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stage(t + 2, (J + 2) % 3);                           // slot of plane t-1: free since the barrier
-            // the K-split partial sums of plane t-2 (published in step t-1), this wave's couts: registers k*OWN .. of every K slice
-            f32x4 part[4];
-            {
-                const char* xb = xchg + ((t - 1) & 1) * (4 * XW) + (r * KW) * XW + lane * 16;
-                if constexpr (KW == 2) {
-                    part[0] = *(const f32x4*)(xb + (k * 2) * 1024);
-                    part[1] = *(const f32x4*)(xb + XW + (k * 2) * 1024);
-                    part[2] = *(const f32x4*)(xb + (k * 2 + 1) * 1024);
-                    part[3] = *(const f32x4*)(xb + XW + (k * 2 + 1) * 1024);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) part[q] = *(const f32x4*)(xb + q * XW + k * 1024);
-                }
+                for (int q = 0; q < 4; ++q) part[q] = *(const f32x4*)(xb + q * XW + k * 1024);
             }
-            // the residual of plane t-2 was requested at the end of step t-1; only this step's DMAs are younger
-            __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));
-            __builtin_amdgcn_sched_barrier(0);
-            float v[OWN];
-            _Float16 vh[OWN], vl[OWN];
-            auto fin = [&](int e) __attribute__((always_inline)) {
-                float s_;
-                if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
-                else s_ = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-                float x_ = s_ * sc[e] + sh[e];
-                _Float16 rh, rl;
-                if constexpr (KW == 2) { rh = __builtin_bit_cast(f16x8, resv[0])[e]; rl = __builtin_bit_cast(f16x8, resv[1])[e]; }
-                else { rh = __builtin_bit_cast(f16x8, resv[0])[e]; rl = __builtin_bit_cast(f16x8, resv[1])[e]; }
-                x_ += (float)rh + (float)rl;
-                x_ = fminf(fmaxf(x_, relu_lo), 65504.f);            // (fp16 range of the hi part; relu_lo = -3e38 without ReLU, then the
-                x_ = fmaxf(x_, -65504.f);                              //  lower clamp applies)
-                v[e] = x_;
-                vh[e] = (_Float16)x_;
-                vl[e] = (_Float16)(x_ - (float)vh[e]);
-            };
-            auto stores = [&]() __attribute__((always_inline)) {
-                const int q_ = t - 2;
-                const bool ok = lane_ok && q_ >= 0;
-                const unsigned po = ok ? (unsigned)((long)q_ * planeB) : 0x80000000u;
-                const unsigned po32 = ok ? (unsigned)((long)q_ * b_planeB) : 0x80000000u;
+        }
+        // its residual was requested at the end of the previous step; only this step's DMAs are younger
+        __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));
+        __builtin_amdgcn_sched_barrier(0);
+        float v[OWN];
+        _Float16 vh[OWN], vl[OWN];
+        auto fin = [&](int e) __attribute__((always_inline)) {
+            float s_;
+            if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
+            else s_ = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+            float x_ = s_ * sc[e] + sh[e];
+            if constexpr (RES) {
+                const _Float16 rh = __builtin_bit_cast(f16x8, resv[0])[e], rl_ = __builtin_bit_cast(f16x8, resv[1])[e];
+                x_ += (float)rh + (float)rl_;
+            }
+            x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);    // ReLU (relu_lo = 0) or the fp16 range of the hi part (relu_lo = -65504)
+            v[e] = x_;
+            vh[e] = (_Float16)x_;
+            vl[e] = (_Float16)(x_ - (float)vh[e]);
+        };
+        auto stores = [&]() __attribute__((always_inline)) {
+            if constexpr (Y32) {
+                const unsigned po32 = f_ok ? (unsigned)((long)qf * b_planeB) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), y32r, f_o32 + po32, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), y32r, f_o32 + 32 + po32, 0, 0);
+            } else {
+                const unsigned po = f_ok ? (unsigned)((long)qf * planeB) : 0x80000000u;
                 if constexpr (KW == 2) {
                     f16x8 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { hi[e] = vh[e]; lo[e] = vl[e]; }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), y16r, o16 + po, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), y16r, o16 + lo_off + po, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), y32r, o32 + po32, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), y32r, o32 + 32 + po32, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), y16r, f_o16 + po, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), y16r, f_o16 + lo_off + po, 0, 0);
                 } else {
                     f16x4 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { hi[e] = vh[e]; lo[e] = vl[e]; }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), y16r, o16 + po, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), y16r, o16 + lo_off + po, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), y32r, o32 + po32, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), y32r, 0x80000000u, 0, 0);   // (count)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), y16r, f_o16 + po, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), y16r, f_o16 + lo_off + po, 0, 0);
                 }
-            };
-            // plane t-1 complete: publish the accumulator (every K slice publishes all 16 registers; the finisher of a cout group sums
-            // the slices in a fixed order), clear it for plane t+2, request the residual
-            auto publish = [&]() __attribute__((always_inline)) {
-                const f32x16 a = acc[A2];
-                char* xb = xchg + (t & 1) * (4 * XW) + wave * XW + lane * 16;
+            }
+        };
+        // output plane t-1 complete: publish the accumulator (every K slice publishes all 16 registers; the finisher of a cout group sums
+        // the slices in a fixed order), clear it, request the residual
+        auto publish = [&]() __attribute__((always_inline)) {
+            const f32x16 a = acc[A2];
+            char* xb = xchg + (gs & 1) * (4 * XW) + wave * XW + lane * 16;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *(f32x4*)(xb + q * 1024) = (f32x4){a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+            for (int q = 0; q < 4; ++q) *(f32x4*)(xb + q * 1024) = (f32x4){a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[A2][e] = 0.f;
-                const int q_ = t - 1;
-                const bool ok = lane_ok && q_ >= 0 && q_ < D;
-                const unsigned po = ok ? (unsigned)((long)q_ * planeB) : 0x80000000u;
+            for (int e = 0; e < 16; ++e) acc[A2][e] = 0.f;
+            if constexpr (RES) {
+                const unsigned po = p_ok ? (unsigned)((long)qp * planeB) : 0x80000000u;
                 if constexpr (KW == 2) {
-                    resv[0] = __builtin_amdgcn_raw_buffer_load_b128(resr, o16 + po, 0, 0);
-                    resv[1] = __builtin_amdgcn_raw_buffer_load_b128(resr, o16 + lo_off + po, 0, 0);
+                    resv[0] = __builtin_amdgcn_raw_buffer_load_b128(resr, p_o16 + po, 0, 0);
+                    resv[1] = __builtin_amdgcn_raw_buffer_load_b128(resr, p_o16 + lo_off + po, 0, 0);
                 } else {
-                    const u32x2 a_ = __builtin_amdgcn_raw_buffer_load_b64(resr, o16 + po, 0, 0);
-                    const u32x2 b_ = __builtin_amdgcn_raw_buffer_load_b64(resr, o16 + lo_off + po, 0, 0);
+                    const u32x2 a_ = __builtin_amdgcn_raw_buffer_load_b64(resr, p_o16 + po, 0, 0);
+                    const u32x2 b_ = __builtin_amdgcn_raw_buffer_load_b64(resr, p_o16 + lo_off + po, 0, 0);
                     resv[0] = (u32x4){a_.x, a_.y, 0u, 0u};
                     resv[1] = (u32x4){b_.x, b_.y, 0u, 0u};
                 }
-            };
-            if constexpr (COMPUTE) {
-                const __attribute__((address_space(3))) char* sb = ringl + J * SLAB + bfrag;
-                f16x8 bh[2], bl[2];
-                bh[0] = *(lds_frag*)(sb);
-                bl[0] = *(lds_frag*)(sb + 4 * CPB);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    const int kh = q / 3, kw = q - kh * 3;
-                    if (q + 1 < 9) {
-                        const int kh1 = (q + 1) / 3, kw1 = (q + 1) - kh1 * 3;
-                        bh[(q + 1) & 1] = *(lds_frag*)(sb + (kh1 * SX + kw1) * 16);
-                        bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + (kh1 * SX + kw1) * 16);
-                    }
-                    const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
-                    const int t0 = kh * 3 + kw, t1 = 9 + t0, t2 = 18 + t0;       // taps kd = 0, 1, 2
-                    if (q < 8) {
-                        acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
-                        acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
-                        acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], h_, acc[A2], 0, 0, 0);
-                        acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], l_, acc[A0], 0, 0, 0);
-                        acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], l_, acc[A1], 0, 0, 0);
-                        acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], l_, acc[A2], 0, 0, 0);
-                        acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t0], h_, acc[A0], 0, 0, 0);
-                        acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A1], 0, 0, 0);
-                        acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A2], 0, 0, 0);
-                        if (q < OWN) fin(q);
-                        if (q == OWN) stores();
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        // last group: the finished plane's accumulator first, its publication in the shadow of the rest
-                        if (q == OWN) stores();
-                        acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], h_, acc[A2], 0, 0, 0);
-                        acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
-                        acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], l_, acc[A2], 0, 0, 0);
-                        acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
-                        acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A2], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], l_, acc[A0], 0, 0, 0);
-                        acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], l_, acc[A1], 0, 0, 0);
-                        acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t0], h_, acc[A0], 0, 0, 0);
-                        acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A1], 0, 0, 0);
-                        publish();
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < OWN; ++e) fin(e);
-                stores();
-                publish();
             }
         };
-
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-#pragma unroll 1
-        for (int t0 = 0; t0 < D; t0 += 3) {
-            step(t0, I0{}, std::true_type{});
-            step(t0 + 1, I1{}, std::true_type{});
-            step(t0 + 2, I2{}, std::true_type{});
+        if constexpr (COMPUTE) {
+            constexpr bool K0 = KIND != 2, K2 = KIND != 1;          // taps kd = 0 (plane t+1 exists), kd = 2 (plane t-1 exists)
+            const __attribute__((address_space(3))) char* sb = ringl + J * SLAB + bfrag;
+            f16x8 bh[2], bl[2];
+            bh[0] = *(lds_frag*)(sb);
+            bl[0] = *(lds_frag*)(sb + 4 * CPB);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int kh = q / 3, kw = q - kh * 3;
+                if (q + 1 < 9) {
+                    const int kh1 = (q + 1) / 3, kw1 = (q + 1) - kh1 * 3;
+                    bh[(q + 1) & 1] = *(lds_frag*)(sb + (kh1 * SX + kw1) * 16);
+                    bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + (kh1 * SX + kw1) * 16);
+                }
+                const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
+                const int t0 = kh * 3 + kw, t1 = 9 + t0, t2 = 18 + t0;       // taps kd = 0, 1, 2
+                if (q == OWN) stores();
+                if (q < 8) {
+                    if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
+                    acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
+                    if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], h_, acc[A2], 0, 0, 0);
+                    if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], l_, acc[A0], 0, 0, 0);
+                    acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], l_, acc[A1], 0, 0, 0);
+                    if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], l_, acc[A2], 0, 0, 0);
+                    if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t0], h_, acc[A0], 0, 0, 0);
+                    acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A1], 0, 0, 0);
+                    if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A2], 0, 0, 0);
+                    if (q < OWN) fin(q);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    // last group: the finished plane's accumulator first, its publication in the shadow of the rest
+                    if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], h_, acc[A2], 0, 0, 0);
+                    if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
+                    if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], l_, acc[A2], 0, 0, 0);
+                    acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
+                    if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A2], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], l_, acc[A0], 0, 0, 0);
+                    acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], l_, acc[A1], 0, 0, 0);
+                    if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t0], h_, acc[A0], 0, 0, 0);
+                    acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A1], 0, 0, 0);
+                    publish();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < OWN; ++e) fin(e);
+            stores();
+            publish();
         }
-        step(D, I0{}, std::false_type{});
-        step(D + 1, I1{}, std::false_type{});
+        ++gs;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+#pragma unroll 1
+    for (unsigned it = 0;; ++it) {
+        const Col cnext = col_of(it + 1);
+        s_next = cnext.valid ? src_of(cnext) : s_cur;
+        step(0, I0{}, I1{});
+        step(1, I1{}, I0{});
+        if (D == 3) {
+            step(2, I2{}, I2{});
+        } else {
+            step(2, I2{}, I0{});
+#pragma unroll 1
+            for (int t0 = 3; t0 + 3 < D; t0 += 3) {
+                step(t0, I0{}, I0{});
+                step(t0 + 1, I1{}, I0{});
+                step(t0 + 2, I2{}, I0{});
+            }
+            step(D - 3, I0{}, I0{});
+            step(D - 2, I1{}, I0{});
+            step(D - 1, I2{}, I2{});
+        }
+        if (!cnext.valid) break;
+        cx_prev = cx_cur;
+        cx_cur = ctx_of(cnext);
+        s_cur = s_next;
     }
+    // drain: publish the last plane, finalize the last two
+    step(D, I0{}, I3{});
+    step(D + 1, I1{}, I3{});
 }
 
-template <int KW, bool CV, int RT = 1, int WT = 28>
-int launch(const drc_s16conv_params& p, hipStream_t stream) {
+template <int KW, bool CV, int RT, int WT, bool RES, bool Y32>
+int launch2(const drc_s16conv_params& p, hipStream_t stream) {
     constexpr int CBI = KW / 2;
     constexpr int SLAB = CBI * 8 * CPB;
     constexpr int XW = 4096;
@@ -376,7 +458,7 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)convs16_kernel<KW, CV, RT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)convs16_kernel<KW, CV, RT, WT, RES, Y32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     constexpr int rows = (4 / KW) * RT;
@@ -384,8 +466,18 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
     // one block per CU (the weights take the register file); a multiple of 8 so that every XCD runs the same number
     long blocks = 256;
     while (blocks > 8 && blocks / 2 >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT, RES, Y32>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
+}
+
+template <int KW, bool CV, int RT = 1, int WT = 28>
+int launch(const drc_s16conv_params& p, hipStream_t stream) {
+    if (p.y32) {
+        if constexpr (KW == 2 && !CV && RT == 1) return launch2<KW, CV, RT, WT, false, true>(p, stream);
+        else return -4;
+    }
+    if constexpr (CV) return launch2<KW, CV, RT, WT, false, false>(p, stream);
+    else return p.res ? launch2<KW, CV, RT, WT, true, false>(p, stream) : launch2<KW, CV, RT, WT, false, false>(p, stream);
 }
 
 }  // namespace
@@ -405,7 +497,9 @@ extern "C" int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* pp, void* stream)
     if (!pp) return -1;
     const drc_s16conv_params& p = *pp;
     const bool cv = p.left || p.right;
-    if (!p.w || !p.scale || !p.shift || (!p.y16 && !p.y32)) return -1;
+    if (!p.w || !p.scale || !p.shift || (!p.y16 == !p.y32)) return -1;          // exactly one output
+    if (p.y32 && (p.res || p.cin != 32 || p.W % 28)) return -4;                     // blocked fp32 output: the 32-channel full-resolution layers without residual
+    if (cv && p.res) return -4;
     if (cv ? (!p.left || !p.right || p.cin != 64) : !p.x) return -1;
     if (p.N < 0) return -2;
     if (!drc_conv3d_k3_s16_supported(p.cin, p.cout, p.D, p.H, p.W)) return -4;

@@ -368,8 +368,9 @@ typedef struct drc_s16conv_params {
     const float* scale;  /* [cout] folded BN scale * 2^-wexp */
     const float* shift;  /* [cout] folded BN shift */
     const void* res;     /* optional RS16 residual, geometry of y16 (may be NULL) */
-    void* y16;           /* RS16 output [N][cout/32][D+2][H+2][8][W+2][8] (may be NULL) */
-    float* y32;          /* blocked fp32 output float[N][cout/16][D+2][H+2][W+2][16] (may be NULL); at least one output */
+    void* y16;           /* RS16 output [N][cout/32][D+2][H+2][8][W+2][8], or NULL when y32 is given */
+    float* y32;          /* blocked fp32 output float[N][cout/16][D+2][H+2][W+2][16] INSTEAD of y16 (cin = 32, W % 28 == 0, no residual:
+                            the cout-1 head's input); exactly one of y16 / y32 */
     const void* left;    /* cost-volume variant (cin = 64): RS16 2D maps [N][1][H+2][8][W+2][8] */
     const void* right;
     int32_t N, D, H, W;

@@ -100,27 +100,34 @@ def test_conv3d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, D, H, W, r
     wp, wexp = s16.pack_weight_s16(w.to(dev))
     sc = (scale * (2.0 ** -wexp)).to(dev).contiguous()
     y16 = E.RS16(N, cout, D, H, W, 1, dev)
-    y32 = E.Blocked(N, cout, D, H, W, 1, 1, 1, dev)
     plan = E.ConvPlanS16(N, cin, cout, D, H, W, relu, cv=cv, device=dev)
     r16 = E.RS16(N, cout, D, H, W, 1, dev).from_dense(res.to(dev)) if with_res else None
+    outs = []
     if cv:
-        plan.run(None, wp, sc, shift.to(dev), y16=y16, y32=y32, res=r16, left=E.RS16(N, 32, 1, H, W, 0, dev).from_dense(L.to(dev)),
+        plan.run(None, wp, sc, shift.to(dev), y16=y16, res=r16, left=E.RS16(N, 32, 1, H, W, 0, dev).from_dense(L.to(dev)),
                  right=E.RS16(N, 32, 1, H, W, 0, dev).from_dense(R.to(dev)), lo4=lo4)
     else:
-        plan.run(E.RS16(N, cin, D, H, W, 1, dev).from_dense(x.to(dev)), wp, sc, shift.to(dev), y16=y16, y32=y32, res=r16)
+        x16 = E.RS16(N, cin, D, H, W, 1, dev).from_dense(x.to(dev))
+        plan.run(x16, wp, sc, shift.to(dev), y16=y16, res=r16)
+        if cin == 32 and not with_res and W % 28 == 0:
+            # the blocked fp32 output form (the cout-1 head's input): instead of RS16
+            y32 = E.Blocked(N, cout, D, H, W, 1, 1, 1, dev)
+            plan.run(x16, wp, sc, shift.to(dev), y32=y32)
+            outs.append(("blocked fp32", y32.to_dense().cpu()))
+            b = y32.view6().clone()
+            b[:, :, 1:D + 1, 1:H + 1, 1:W + 1] = 0
+            assert not b.any()
+    outs.append(("RS16", y16.to_dense().cpu()))
     m = ref.abs().max().item()
-    for name, got in (("RS16", y16.to_dense().cpu()), ("blocked fp32", y32.to_dense().cpu())):
+    for name, got in outs:
         err = (got.double() - ref).abs().max().item()
         print(f"{name}: max|err| {err:.3e} (fp32 chain {e32:.3e}), max|ref| {m:.3f}")
         assert err <= 2e-5 * m + 1e-5
         assert err <= 2.0 * e32 + 1e-6 * m, (err, e32)
-    # the halo stays zero in both outputs
+    # the halo stays zero
     v = y16.view7().clone()
     v[:, :, 1:D + 1, 1:H + 1, :, 1:W + 1] = 0
     assert not v.any()
-    b = y32.view6().clone()
-    b[:, :, 1:D + 1, 1:H + 1, 1:W + 1] = 0
-    assert not b.any()
 
 
 def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):

@@ -70,16 +70,20 @@ def one_case(dev, N, cin, cout, D, H, W, relu, with_res, cv=False, lo4=0, in_sca
     y16 = torch.zeros(N, cout // 32, D + 2, H + 2, 8, W + 2, 8, dtype=torch.float16, device=dev)
     yb = E.Blocked(N, cout, D, H, W, 1, 1, 1, dev)
     r16 = s16.rs16_from_dense(res.to(dev)) if with_res else None
+    b = 0.0
     if cv:
         l16 = s16.rs16_from_dense(L.to(dev))
         r_16 = s16.rs16_from_dense(R.to(dev))
-        s16.conv3d_k3(None, wp, sc, sh, D, H, W, cin, cout, relu, y16=y16, y32=yb.storage, res=r16, left=l16, right=r_16, lo4=lo4)
+        s16.conv3d_k3(None, wp, sc, sh, D, H, W, cin, cout, relu, y16=y16, res=r16, left=l16, right=r_16, lo4=lo4)
     else:
         x16 = s16.rs16_from_dense(x.to(dev))
-        s16.conv3d_k3(x16, wp, sc, sh, D, H, W, cin, cout, relu, y16=y16, y32=yb.storage, res=r16)
+        s16.conv3d_k3(x16, wp, sc, sh, D, H, W, cin, cout, relu, y16=y16, res=r16)
+        if cin == 32 and not with_res and W % 28 == 0:
+            s16.conv3d_k3(x16, wp, sc, sh, D, H, W, cin, cout, relu, y32=yb.storage)
+            torch.cuda.synchronize()
+            b = stats("split-f16 kernel, blocked fp32 out", yb.to_dense().cpu(), ref)
     torch.cuda.synchronize()
     a = stats("split-f16 kernel, RS16 output", s16.rs16_to_dense(y16).cpu(), ref)
-    b = stats("split-f16 kernel, blocked fp32 out", yb.to_dense().cpu(), ref)
     halo = y16.clone()
     halo[:, :, 1:D + 1, 1:H + 1, :, 1:W + 1] = 0
     print(f"  halo untouched: {bool((halo == 0).all())}; wexp {wexp}", flush=True)
@@ -147,7 +151,6 @@ def main():
     timing(dev, N, 32, 32, 12, 28, 28)
     timing(dev, N, 32, 32, 12, 28, 28, res=True)
     timing(dev, N, 32, 32, 12, 28, 28, y32=True, y16=False)
-    timing(dev, N, 32, 32, 12, 28, 28, y32=True, y16=True)
     timing(dev, N, 64, 32, 12, 28, 28)
     timing(dev, N, 64, 32, 12, 28, 28, cv=True)
     timing(dev, 16, 32, 32, 12, 28, 28)
