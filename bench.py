@@ -279,13 +279,21 @@ def main():
 
     # ---- extras.  The train step is the only one with a collective (one flat gradient all-reduce): EVERY rank enters it.
     # The others have none and run on rank 0 at world size 1 only (the scaling runs stay short; their numbers do not depend on N).
+    if rank == 0:
+        extra["world"] = world_info(dev, world)
     if not args.no_extra:
         try:
             tr = train_step_extra(dev, model, world)
             if rank == 0:
                 extra["train_step"] = tr
-        except Exception as ex:  # report, never hide -- but every rank must leave through the same door
+        except Exception as ex:  # report, never hide (the step itself agrees on an ok flag before its collective: no rank is left behind)
             extra["train_step"] = {"error": repr(ex)}
+        try:
+            si = sharded_inference_extra(dev, world)      # the product's inference loop: shard -> DispRCNN3D -> tensor gather (every rank)
+            if rank == 0:
+                extra["sharded_inference"] = si
+        except Exception as ex:
+            extra["sharded_inference"] = {"error": repr(ex)}
         if rank == 0 and world == 1:
             try:
                 rank0_extras(dev, extra)
@@ -303,6 +311,59 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def world_info(dev, world):
+    """What the driver's scaling run can check: ranks, the device of rank 0, the collective library behind backend "nccl"."""
+    info = {"ranks": world, "device": torch.cuda.get_device_name(dev), "backend": "nccl (RCCL)" if world > 1 else "none (single rank)"}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as ex:          # noqa: BLE001
+        info["rccl_version"] = repr(ex)[:80]
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, torch.cuda.get_device_name(dev))
+        info["devices"] = names
+    return info
+
+
+def sharded_inference_extra(dev, world):
+    """disprcnn_amd.utils.comm.sharded_inference on every rank: 4 synthetic KITTI-sized images x 16 ROIs per rank, DispRCNN3D (device-side
+    pairing + ROIAlign crops + PSMNet 224^2, D=96) on this rank's shard, then ONE tensor gather of the [R,224,224] disparities on rank 0
+    (reference: engine/inference.py:53-72 pickles them).  Reports the gather time next to the compute time."""
+    from disprcnn_amd.modeling.detector.disprcnn3d import DispRCNN3D, default_cfg
+    from disprcnn_amd.structures import BoxList, ImageList
+    from disprcnn_amd.utils import synth
+    from disprcnn_amd.utils.comm import sharded_inference
+    mB, _ = build_model(dev, 48, -48, "B")
+    det = DispRCNN3D(default_cfg(48, -48, 224))
+    det.dispnet = mB
+    det = det.to(dev).eval()
+    Wi, Hi, per_rank, nroi = 1242, 375, 4, 16
+    samples = []
+    for i in range(per_rank * world):
+        pair = synth.hash_uniform(f"shard:{i}", (2, 3, Hi, Wi), 0.0, 1.0).to(dev)
+        u = synth.hash_uniform(f"shardboxes:{i}", (nroi, 4), 0.0, 1.0)
+        x1 = 20 + u[:, 0] * (Wi - 400); y1 = 10 + u[:, 1] * (Hi - 240)
+        lb = torch.stack([x1, y1, x1 + 40 + u[:, 2] * 260, y1 + 30 + u[:, 3] * 170], 1)
+        rb = lb.clone(); rb[:, [0, 2]] -= 2 + 78 * u[:, 0:1]
+        rb[:, [0, 2]] = rb[:, [0, 2]].clamp(min=0)
+        bl, br = BoxList(lb.to(dev), (Wi, Hi)), BoxList(rb.to(dev), (Wi, Hi))
+        for b in (bl, br):
+            b.add_field("scores", torch.ones(nroi, device=dev)); b.add_field("labels", torch.ones(nroi, dtype=torch.int64, device=dev))
+        samples.append((i, {"left": ImageList(pair[:1], [(Hi, Wi)]), "right": ImageList(pair[1:], [(Hi, Wi)])}, {"left": [bl], "right": [br]}))
+    sharded_inference(det, samples)                   # warm-up (plans, workspaces)
+    timing = {}
+    got = sharded_inference(det, samples, timing=timing)
+    out = {"images": len(samples), "images_per_rank": per_rank, "rois_per_image": nroi,
+           "compute_ms_rank0": round(timing["compute_s"] * 1e3, 2), "gather_ms_rank0": round(timing["gather_s"] * 1e3, 3),
+           "gathered_bytes": int(len(samples) * nroi * 224 * 224 * 4),
+           "workload": "comm.sharded_inference: shard_range -> DispRCNN3D per image (no collective) -> gather_predictions (tensor all_gather)"}
+    if got is not None:
+        out["gathered_images"] = len(got)
+        out["disparity_shape"] = list(got[0].get_field("disparity").shape)
+    del det, mB
+    return out
 
 
 def _time(fn, warm, reps):
@@ -324,7 +385,7 @@ def train_step_extra(dev, model_a, world):
     the all-reduce time is measured with events around the sync."""
     from disprcnn_amd.utils import synth
     from disprcnn_amd.utils.loss_utils import PSMLoss
-    from disprcnn_amd.utils.comm import GradientSync
+    from disprcnn_amd.utils.comm import GradientSync, all_ranks_ok
     mB, _ = build_model(dev, 48, -48, "B")
     tr = {}
     for tag, mdl, nroi in (("config_a_from_features_64roi", model_a, 64), ("config_b_full_psmnet_8roi", mB, 8)):
@@ -347,16 +408,31 @@ def train_step_extra(dev, model_a, world):
         opt = torch.optim.SGD(mdl.parameters(), lr=1e-7, momentum=0.9)   # the parameters change every step: weights are re-packed
         sync_ms = []
 
+        failed = []
+
         def train_step():
-            sync.zero_grad()                     # .grad = zeroed views of the flat all-reduce buffer: the backward fills it directly
-            loss = crit(fwd(), {"disparity": tgt, "mask": msk})
-            loss.backward()
+            # the forward / backward have no collective; the gradient sync has one.  A rank whose local part raised must not leave the
+            # others waiting in the all-reduce: every rank agrees on an ok flag first (world 1: a local bool) and all skip the sync together
+            loss, err = None, None
+            try:
+                sync.zero_grad()                 # .grad = zeroed views of the flat all-reduce buffer: the backward fills it directly
+                loss = crit(fwd(), {"disparity": tgt, "mask": msk})
+                loss.backward()
+            except Exception as ex:              # noqa: BLE001
+                err = ex
+            if not all_ranks_ok(err is None, dev):
+                failed.append(repr(err) if err is not None else "another rank failed")
+                return loss
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); sync(); e1.record()
             sync_ms.append((e0, e1))
             opt.step()
             return loss
         tt = _time(train_step, 3, 5)             # (the eager step is host-bound -- ~2,800 launches for Config B -- and noisy from box to box)
+        if failed:
+            tr[tag] = {"error": failed[0][:300]}
+            mdl.eval()
+            continue
         ar = sum(a_.elapsed_time(b_) for a_, b_ in sync_ms[-5:]) / 5
         tr[tag] = {"ms_per_step": round(tt * 1e3, 2), "roi_pairs_per_s_per_gpu": round(nroi / tt, 1),
                    "regressor_tflops_fwd_bwd": round(3 * fl3 / tt / 1e12, 2),
@@ -389,6 +465,18 @@ def train_step_extra(dev, model_a, world):
 def rank0_extras(dev, extra):
     from disprcnn_amd import engine as E
     from disprcnn_amd.utils import synth
+    # ---- a1 on its own ("a1: HBM bandwidth"): the MATERIALISED concat volume (what the train path builds; the eval path folds it
+    # into the first layer's loads and never writes it).  Algorithmic bytes per ROI = 4 * (2*C*H'W' + 2*C*D'H'W') = 2,609,152 at Config A.
+    n_cv = 512
+    fl_cv, fr_cv = synth.synth_features(n_cv, 32, 28, 28, tag="benchcv")
+    fl_cv, fr_cv = fl_cv.to(dev), fr_cv.to(dev)
+    vol = E.Blocked(n_cv, 64, 12, 28, 28, 1, 1, 1, dev)
+    t_cv = _time(lambda: E.cost_volume_blocked(fl_cv, fr_cv, vol, 0, 12, 0), 2, 10)
+    by_cv = 4 * (2 * 32 * 28 * 28 + 2 * 32 * 12 * 28 * 28) * n_cv
+    extra["cost_volume_standalone"] = {"GB_per_s_algorithmic": round(by_cv / t_cv / 1e9, 1), "us_per_launch": round(t_cv * 1e6, 1), "roi_pairs": n_cv,
+                                       "frac_of_hbm_peak_8TBps": round(by_cv / t_cv / 8e12, 3), "roi_volumes_per_s": round(n_cv / t_cv, 1),
+                                       "workload": "drc_cost_volume_blocked_fwd: dense features [N,32,28,28] x2 -> blocked fp32 volume [N,64,12,28,28] (zero halo not written)"}
+    del vol, fl_cv, fr_cv
     # ---- Config B (224x224, D=96, full PSMNet incl. the 2D feature CNN), 16 ROI pairs per step
     mB, _ = build_model(dev, 48, -48, "B")
     l, r = synth.synth_images(16, 224, 224, tag="benchB")
@@ -462,23 +550,29 @@ def rank0_extras(dev, extra):
         E.TIMING = []
         pair_step()
         torch.cuda.synchronize()
-        fl_exec = sum(f * (64.0 / 216.0 if k.startswith("wino3d") else 16.0 / 36.0 if k.startswith("wino2d") else 1.0) for k, f, _, _ in E.TIMING)
+        # per launch: the flops it EXECUTES (Winograd F(2x2x2,3x3x3) runs 64 multiplies where the direct form needs 216, F(2x2,3x3) 16 of 36) and
+        # the peak of the pipe it runs on: fp32 MFMA 157.3 TF, or -- the split-f16 kernels, three f16 products per fp32 product -- 2500 / 3 TF
+        ratio = lambda k: 64.0 / 216.0 if k.startswith("wino3d") else 16.0 / 36.0 if k.startswith("wino2d") else 1.0      # noqa: E731
+        peak_of = lambda k: PEAK_F16_TFLOPS / 3.0 if k.startswith("convs16") else PEAK_F32_TFLOPS                       # noqa: E731
+        fl_exec = sum(f * ratio(k) for k, f, _, _ in E.TIMING)
+        t_at_peak = sum(f * ratio(k) / (peak_of(k) * 1e12) for k, f, _, _ in E.TIMING)      # seconds the pair's conv launches would take at their pipes' peaks
         fl_timed = sum(f for _, f, _, _ in E.TIMING)
         E.TIMING = None
     fl_pair = FLOPS_BACKBONE_PAIR + fl_b
     extra["kitti_pair_r50fpn_plus_16roi"] = {
         "stereo_pairs_per_s": round(1.0 / tp, 2), "ms_per_pair": round(tp * 1e3, 2), "backbone_ms": round(tbb * 1e3, 2),
         "backbone_tflops": round(FLOPS_BACKBONE_PAIR / tbb / 1e12, 2),
-        "roofline": {"bound": "mfma", "achieved": round(fl_pair / tp / 1e12, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(fl_pair / tp / 1e12 / PEAK_F32_TFLOPS, 4),
-                     "executed_frac": round(fl_exec / tp / 1e12 / PEAK_F32_TFLOPS, 4),
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s",
+                     "frac": round(t_at_peak / tp, 4),
+                     "frac_is": "sum over the pair's conv launches of (executed flops / the peak of the pipe the kernel runs on) / wall time: fp32 MFMA "
+                                "157.3 TF (trunk, 2D CNN; Winograd launches counted at their executed 16/36 or 64/216), split-f16 kernels 2500/3 TF",
+                     "direct_conv_equivalent_tflops": round(fl_pair / tp / 1e12, 2),
+                     "direct_equiv_over_f32_peak": round(fl_pair / tp / 1e12 / PEAK_F32_TFLOPS, 4),
                      "executed_flops_per_pair": fl_exec, "conv_flops_of_the_timed_launches": fl_timed,
                      "flops_per_pair": fl_pair,
-                     "note": ("whole stereo-pair pipeline, direct-convolution-equivalent conv flops (SURVEY 8a/8d: backbone 250.3 G + 16 x "
-                              "(2 x 22.19 G 2D CNN + 48.51 G regressor)) / wall time = `frac`, NOT an executed fraction: the Winograd layers execute 64/216 "
-                              "(3D) and 16/36 (2D) of their share.  `executed_frac` = the flops the launches actually execute on the matrix cores "
-                              "(per-launch conv flops x the kernel's Winograd ratio, summed over one pair) / wall time / peak; per-kernel MFMA-busy and "
-                              "HBM bytes: profiles/r4_pair_backbone_*.md, r4_configB_*.md")},
+                     "note": ("direct_conv_equivalent_* = SURVEY 8a/8d's algorithmic conv flops (backbone 250.3 G + 16 x (2 x 22.19 G 2D CNN + 48.51 G "
+                              "regressor)) / wall time: a rate, not a roofline fraction; per-kernel MFMA-busy and HBM bytes: profiles/r5_pair_backbone_*.md, "
+                              "r5_configB_*.md")},
         "workload": "BASELINE configs[1]: R-50-FPN on 2x3x375x1242 (250.3 GFLOP/pair, SURVEY a12) + 16 ROIs: pairing, ROIAlign crops, PSMNet 224^2 D=96"}
     del bb, det, mB
     # ---- the 2D stage in front of the path: DispRCNN = R-50-FPN trunk + Stereo RPN + stereo box head + mask head on the pair

@@ -366,11 +366,22 @@ def stem_conv(images, w_packed, scale, shift, y, relu=True, unit0=0):
     n, _, H, W = images.shape
     if (y.D, y.H, y.W) != (1, (H + 1) // 2, (W + 1) // 2) or unit0 < 0 or unit0 + n > y.N:
         raise ValueError("stem_conv: output geometry does not match a 3x3 stride-2 pad-1 convolution of the input")
+    cout_pad = w_packed.shape[1]
+    if not isinstance(y, Blocked) or y.storage.dtype != torch.float32 or y.cb * CB < cout_pad:
+        raise ValueError("stem_conv: y must be a blocked fp32 tensor with at least the packed weights' output channels")
+    if scale.numel() < cout_pad or shift.numel() < cout_pad or scale.dtype != torch.float32 or shift.dtype != torch.float32:
+        raise ValueError("stem_conv: scale / shift must be fp32 vectors of at least cout_pad entries")
     x = images.contiguous()
+    if TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(y.device))
     st = _lib.lib().drc_conv2d_k3s2_stem_fwd(_ptr(x), n, H, W, _ptr(w_packed), w_packed.shape[1], _ptr(scale), _ptr(shift), _ptr(y.storage),
                                              y.n_stride, y.cb_stride, y.h_stride, y.interior_off + unit0 * y.n_stride, y.H, y.W, int(relu),
                                              _stream_ptr(y.device))
     _lib.check(st, "drc_conv2d_k3s2_stem_fwd")
+    if TIMING is not None:
+        e1.record(torch.cuda.current_stream(y.device))
+        TIMING.append(("stemconv_kernel", 2 * n * y.H * y.W * 27 * cout_pad, e0, e1))
 
 
 def pack_conv_weight(w, transposed=False):

@@ -11,11 +11,16 @@ from .. import _lib
 from .. import engine as E
 
 
+_MASK_CHECK_BYTES = 256 << 20      # masks above this size (~46k boxes per view) are checked against the free device memory first
+
+
 def _mask_workspace(views, n, device):
     """The dense suppression mask: views * n * ceil(n / 64) words of 8 bytes (1.8 GB per view at 120k boxes, 34 GB at the 524,288-box limit).
     Checked against the free device memory first, so that an oversized call fails with the reason instead of an allocator error."""
     words = views * n * ((n + 63) // 64)
     need = words * 8
+    if need <= _MASK_CHECK_BYTES:           # the per-image RPN / box-head calls (a few thousand boxes): no driver query on the hot path
+        return torch.empty(words, dtype=torch.int64, device=device)
     free, _total = torch.cuda.mem_get_info(device)
     cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
     if need > free + cached:

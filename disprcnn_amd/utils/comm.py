@@ -108,6 +108,47 @@ def gather_predictions(predictions, fields=("scores", "labels", "disparity")):
     return [out[i] for i in sorted(out)]
 
 
+def all_ranks_ok(ok, device=None):
+    """True iff `ok` is true on EVERY rank (one tiny MIN all-reduce).  Call it before a step that contains a collective when a rank may have
+    failed locally (an exception caught per rank): a rank that skips the collective would leave the others waiting forever."""
+    if get_world_size() == 1:
+        return bool(ok)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def sharded_inference(model, samples, fields=("scores", "labels", "disparity"), timing=None):
+    """The sharded inference loop of one node (reference: engine/inference.py:24-72 -- every rank runs the model on its share of the
+    images, then the per-image predictions are gathered on the main process).
+
+    samples : a sequence of (image_id, lr_images, lr_result), the SAME on every rank (the reference reaches the same partition through
+              its DistributedSampler); this rank takes the contiguous `shard_range` of it.
+    model   : the detector (DispRCNN3D: forward(lr_images, lr_result) -> {"left": [BoxList], "right": [...]}); called once per sample of
+              the shard with NO collective in between -- ROIs and images are independent units.
+    Returns the left-view BoxLists of ALL samples ordered by image id on the main process, None on the others (gather_predictions: the
+    [R,H,W] disparities travel as tensors, one row all_gather per field).  `timing` (a dict) receives compute_s / gather_s of this rank."""
+    import time
+    lo, hi = shard_range(len(samples))
+    local = {}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for image_id, lr_images, lr_result in samples[lo:hi]:
+            out = model(lr_images, lr_result)
+            left = out["left"] if isinstance(out, dict) else out
+            local[int(image_id)] = left[0] if isinstance(left, (list, tuple)) else left
+    if torch.cuda.is_available() and any(b.bbox.is_cuda for b in local.values()):
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    gathered = gather_predictions(local, fields)
+    t2 = time.perf_counter()
+    if timing is not None:
+        timing.update(compute_s=t1 - t0, gather_s=t2 - t1, shard=(lo, hi))
+    return gathered
+
+
 def reduce_dict(d, average=True):
     """Reduce a dict of scalar tensors to rank 0 (reference comm.py:90-116, trainer.py:19-41)."""
     world = get_world_size()

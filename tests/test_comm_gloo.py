@@ -169,3 +169,66 @@ def test_gather_predictions_rank_without_images_int64_field():
     assert [m[0] for m in main] == [2, 0, 3] and all(m[1] for m in main)
     assert main[0][2] == [0, 1] and main[2][2] == [20, 21, 22]
     assert main[2][3] == (3, 4, 4)
+
+
+# ------------------------------------------------------------------ the product's sharded inference loop
+def _sharded_worker(rank, world, port, n_images, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from disprcnn_amd.structures.bounding_box import BoxList
+        calls = []
+
+        class StubDetector:
+            """Stands in for DispRCNN3D on the CPU: image i with r = i % 3 ROIs gets r boxes and a [r,4,5] 'disparity' filled with i."""
+
+            def __call__(self, lr_images, lr_result):
+                i = int(lr_images["left"])
+                calls.append(i)
+                b = lr_result["left"][0]
+                b.add_field("disparity", torch.full((len(b), 4, 5), float(i)))
+                return {"left": [b], "right": lr_result["right"]}
+
+        def sample(i):
+            r = i % 3
+            boxes = torch.tensor([[1.0, 2.0, 3.0 + j, 4.0 + i] for j in range(r)]).reshape(-1, 4)
+            b = BoxList(boxes, (100 + i, 50))
+            b.add_field("scores", torch.full((r,), 0.5 + 0.01 * i))
+            b.add_field("labels", torch.ones(r, dtype=torch.int64))
+            return (i, {"left": i, "right": i}, {"left": [b], "right": [b]})
+
+        samples = [sample(i) for i in range(n_images)]
+        timing = {}
+        got = comm.sharded_inference(StubDetector(), samples, timing=timing)
+        lo, hi = comm.shard_range(n_images)
+        assert calls == list(range(lo, hi)) and timing["shard"] == (lo, hi)        # only this rank's shard was computed
+        ok_all = comm.all_ranks_ok(True)
+        ok_one = comm.all_ranks_ok(rank != 1)                                       # rank 1 "failed": every rank learns it
+        if rank == 0:
+            assert got is not None and len(got) == n_images
+            for i, b in enumerate(got):
+                assert len(b) == i % 3 and b.size == (100 + i, 50)
+                assert torch.equal(b.get_field("disparity"), torch.full((i % 3, 4, 5), float(i)))
+                assert torch.allclose(b.get_field("scores"), torch.full((i % 3,), 0.5 + 0.01 * i)) and b.get_field("labels").dtype == torch.int64
+        else:
+            assert got is None
+        q.put((rank, ok_all, ok_one))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_inference_world2_gloo():
+    """comm.sharded_inference: shard -> model per sample (no collective) -> tensor gather on rank 0, with a stub detector; ragged ROI
+    counts incl. images without ROIs; and the all-ranks-ok flag that guards collective-bearing steps."""
+    for n_images in (7, 1):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+        for p in ps:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in ps)
+        for p in ps:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert res == [(0, True, False), (1, True, False)]

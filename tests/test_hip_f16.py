@@ -154,32 +154,57 @@ def test_config_a_f16_vs_fp32_oracle(dev):
         m.train().forward_from_features(fl.to(dev), fr.to(dev), (112, 112))
 
 
-def test_stress_shape_64_rois_f16_vs_fp32(dev):
-    """BASELINE configs[3]: 64 ROI crops 224x224, D=96 through the full PSMNet with the fp16-storage regressor, against the fp32 HIP
-    path on all 64 ROIs (itself held to the reference goldens) and against the CPU fp32 oracle on a sampled pair of ROIs."""
-    sd = state_for("B")
+# Measured on MI355X (round 5, all 64 ROIs, D = 96) against the CPU fp32 oracle, mean / max |err| px:
+#     fp16-STORAGE regressor: sharp set "B" 0.0514 / 1.15, tempered set "Bt" 0.0050 / 0.061;   default split-f16 path: 2.6e-4 / 7.7e-3 and 2.4e-5 / 2.7e-4.
+# SURVEY 8c proposed 5e-2 for the fp16 mode: the tempered set (classif*.2 weights x 0.1, "realistic softmax entropy") is 10x inside it, the
+# sharp synthetic set (near-saturated softmax over 96 disparities) sits AT it.  The bounds below are those measurements with ~15-20 % margin;
+# they are statements of what the fp16-storage mode delivers, not tolerances tuned to pass.
+STRESS_BOUNDS = {"B": 6.0e-2, "Bt": 6.0e-3}
+
+
+def _stress_state(case):
+    if case == "Bt":                      # tempered weights, the BatchNorm statistics of the B fixture (no BN behind classif*.2)
+        import os
+        from tests.helpers import GOLDEN
+        from disprcnn_amd.modeling.psmnet.keys import psmnet_state_template
+        return synth.load_bn_stats(synth.synth_state_dict(psmnet_state_template(), tempered=True), os.path.join(GOLDEN, "bn_stats_B.npz"))
+    return state_for(case)
+
+
+@pytest.mark.parametrize("case", ["B", "Bt"])
+def test_stress_shape_64_rois_f16_vs_fp32(dev, case):
+    """BASELINE configs[3]: 64 ROI crops 224x224, D=96 through the full PSMNet -- ALL 64 ROIs against the CPU fp32 oracle (pinned to the
+    reference) for (a) the fp16-storage regressor (regressor_storage = "f16": half the activation bytes, error bound STRESS_BOUNDS) and (b) the
+    default path (split-f16 arithmetic: fp16 inputs on the matrix cores at fp32-class error, the bound of the fp32 path: mean <= 1e-3 px)."""
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    sd = _stress_state(case)
     left, right = synth.synth_images(64, 224, 224, tag="stress16")
-    m16 = _model(dev, "B", 48, -48, "f16")
+
+    def run(storage):
+        m = PSMNet(48, -48)
+        m.load_state_dict(sd, strict=True)
+        m.regressor_storage = storage
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            out = m((left.to(dev), right.to(dev))).cpu()
+        b = m._rt.workspace_bytes()
+        keys = {k[0] for k in m._rt._ws}
+        del m
+        torch.cuda.empty_cache()
+        return out, b, keys
+    got16, bytes16, _ = run("f16")
+    got32, bytes32, keys32 = run("f32")
+    assert "3ds16" in keys32                       # the default: split-f16 arithmetic, fp32-class
     with torch.no_grad():
-        got = m16((left.to(dev), right.to(dev))).cpu()
-    bytes16 = m16._rt.workspace_bytes()
-    del m16
-    torch.cuda.empty_cache()
-    m32 = _model(dev, "B", 48, -48, "f32")
-    with torch.no_grad():
-        ref = m32((left.to(dev), right.to(dev))).cpu()
-    bytes32 = m32._rt.workspace_bytes()
-    err = (got - ref).abs()
-    print(f"stress 64 ROIs f16 vs f32 HIP: mean/max |err| px {err.mean().item():.4f} {err.max().item():.4f}; "
-          f"workspace {bytes16 / 2**30:.1f} GiB vs {bytes32 / 2**30:.1f} GiB")
-    assert err.mean().item() <= 1e-1 and torch.isfinite(got).all()
+        oref = torch.cat([O.psmnet_forward(sd, left[i:i + 16], right[i:i + 16], 48, -48) for i in range(0, 64, 16)])
+    e16, e32 = (got16 - oref).abs(), (got32 - oref).abs()
+    print(f"stress 64 ROIs [{case}] vs CPU fp32 oracle (all 64): fp16 storage mean/max |err| px {e16.mean().item():.4f} {e16.max().item():.4f}; "
+          f"split-f16 (default) {e32.mean().item():.2e} {e32.max().item():.2e}; workspace {bytes16 / 2**30:.1f} GiB vs {bytes32 / 2**30:.1f} GiB")
+    assert torch.isfinite(got16).all() and torch.isfinite(got32).all()
+    assert e16.mean().item() <= STRESS_BOUNDS[case]
+    assert e16.reshape(64, -1).mean(1).max().item() <= 3 * STRESS_BOUNDS[case]          # ... no single ROI far off
+    assert e32.mean().item() <= 1e-3 and e32.max().item() <= 2e-2 and e32.reshape(64, -1).mean(1).max().item() <= 1e-3
     assert bytes16 < 0.8 * bytes32                                    # the regressor's activations take half the bytes (the fp32 2D CNN is shared)
-    pick = [3, 41]
-    with torch.no_grad():
-        oref = O.psmnet_forward(sd, left[pick], right[pick], 48, -48)
-    oerr = (got[pick] - oref).abs()
-    print("stress f16 vs CPU fp32 oracle (2 ROIs): mean/max |err| px", oerr.mean().item(), oerr.max().item())
-    assert oerr.mean().item() <= 1e-1
 
 
 def test_f16_feature_cnn_vs_fp32_path(dev):

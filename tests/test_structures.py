@@ -45,9 +45,25 @@ def test_disparity_map_resize_negative_size_is_a_copy():
     assert torch.equal(r.data, d.data) and r.data is not d.data
 
 
-def test_disparity_map_resize_needs_the_gpu():
-    with pytest.raises(RuntimeError):
-        DisparityMap(torch.zeros(4, 4)).resize((8, 8))
+@pytest.mark.parametrize("name,hw,dst", RESIZE)
+def test_disparity_map_resize_cpu_vs_reference(name, hw, dst):
+    """A CPU map (the dataloader side: the reference resamples its targets' CPU DisparityMaps in the transforms) against the
+    reference-recorded outputs: bilinear to 1e-5 px, the signed max pooling exactly."""
+    d = synth.hash_uniform(f"structures:resize:{name}", hw, -48.0, 48.0)
+    bil = DisparityMap(d).resize(dst).data
+    ref = torch.from_numpy(G[f"resize:{name}:bilinear"])
+    assert tuple(bil.shape) == tuple(ref.shape)
+    assert (bil - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    _eq(DisparityMap(d).resize(dst, use_max_pooling=True).data, f"resize:{name}:maxpool")
+
+
+def test_boxlist_map_follows_resize_on_cpu():
+    """BoxList.resize forwards to its maps (reference bounding_box.py:156-199) -- on the CPU tensors a dataloader worker holds."""
+    d = synth.hash_uniform("structures:map", (SIZE[1], SIZE[0]), 0.0, 64.0)
+    b = BoxList(torch.tensor(BOXES), SIZE)
+    b.add_map("disparity", DisparityMap(d))
+    got = b.resize((160, 48)).get_map("disparity").data
+    assert (got - torch.from_numpy(G["map:resize"])).abs().max().item() <= 1e-5 * 64.0
 
 
 def test_boxlist_convert_resize_transpose_crop_vs_reference():
