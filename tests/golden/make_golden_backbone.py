@@ -130,8 +130,33 @@ def main_r101():
     np.savez_compressed(os.path.join(HERE, "backbone_r101_golden.npz"), **out)
 
 
+def main_r101_kitti():
+    """R-101-FPN on a KITTI-sized stereo pair (2 x 3 x 375 x 1242), with the BatchNorm statistics main_r101 recorded -> backbone_r101_kitti_golden.npz
+    (round 5: the shipped 2D config's conv body at the shipped input size; the other fixtures stay as they are)."""
+    cfg.MODEL.BACKBONE.CONV_BODY = "R-101-FPN"
+    cfg.MODEL.RESNETS.BACKBONE_OUT_CHANNELS = 256
+    model = build_backbone(cfg)
+    sd = backbone_state(model.state_dict())
+    synth.load_bn_stats(sd, os.path.join(HERE, "bn_stats_backbone_r101.npz"))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    out = {}
+    x = synth.hash_uniform("bb:kitti", (2, 3, 375, 1242), -2.0, 2.0)
+    with torch.no_grad():
+        feats = model.body(x)
+        outs = model(x)
+    for i, f in enumerate(feats):
+        sample(out, f"kitti_c{i + 2}", f)
+    for i, o in enumerate(outs):
+        sample(out, f"kitti_p{i + 2}", o)
+    print("R-101 kitti", [tuple(o.shape) for o in outs], float(outs[0].abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "backbone_r101_kitti_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    if "--r101" in sys.argv:
+    if "--r101-kitti" in sys.argv:
+        main_r101_kitti()
+    elif "--r101" in sys.argv:
         main_r101()
     else:
         main()

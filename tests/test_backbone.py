@@ -116,3 +116,20 @@ def test_hip_backbone_r101_vs_reference_golden(tag):
     assert len(outs) == 5
     for i, o in enumerate(outs):
         _check(z, f"{tag}_p{i + 2}", o, 6e-4)
+
+
+@pytest.mark.gpu
+def test_hip_backbone_r101_kitti_size_vs_reference_golden():
+    """The shipped 2D config's conv body (R-101-FPN, configs/kitti/car/vob/mask.yaml:5) at the shipped input size, a 2 x 3 x 375 x 1242 stereo pair:
+    all five pyramid levels against the reference's torch-CPU output recorded by make_golden_backbone.py --r101-kitti (bound as for the small
+    R-101 cases: 6e-4 * max|ref| on 512 sampled values per level)."""
+    dev = torch.device("cuda:0")
+    m, _ = _model_and_state_r101()
+    m = m.to(dev).eval()
+    z = np.load(os.path.join(GOLDEN, "backbone_r101_kitti_golden.npz"))
+    x = synth.hash_uniform("bb:kitti", (2, 3, 375, 1242), -2.0, 2.0).to(dev)
+    with torch.no_grad():
+        outs = m(x)
+    assert [tuple(o.shape[2:]) for o in outs] == [(94, 310), (47, 155), (24, 78), (12, 39), (6, 20)]
+    for i, o in enumerate(outs):
+        _check(z, f"kitti_p{i + 2}", o, 6e-4)

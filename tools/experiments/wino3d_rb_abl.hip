@@ -43,9 +43,27 @@ __device__ __forceinline__ f32x4 rb_sub(const f32x4 a, const f32x4 b, const f32x
 #define RB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define RB_WAVES 8
 #define RB_RING_BYTES 32768
+#ifdef RB_ABL_NOBARRIER
+#define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
 #define RB_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 
+#ifdef RB_TRACE
+// development only: s_memtime stamps of block RB_TRACE_BLOCK, waves 0 and 4 (the two waves of one SIMD), 16 marks per step, 64 steps
+__device__ unsigned long long rb_trace_buf[2][64][16];
+#define RB_MARK(k)                                                                                              \
+    do {                                                                                                        \
+        if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && stepno >= 8 && stepno < 72)                      \
+            rb_trace_buf[wave >> 2][stepno - 8][k] = __builtin_readcyclecounter();                              \
+    } while (0)
+extern "C" int drc_rb_trace_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_trace_buf), sizeof(rb_trace_buf));
+}
+#else
+#define RB_MARK(k)
+#endif
 
 namespace {
 
@@ -210,6 +228,9 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     // (all uniform offsets are 32-bit: the launcher checks N * x_n_stride * 4 < 2^32 and the packed weights < 2^31 floats)
     const unsigned xcb4 = (unsigned)p.x_cb_stride * 4u, xd4 = (unsigned)p.x_d_stride * 4u;
     auto stage_issue = [&](const Item& it, int xd, int cb, Raw& r) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOSTAGE
+        return;
+#endif
         if (!it.valid) return;
         if constexpr (CV) {
             const bool right = cb >= cv.cbi;                                      // wave-uniform
@@ -239,6 +260,9 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     };
     // depth butterfly, w butterfly, four w-frequencies into brick buffer `bb`
     auto stage_finish = [&](const Item& it, int xd, char* bb, const Raw& r) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOSTAGE
+        return;
+#endif
         if (!it.valid) return;
         const float sgn = xd == 1 ? 1.f : -1.f;
         f32x4 d[4];
@@ -266,6 +290,9 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
     const unsigned wxi4 = (unsigned)(p.cb_in * n_ct) * 1024u;         // bytes per frequency point
     const unsigned wcb4 = (unsigned)n_ct * 1024u;                     // bytes per channel block
     auto ring_fill = [&](int slab, int xd, int cb, int hf) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOFILL
+        return;
+#endif
         const char* src = wlane + ((unsigned)(xd * 16 + hf * 8) * wxi4 + (unsigned)cb * wcb4);
         char* dst = ring + slab * 16384 + wave * 1024;
         __builtin_amdgcn_global_load_lds(RB_GLOBAL_PTR(src), RB_LDS_PTR(dst), 16, 0, 0);
@@ -286,6 +313,15 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int HALF = decltype(half_tag)::value;
         f32x4 wf0[4], wf1[4], ta[4], tb_[4], tc[4], v0[4], v1[4];
+#ifdef RB_ABL_NOLDSR
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) {
+            const f32x4 c_ = {(float)lane, (float)(lane + xw), 1.f, 2.f};
+            wf0[xw] = c_; wf1[xw] = c_ * 2.f; ta[xw] = c_ * 3.f; tb_[xw] = c_ * 4.f; tc[xw] = c_ * 5.f;
+            asm volatile("" : "+v"(wf0[xw]), "+v"(wf1[xw]), "+v"(ta[xw]), "+v"(tb_[xw]), "+v"(tc[xw]));
+        }
+        if (false)
+#endif
         {
         // first row's operands: weights of frequency row 2*HALF, the two transformed rows its h butterfly combines
 #pragma unroll
@@ -310,6 +346,9 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         }
 #pragma unroll
         for (int xw = 0; xw < 4; ++xw) asm volatile("" : "+v"(v0[xw]));
+#ifdef RB_ABL_NOLDSR
+        if (false)
+#endif
         {
         // second row's operands, requested before the first row's MFMAs so that they arrive in their shadow
 #pragma unroll
@@ -318,7 +357,12 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         for (int xw = 0; xw < 4; ++xw) wf1[xw] = *(const f32x4*)(rs + (1 * 4 + xw) * 2048);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef RB_ABL_NOMFMA
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) acc[2 * HALF][xw] += wf0[xw] * v0[xw];
+#else
         RB_MFMA_ROW(2 * HALF, wf0, v0)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF == 0) {                 // xh 1: t1 + t2      (tc = t1)
 #pragma unroll
@@ -327,12 +371,22 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
 #pragma unroll
             for (int xw = 0; xw < 4; ++xw) v1[xw] = RB_SUB(ta[xw], tc[xw]);
         }
+#ifdef RB_ABL_NOMFMA
+#pragma unroll
+        for (int xw = 0; xw < 4; ++xw) acc[2 * HALF + 1][xw] += wf1[xw] * v1[xw];
+#else
         RB_MFMA_ROW(2 * HALF + 1, wf1, v1)
+#endif
     };
 
     // end of a depth frequency: in-plane inverse (A^T . A, 4x4 -> 2x2), folded into the running depth sums (A^T columns
     // [1 1 1 0] for od 0, [0 1 -1 -1] for od 1); the last frequency runs the epilogue
     auto phase_end = [&](int xd_, const Geo& geo) __attribute__((always_inline)) {
+#ifdef RB_ABL_NOPE
+        if (xd_ < 3) return;
+        if (geo.valid && lane == 0 && acc[0][0].x + acc[1][1].y + acc[2][2].z + acc[3][3].w == 1.2345e-30f) p.y[0] = 1.f;
+        return;
+#endif
         // the last frequency: the residual's eight float4 are requested first, so that they travel under the inverse transform
         const bool last = (D2 || xd_ == 3) && geo.valid;
         const int ct = ct0 + ctl;
@@ -442,18 +496,28 @@ __device__ __forceinline__ void wino3d_rb_body(const drc_tapconv_params& p, cons
         const char* tb23 = brick + (unsigned)(stepno & 1) * buf_bytes + geo.lds23;
         char* nb = brick + (unsigned)((stepno + 1) & 1) * buf_bytes;
         Raw r;
+        RB_MARK(0);
         ring_fill(1, c0.xd, c0.cb, 1);
+        RB_MARK(1);
         consume(first_tag, std::integral_constant<int, 0>{}, tb01, tb23, rs_lane, [&]() __attribute__((always_inline)) { stage_issue(itA, c1.xd, c1.cb, r); });
+        RB_MARK(2);
         stage_finish(itA, c1.xd, nb, r);
+        RB_MARK(3);
         RB_BARRIER();
+        RB_MARK(4);
         ring_fill(0, c1.xd, c1.cb, 0);
+        RB_MARK(5);
         consume(first_tag, std::integral_constant<int, 1>{}, tb01, tb23, rs_lane + 16384, [&]() __attribute__((always_inline)) { stage_issue(itB, c1.xd, c1.cb, r); });
+        RB_MARK(6);
         stage_finish(itB, c1.xd, nb, r);
+        RB_MARK(7);
         if (c0.cb == p.cb_in - 1) {
             phase_end(c0.xd, geo);
             if (next_round && c1.round < rounds) geo = geo_of(c1.round);
         }
+        RB_MARK(8);
         RB_BARRIER();
+        RB_MARK(9);
         c0 = c1;
         ++stepno;
     };
