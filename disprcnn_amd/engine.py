@@ -1418,9 +1418,11 @@ class ConvPlanS16:
         if nw in (14, 7):
             rt, wt = (2, 14) if nw == 14 else (4, 7)
         if kind == "s1":
-            self.kname = "convs16_kernel<%d,%s,%d,%d>" % (cin // 16, "true" if cv else "false", rt, wt)
+            self._kfmt = "convs16_kernel<%d,%s,%d,%d,%%s,%%s>" % (cin // 16, "true" if cv else "false", rt, wt)
+            self.kname = self._kfmt % ("false", "false")          # (the residual / blocked-fp32-output template flags follow the call's arguments)
         elif kind == "s2":
-            self.kname = "convs16d_kernel<%d,%d,%d>" % (cin // 16, rt, wt)
+            ring = 3 if (cin == 32 and nw in (14, 7)) else 2                    # convs16d.hip's dispatch: what fits the LDS
+            self.kname = "convs16d_kernel<%d,%d,%d,%d>" % (cin // 16, rt, wt, ring)
         else:
             self.kname = "convs16u_kernel<%d,%d>" % (rt, wt)
 
@@ -1454,4 +1456,5 @@ class ConvPlanS16:
         _lib.check(st, fn)
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(dev))
-            TIMING.append((self.kname, self.flops, e0, e1))
+            kn = self._kfmt % ("true" if res is not None else "false", "true" if y32 is not None else "false") if self.kind == "s1" else self.kname
+            TIMING.append((kn, self.flops, e0, e1))

@@ -84,28 +84,28 @@ def _export(obj, stubs):
 
 def save_predictions(predictions, path):
     """Write `predictions` -- {'left': [BoxList], 'right': [BoxList]} or a list of BoxLists -- in the reference's format."""
-    added, patched, stubs = [], [], {}
+    saved, stubs = {}, {}
     try:
+        # pickle writes a class by its dotted path and checks that the path resolves to that very class: for the duration of the save the
+        # reference's module paths hold stand-in modules with stand-in classes.  Whatever sys.modules had under those names (nothing; the
+        # real reference, /root/reference on the path; or the `disprcnn` alias package of this repo) is put back afterwards.
         for module, name in _REF.values():
             parts = module.split(".")
             for i in range(1, len(parts) + 1):                         # parent packages too: pickle imports the dotted path
                 m = ".".join(parts[:i])
-                if m not in sys.modules:
+                if m not in saved:
+                    saved[m] = sys.modules.get(m)
                     sys.modules[m] = types.ModuleType(m)
-                    added.append(m)
-            mod = sys.modules[module]
-            cls = getattr(mod, name, None)
-            if cls is None:                                            # the reference itself is not importable here: a stand-in
-                cls = _stub(module, name)
-                setattr(mod, name, cls)
-                patched.append((mod, name))
+            cls = _stub(module, name)
+            setattr(sys.modules[module], name, cls)
             stubs[(module, name)] = cls
         torch.save(_export(predictions, stubs), path, pickle_module=_PickleModule, pickle_protocol=2)
     finally:
-        for mod, name in patched:
-            delattr(mod, name)
-        for m in reversed(added):
-            sys.modules.pop(m, None)
+        for m, old in saved.items():
+            if old is None:
+                sys.modules.pop(m, None)
+            else:
+                sys.modules[m] = old
 
 
 def load_predictions(path, map_location="cpu"):

@@ -48,8 +48,12 @@ def test_written_file_matches_the_reference_layout(tmp_path):
     assert manifest["our_reader_loads_reference_file"] and manifest["reference_classes_load_our_file"]
     path = str(tmp_path / "predictions.pth")
     preds = _build()
+    before = {m: v for m, v in sys.modules.items() if m == "disprcnn" or m.startswith("disprcnn.")}
     save_predictions(preds, path)
-    assert not any(m == "disprcnn" or m.startswith("disprcnn.") for m in sys.modules), "the stand-in modules must not outlive the save"
+    after = {m: v for m, v in sys.modules.items() if m == "disprcnn" or m.startswith("disprcnn.")}
+    # the stand-in modules must not outlive the save: whatever was registered under the reference's names before (nothing, or this repo's
+    # `disprcnn` alias package) is there again, the very same objects
+    assert after.keys() == before.keys() and all(after[m] is before[m] for m in before)
     data = _pickle_of(path)
     got_globals = sorted({a for op, a, _ in pickletools.genops(data) if op.name == "GLOBAL"})
     assert got_globals == manifest["reference_globals"]                  # the same class paths and helpers, nothing of ours
