@@ -275,6 +275,7 @@ def main():
                 plans = (model._rt._ws.get(("3ds16", nb, 12, 28, 28)) or model._rt._ws[("3d", nb, 12, 28, 28)])["p"]   # the launch heuristics depend on the batch: name what ran
                 bs[str(nb)] = {"roi_pairs_per_s": round(nb / tb_, 1), "ms_per_step": round(tb_ * 1e3, 3),
                                "kernels": {k: plans[k].kname for k in ("dres1.0", "hg1.conv1", "hg1.conv2", "hg1.conv4", "hg1.conv5")}}
+            bs["note"] = "batches of <= 96 units are replayed from a captured HIP graph (PSMNet.graph_eval = 'auto'): the eager step is host-bound there"
             extra["batch_sensitivity_rois_per_step"] = bs
 
     # ---- extras.  The train step is the only one with a collective (one flat gradient all-reduce): EVERY rank enters it.
@@ -488,27 +489,53 @@ def rank0_extras(dev, extra):
                                      "stereo_pairs_per_s_16roi": round(1 / tb, 2),
                                      "direct_conv_equivalent_tflops": round(fl_b / tb / 1e12, 1),
                                      "workload": "16 ROI crops 224x224, D=96 (-48..48): 2D CNN + cost volume + 3D + soft-argmin"}
-    # ---- BASELINE configs[3] shape (64 ROIs/image at 224x224x96) in fp32 (the reference's own precision)
+    # ---- BASELINE configs[3] shape (64 ROIs/image at 224x224x96).  (a) the default path: the regressor in split-f16 arithmetic (fp16 operands
+    # on the f16 matrix cores, fp32-class error: 2.6e-4 px mean against the CPU fp32 oracle over all 64 ROIs, tests/test_hip_f16.py), fp32 2D CNN
     l64, r64 = synth.synth_images(64, 224, 224, tag="benchB64")
     l64, r64 = l64.to(dev), r64.to(dev)
+
+    def parts(fn):
+        """One instrumented pass: time and conv flops of the regressor's launches (3D kernels) and of the 2D CNN's."""
+        E.TIMING = []
+        with torch.no_grad():
+            fn()
+        torch.cuda.synchronize()
+        reg = [(f, a.elapsed_time(b) * 1e-3) for k, f, a, b in E.TIMING if k.startswith(("convs16", "conv16", "wino3d", "tapdirect", "downdirect_kernel<7", "downdirect_kernel<4", "deconv"))]
+        cnn = [(f, a.elapsed_time(b) * 1e-3) for k, f, a, b in E.TIMING if k.startswith(("wino2d", "conv2d", "pointwise", "stemconv", "tap2d"))]
+        E.TIMING = None
+        return sum(t for _, t in reg), sum(f for f, _ in reg), sum(t for _, t in cnn), sum(f for f, _ in cnn)
     with torch.no_grad():
         ts = _time(lambda: mB((l64, r64)), 1, 3)
-    extra["stress_64roi_224x224x96_f32"] = {"roi_pairs_per_s": round(64 / ts, 1), "ms_per_64_roi_image": round(ts * 1e3, 2),
-                                            "regressor_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / ts / 1e12, 1)}
-    # ---- the same shape with the fp16-STORAGE regressor (configs[3] as named: "fp16"): fp16 cost volume + 3D regressor on the f16
-    # matrix cores with fp32 accumulation, fp32 2D CNN; accuracy bound in tests/test_hip_f16.py (mean <= 1e-1 px vs fp32)
+    t_reg, f_reg, t_cnn, f_cnn = parts(lambda: mB((l64, r64)))
+    extra["stress_64roi_224x224x96"] = {
+        "roi_pairs_per_s": round(64 / ts, 1), "ms_per_64_roi_image": round(ts * 1e3, 2),
+        "dtype": "regressor: split-f16 (3 f16-MFMA products per fp32 product, f32 accumulate), fp32-class error; 2D CNN: f32 MFMA",
+        "regressor_ms": round(t_reg * 1e3, 2), "regressor_tflops_fp32_equivalent": round(f_reg / t_reg / 1e12, 1),
+        "regressor_frac_of_f16_mfma_peak": round(3 * f_reg / t_reg / 1e12 / PEAK_F16_TFLOPS, 4),
+        "cnn2d_ms": round(t_cnn * 1e3, 2), "cnn2d_direct_conv_equivalent_tflops": round(f_cnn / t_cnn / 1e12, 1),
+        "note": "regressor_ms / cnn2d_ms are sums of per-launch HIP-event times of one instrumented pass (convolution launches only)"}
+    # ---- (b) the same shape with the fp16-STORAGE regressor (half the activation bytes; one f16 product per fp32 product): fp16 cost volume + 3D
+    # regressor with fp32 accumulation, fp32 2D CNN; error vs the CPU fp32 oracle measured over all 64 ROIs in tests/test_hip_f16.py
+    # (5.1e-2 px mean on the sharp synthetic weights, 5.0e-3 on the tempered set)
     mB.regressor_storage = "f16"
     with torch.no_grad():
         out16 = mB((l64, r64))
         t16 = _time(lambda: mB((l64, r64)), 1, 3)
+    t_reg16, f_reg16, _, _ = parts(lambda: mB((l64, r64)))
     mB.regressor_storage = "f32"
     with torch.no_grad():
         ref64 = mB((l64, r64))
         err16 = (out16 - ref64).abs().mean().item()
     del ref64
+    # HBM bytes the fp16-storage regressor must move per ROI: every conv's input + output (+ residual) once, 2 bytes per value (SURVEY 8a: 279.1 MB
+    # of fp32 activation traffic per ROI at Config B, halved) -- its kernels are priced against HBM as well as against the MFMA peak
     extra["stress_64roi_224x224x96_f16_storage"] = {"roi_pairs_per_s": round(64 / t16, 1), "ms_per_64_roi_image": round(t16 * 1e3, 2),
-                                                    "regressor_direct_conv_equivalent_tflops": round(FLOPS_PER_VOXEL_3D * 24 * 56 * 56 * 64 / t16 / 1e12, 1),
-                                                    "mean_abs_err_px_vs_f32_path": round(err16, 4),
+                                                    "regressor_ms": round(t_reg16 * 1e3, 2),
+                                                    "regressor_direct_conv_equivalent_tflops": round(f_reg16 / t_reg16 / 1e12, 1),
+                                                    "regressor_frac_of_f16_mfma_peak": round(f_reg16 / t_reg16 / 1e12 / PEAK_F16_TFLOPS, 4),
+                                                    "regressor_algorithmic_hbm_GB_per_s": round(64 * 279.1e6 / 2 / t_reg16 / 1e9, 1),
+                                                    "regressor_frac_of_hbm_peak_8TBps": round(64 * 279.1e6 / 2 / t_reg16 / 8e12, 3),
+                                                    "mean_abs_err_px_vs_default_path": round(err16, 4),
                                                     "dtype": "f16 storage / f32 accumulate (v_mfma_f32_16x16x32_f16) for cost volume + 3D regressor; 2D CNN f32"}
     # (the opt-in all-fp16 mode, PSMNet.feature_storage = "f16", is not reported here: its error vs the fp32 path -- 0.34 px, tests/test_hip_f16.py --
     # is outside the bound a throughput figure may be quoted under)

@@ -13,6 +13,8 @@ import torch
 from ... import engine as E
 from .submodule import SPP_BRANCHES, TRUNK_STAGES
 
+GRAPH_MAX_UNITS = 96     # eval: batches up to this many ROI pairs replay a captured HIP graph (PSMNet.graph_eval = "auto")
+GRAPH_MAX_ENTRIES = 12   # captured graphs kept per runtime (one per exact input shape), least recently used dropped
 MAX_SLOTS = 4            # train-mode forward passes of one geometry that may await their backward at once (each owns a workspace pool)
 WS_MAX_PLANS = 48        # launch-plan sets kept per runtime (one per exact unit count; they hold views, not memory)
 
@@ -131,6 +133,8 @@ class PSMNetRuntime:
         self._tape = None       # list of recorded ops while a differentiable train-mode forward runs
         self._held = {}         # workspace slot -> token of the differentiable forward whose saved activations live there
         self._slot = 0          # slot the running forward uses
+        self._graphs = OrderedDict()    # eval HIP graphs: key -> (epoch, static inputs, GraphedStep)
+        self._epoch = 0         # advanced whenever what a captured graph points at is replaced (packed weights, BN folds, a workspace pool)
 
     # ------------------------------------------------------------------ workspace slots (forwards awaiting their backward)
     def _pick_slot(self):
@@ -174,6 +178,7 @@ class PSMNetRuntime:
                 for k in [k for k, w in self._ws.items() if w.get("pool") is pool]:
                     del self._ws[k]
             pool = self._pools[gkey] = E.WorkspacePool(E.bucket_units(n), self.device)
+            self._epoch += 1            # captured graphs point into the replaced pool
         return pool
 
     def _ws_get(self, key):
@@ -211,11 +216,27 @@ class PSMNetRuntime:
                     "second backward through the same forward is not supported: run the forward again).")
 
     # ------------------------------------------------------------------ weights
+    def _slots(self, kind):
+        """[(owner dict, name, tensor)] of every parameter / buffer: model.parameters() walks ~300 modules (1 ms of host time per call, twice
+        per forward); the slots are rebuilt only when a tensor OBJECT was replaced in its owner (checked by identity, ~15 us)."""
+        cache = self.__dict__.setdefault("_slot_cache", {})
+        sl = cache.get(kind)
+        if sl is not None and all(d.get(n) is t for d, n, t in sl):
+            return sl
+        sl = []
+        for mod in self.model.modules():
+            d = mod._parameters if kind == "p" else mod._buffers
+            sl.extend((d, n, t) for n, t in d.items() if t is not None)
+        cache[kind] = sl
+        return sl
+
     def _version(self):
-        return tuple(t._version for t in self.model.parameters()) + tuple(t.data_ptr() for t in self.model.parameters())
+        sl = self._slots("p")
+        return tuple([t._version for _, _, t in sl]) + tuple([t.data_ptr() for _, _, t in sl])
 
     def _buffers_version(self):
-        return tuple(t._version for t in self.model.buffers()) + tuple(t.data_ptr() for t in self.model.buffers())
+        sl = self._slots("b")
+        return tuple([t._version for _, _, t in sl]) + tuple([t.data_ptr() for _, _, t in sl])
 
     def _compile(self):
         """Packed weights are rebuilt when a PARAMETER changed; the eval-mode BatchNorm folds additionally when a buffer (running
@@ -230,6 +251,7 @@ class PSMNetRuntime:
                         if isinstance(c, _Conv):
                             c.refold()
                     self._folds_version = vb
+                    self._epoch += 1
             return self._w
         m, dev = self.model, self.device
         W = {}
@@ -260,6 +282,7 @@ class PSMNetRuntime:
         cb3("fe.lastconv.0", fe.lastconv[0])
         W["fe.lastconv.2"] = _Conv(fe.lastconv[2], None, dev)
         self._w, self._weights_version, self._folds_version = W, v, None
+        self._epoch += 1
         if not self._training:
             for c in W.values():
                 if isinstance(c, _Conv):
@@ -617,12 +640,56 @@ class PSMNetRuntime:
             outs.append(d)
         return tuple(outs) if training else outs[0]
 
+    # ------------------------------------------------------------------ eval as a replayed HIP graph (small batches are launch-bound)
+    def _graph_mode(self, n_units, training):
+        """PSMNet.graph_eval: "auto" (default) -- eval batches of at most GRAPH_MAX_UNITS units replay a captured HIP graph (one image's 16 ROIs
+        are ~45-150 launches of a few us each: the eager step is bound by the host, 1.47 ms vs 0.70 ms at 16 ROI pairs of Config A);
+        True: every eval batch; False: never.  Never while a train-mode forward awaits its backward, under autograd, or inside a capture."""
+        mode = getattr(self.model, "graph_eval", "auto")
+        if mode not in ("auto", True, False):
+            raise ValueError("PSMNet.graph_eval must be 'auto', True or False")
+        if training or mode is False or self._held or torch.is_grad_enabled() or n_units == 0 or E.TIMING is not None:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        return mode is True or n_units <= GRAPH_MAX_UNITS
+
+    def _replay(self, key, inputs, fn):
+        """inputs: the caller's tensors; fn(*static_inputs) -> output tensor.  The graph is captured on first use of `key` (after an eager
+        warm-up that builds plans / workspaces), re-captured when what it points at was replaced (epoch), and replayed otherwise."""
+        from ...utils.graph import GraphedStep
+        self._compile()                                   # a parameter / buffer change advances the epoch BEFORE the lookup
+        ent = self._graphs.get(key)
+        if ent is not None and ent[0] != self._epoch:
+            del self._graphs[key]
+            ent = None
+        if ent is None:
+            static = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in inputs]
+            for s_, t in zip(static, inputs):
+                s_.copy_(t)
+            fn(*static)                                    # eager once: plans, workspaces, pools (may advance the epoch)
+            step = GraphedStep(lambda: fn(*static), warmup=1)
+            ent = (self._epoch, static, step)
+            self._graphs[key] = ent
+            while len(self._graphs) > GRAPH_MAX_ENTRIES:
+                self._graphs.popitem(last=False)
+            return step().clone()                          # (a capture records the launches, it does not run them: replay once)
+        self._graphs.move_to_end(key)
+        for s_, t in zip(ent[1], inputs):
+            s_.copy_(t)
+        return ent[2]().clone()
+
     def forward_features(self, fl, fr, out_hw, training=False):
         self._training = bool(training)
         self._slot = self._pick_slot()
-        params = [p for p in self.model.parameters() if p.requires_grad and not self._is_fe_param(p)]
-        if training and torch.is_grad_enabled() and (fl.requires_grad or fr.requires_grad or params):
-            return _RegressorTrainFn.apply(self, tuple(out_hw), fl, fr, *params)
+        if fl.is_cuda and fl.shape == fr.shape and fl.dim() == 4 and self._graph_mode(fl.shape[0], training):
+            key = ("feat", tuple(fl.shape), tuple(out_hw), self.model.maxdisp, self.model.mindisp, getattr(self.model, "regressor_math", "auto"),
+                   getattr(self.model, "regressor_storage", "f32"))
+            return self._replay(key, (fl, fr), lambda a, b: self._forward_features_impl(a, b, out_hw, False))
+        if training and torch.is_grad_enabled():
+            params = [p for _, _, p in self._slots("p") if p.requires_grad and not self._is_fe_param(p)]
+            if fl.requires_grad or fr.requires_grad or params:
+                return _RegressorTrainFn.apply(self, tuple(out_hw), fl, fr, *params)
         return self._forward_features_impl(fl, fr, out_hw, training)
 
     def _is_fe_param(self, p):
@@ -893,9 +960,14 @@ class PSMNetRuntime:
     def forward_images(self, left, right, training=False):
         self._training = bool(training)
         self._slot = self._pick_slot()
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        if training and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or params):
-            return _PSMNetTrainFn.apply(self, left, right, *params)
+        if left.is_cuda and left.dim() == 4 and self._graph_mode(left.shape[0], training):
+            key = ("img", tuple(left.shape), self.model.maxdisp, self.model.mindisp, getattr(self.model, "regressor_math", "auto"),
+                   getattr(self.model, "regressor_storage", "f32"), getattr(self.model, "feature_storage", "f32"))
+            return self._replay(key, (left, right), lambda a, b: self._forward_images_impl(a, b, False))
+        if training and torch.is_grad_enabled():
+            params = [p for _, _, p in self._slots("p") if p.requires_grad]
+            if left.requires_grad or right.requires_grad or params:
+                return _PSMNetTrainFn.apply(self, left, right, *params)
         return self._forward_images_impl(left, right, training)
 
     def _forward_images_impl(self, left, right, training):

@@ -149,6 +149,14 @@ def main_r101_kitti():
         sample(out, f"kitti_c{i + 2}", f)
     for i, o in enumerate(outs):
         sample(out, f"kitti_p{i + 2}", o)
+    # the same reference modules in fp64: what the fp32 run above approximates (104 convolutions deep, its own rounding noise reaches
+    # 6e-4 * max|ref| at p5) -- recorded at the same sample positions, so that a test can hold an fp32 implementation to the reference's
+    # OWN distance from exact arithmetic instead of to a bound between two noisy fp32 runs
+    model.double()
+    with torch.no_grad():
+        outs64 = model(x.double())
+    for i, o in enumerate(outs64):
+        out[f"kitti_p{i + 2}_val64"] = o.reshape(-1)[torch.from_numpy(out[f"kitti_p{i + 2}_idx"])].numpy()
     print("R-101 kitti", [tuple(o.shape) for o in outs], float(outs[0].abs().mean()))
     np.savez_compressed(os.path.join(HERE, "backbone_r101_kitti_golden.npz"), **out)
 

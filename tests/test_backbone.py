@@ -121,8 +121,10 @@ def test_hip_backbone_r101_vs_reference_golden(tag):
 @pytest.mark.gpu
 def test_hip_backbone_r101_kitti_size_vs_reference_golden():
     """The shipped 2D config's conv body (R-101-FPN, configs/kitti/car/vob/mask.yaml:5) at the shipped input size, a 2 x 3 x 375 x 1242 stereo pair:
-    all five pyramid levels against the reference's torch-CPU output recorded by make_golden_backbone.py --r101-kitti (bound as for the small
-    R-101 cases: 6e-4 * max|ref| on 512 sampled values per level)."""
+    all five pyramid levels against the reference recorded by make_golden_backbone.py --r101-kitti.  104 convolutions deep the reference's own
+    fp32 run is 1.3e-4 (p2) .. 6.2e-4 (p5) * max|ref| away from its fp64 run (recorded next to it), so two fp32 implementations may differ by
+    more than either is wrong: the HIP trunk is held (a) to the fp64 values within 1.5x the reference-fp32's own distance (+1e-4), and (b) to the
+    reference-fp32 values within 1.5e-3 * max|ref| (a gross-error bound)."""
     dev = torch.device("cuda:0")
     m, _ = _model_and_state_r101()
     m = m.to(dev).eval()
@@ -132,4 +134,11 @@ def test_hip_backbone_r101_kitti_size_vs_reference_golden():
         outs = m(x)
     assert [tuple(o.shape[2:]) for o in outs] == [(94, 310), (47, 155), (24, 78), (12, 39), (6, 20)]
     for i, o in enumerate(outs):
-        _check(z, f"kitti_p{i + 2}", o, 6e-4)
+        tag = f"kitti_p{i + 2}"
+        got = o.detach().cpu().reshape(-1).double()[torch.from_numpy(z[tag + "_idx"])]
+        ref32, ref64 = torch.from_numpy(z[tag + "_val"]).double(), torch.from_numpy(z[tag + "_val64"]).double()
+        scale = max(1.0, ref64.abs().max().item())
+        e_hip, e_ref = (got - ref64).abs().max().item() / scale, (ref32 - ref64).abs().max().item() / scale
+        print(f"{tag}: HIP vs fp64 {e_hip:.2e}, reference fp32 vs fp64 {e_ref:.2e}, HIP vs reference fp32 {(got - ref32).abs().max().item() / scale:.2e}")
+        assert e_hip <= 1.5 * e_ref + 1e-4, (tag, e_hip, e_ref)
+        assert (got - ref32).abs().max().item() <= 1.5e-3 * scale
