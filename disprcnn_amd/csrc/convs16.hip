@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int n_ = lane & 31, g = lane >> 5;
     const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;      // this lane's voxel inside the MFMA tile (lanes >= RT*WT idle)
     const int r = wave / KW, k = wave % KW;     // MFMA tile of the workgroup, K slice
-    const int ct = blockIdx.y;                  // cout tile of 32
+    const int n_ct = p.cout / 32;
+    const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tile of 32: the tiles of one column set run side by side on ONE XCD (block b -> XCD b % 8), so the
+                                                      // input the second tile stages is an L2 hit (as separate grid.y passes the input came from HBM once per tile)
 
     const int D = p.D, H = p.H, W = p.W;
     const int Wp = W + 2, Hp = H + 2;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int n_xt = W / TX, n_yt = (H + RPW * RT - 1) / (RPW * RT);
     // XCD-aware order: block b runs on XCD b % 8; the 32 blocks of an XCD take 32 consecutive columns of the units n % 8 == xcd, so that the
     // row tiles sharing halo rows meet in one L2
-    const unsigned xcd = blockIdx.x & 7, qx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
 
     // ---- the columns of this workgroup, in order; the pipeline below runs through them WITHOUT draining at a column's end: the first two
@@ -235,12 +237,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     cx_prev.ok = false;
 
     f32x16 acc[3];
-    u32x4 resv[2];           // residual (hi, lo) of the plane finalized next step (KW == 4: low 8 bytes used)
+    u32x4 resv[3][2];        // residual (hi, lo) tiles, requested a full step before their use: slot J holds the tile requested in a step with t % 3 == J
 #pragma unroll
     for (int a_ = 0; a_ < 3; ++a_)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a_][e] = 0.f;
-    resv[0] = resv[1] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_) resv[a_][0] = resv[a_][1] = (u32x4){0u, 0u, 0u, 0u};
     stage(s_cur, 0, 0);
     stage(s_cur, 1 < D ? 1 : 0, 1);
     __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));      // plane 0 landed (step 0's own wait assumes a full previous step)
@@ -262,6 +265,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL + NS + NR, 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // contexts of the planes finalized / published in this step
+        const bool fcur = t >= 2, pcur = t >= 1;
+        const int qf = fcur ? t - 2 : D - 2 + t, qp = pcur ? t - 1 : D - 1;
+        const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc((void*)(pcur ? cx_cur.resb : cx_prev.resb), 0, nres, 0x00020000);
+        const unsigned p_o16 = pcur ? cx_cur.o16 : cx_prev.o16;
+        const bool p_ok = (pcur ? cx_cur.ok : cx_prev.ok) && qp >= 0 && qp < D;
+        if constexpr (RES) {
+            // the residual of the plane this step PUBLISHES (finalized in the next step): requested now, a whole step before its use
+            const unsigned po = p_ok ? (unsigned)((long)qp * planeB) : 0x80000000u;
+            if constexpr (KW == 2) {
+                resv[J][0] = __builtin_amdgcn_raw_buffer_load_b128(resr, p_o16 + po, 0, 0);
+                resv[J][1] = __builtin_amdgcn_raw_buffer_load_b128(resr, p_o16 + lo_off + po, 0, 0);
+            } else {
+                const u32x2 a_ = __builtin_amdgcn_raw_buffer_load_b64(resr, p_o16 + po, 0, 0);
+                const u32x2 b_ = __builtin_amdgcn_raw_buffer_load_b64(resr, p_o16 + lo_off + po, 0, 0);
+                resv[J][0] = (u32x4){a_.x, a_.y, 0u, 0u};
+                resv[J][1] = (u32x4){b_.x, b_.y, 0u, 0u};
+            }
+        }
         {   // slab t+2 (of the next column behind this one's last plane) into the slot of plane t-1: free since the barrier
             const int tp = t + 2;
             const bool nxt = tp >= D;
@@ -275,16 +297,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             pl = pl < D ? pl : D - 1;
             stage(q, pl, (J + 2) % 3);
         }
-        // contexts of the planes finalized / published in this step
-        const bool fcur = t >= 2, pcur = t >= 1;
-        const int qf = fcur ? t - 2 : D - 2 + t, qp = pcur ? t - 1 : D - 1;
         const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc(fcur ? cx_cur.y16b : cx_prev.y16b, 0, n16, 0x00020000);
         const __amdgpu_buffer_rsrc_t y32r = __builtin_amdgcn_make_buffer_rsrc(fcur ? cx_cur.y32b : cx_prev.y32b, 0, n32, 0x00020000);
-        const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc((void*)(pcur ? cx_cur.resb : cx_prev.resb), 0, nres, 0x00020000);
         const unsigned f_o16 = fcur ? cx_cur.o16 : cx_prev.o16, f_o32 = fcur ? cx_cur.o32 : cx_prev.o32;
         const bool f_ok = (fcur ? cx_cur.ok : cx_prev.ok) && qf >= 0 && qf < D;
-        const unsigned p_o16 = pcur ? cx_cur.o16 : cx_prev.o16;
-        const bool p_ok = (pcur ? cx_cur.ok : cx_prev.ok) && qp >= 0 && qp < D;
         // the K-split partial sums of the plane to finalize (published in the previous step), this wave's couts: registers k*OWN .. of
         // every K slice
         f32x4 part[4];
@@ -300,9 +316,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int q = 0; q < 4; ++q) part[q] = *(const f32x4*)(xb + q * XW + k * 1024);
             }
         }
-        // its residual was requested at the end of the previous step; only this step's DMAs are younger
-        __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));
-        __builtin_amdgcn_sched_barrier(0);
+        // its residual was requested at the head of the previous step: younger are that step's DMAs and stores and this step's requests
+        if constexpr (RES) {
+            __builtin_amdgcn_s_waitcnt(S16_WAITCNT(2 * NL + NS + NR, 15));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float v[OWN];
         _Float16 vh[OWN], vl[OWN];
         auto fin = [&](int e) __attribute__((always_inline)) {
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else s_ = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
             float x_ = s_ * sc[e] + sh[e];
             if constexpr (RES) {
-                const _Float16 rh = __builtin_bit_cast(f16x8, resv[0])[e], rl_ = __builtin_bit_cast(f16x8, resv[1])[e];
+                const _Float16 rh = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][0])[e], rl_ = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][1])[e];
                 x_ += (float)rh + (float)rl_;
             }
             x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);    // ReLU (relu_lo = 0) or the fp16 range of the hi part (relu_lo = -65504)
@@ -350,18 +368,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int q = 0; q < 4; ++q) *(f32x4*)(xb + q * 1024) = (f32x4){a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[A2][e] = 0.f;
-            if constexpr (RES) {
-                const unsigned po = p_ok ? (unsigned)((long)qp * planeB) : 0x80000000u;
-                if constexpr (KW == 2) {
-                    resv[0] = __builtin_amdgcn_raw_buffer_load_b128(resr, p_o16 + po, 0, 0);
-                    resv[1] = __builtin_amdgcn_raw_buffer_load_b128(resr, p_o16 + lo_off + po, 0, 0);
-                } else {
-                    const u32x2 a_ = __builtin_amdgcn_raw_buffer_load_b64(resr, p_o16 + po, 0, 0);
-                    const u32x2 b_ = __builtin_amdgcn_raw_buffer_load_b64(resr, p_o16 + lo_off + po, 0, 0);
-                    resv[0] = (u32x4){a_.x, a_.y, 0u, 0u};
-                    resv[1] = (u32x4){b_.x, b_.y, 0u, 0u};
-                }
-            }
         };
         if constexpr (COMPUTE) {
             constexpr bool K0 = KIND != 2, K2 = KIND != 1;          // taps kd = 0 (plane t+1 exists), kd = 2 (plane t-1 exists)
@@ -464,9 +470,10 @@ int launch2(const drc_s16conv_params& p, hipStream_t stream) {
     constexpr int rows = (4 / KW) * RT;
     const long columns = (long)p.N * ((p.H + rows - 1) / rows) * (p.W / WT);
     // one block per CU (the weights take the register file); a multiple of 8 so that every XCD runs the same number
-    long blocks = 256;
-    while (blocks > 8 && blocks / 2 >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT, RES, Y32>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
+    const int n_ct = p.cout / 32;
+    long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
+    while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
+    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT, RES, Y32>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
 

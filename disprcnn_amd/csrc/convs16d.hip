@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int n_ = lane & 31, g = lane >> 5;
     const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;
     const int r = wave / KW, k = wave % KW;
-    const int ct = blockIdx.y;
+    const int n_ct = p.cout / 32;
+    const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tiles side by side on one XCD (see convs16.hip)
 
     // input geometry (p.D, p.H, p.W) -> output (D/2, H/2, W/2)
     const int Di = p.D, Hi = p.H, Wi = p.W;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef const __attribute__((address_space(3))) f16x8 lds_frag;
 
     const int n_xt = Wo / WT, n_yt = (Ho + RPW * RT - 1) / (RPW * RT);
-    const unsigned xcd = blockIdx.x & 7, qx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
     const float relu_lo = p.relu ? 0.f : -3.0e38f;
 
@@ -295,9 +296,10 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
     }
     const int Ho = p.H / 2, Wo = p.W / 2;
     const long columns = (long)p.N * ((Ho + RPW * RT - 1) / (RPW * RT)) * (Wo / WT);
-    long blocks = 256;
-    while (blocks > 8 && blocks / 2 >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16d_kernel<KW, RT, WT, RING>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
+    const int n_ct = p.cout / 32;
+    long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
+    while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
+    hipLaunchKernelGGL((convs16d_kernel<KW, RT, WT, RING>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
 

@@ -78,7 +78,8 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
 
     const int n_ = lane & 31, g = lane >> 5;
     const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;
-    const int ct = blockIdx.y;
+    const int n_ct = p.cout / 32;
+    const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tiles side by side on one XCD (see convs16.hip)
     const int Di = p.D, Hi = p.H, Wi = p.W;
     const int Wpi = Wi + 2, Hpi = Hi + 2;
     const long i_rowB = (long)Wpi * 128, i_planeB = (long)Hpi * i_rowB, i_cbB = (long)(Di + 2) * i_planeB, i_nB = 2 * i_cbB;
@@ -117,9 +118,9 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
     typedef const __attribute__((address_space(3))) f32x4 lds_f4;
 
     const int n_xt = Wi / WT, n_yt = (Hi + RT - 1) / RT;
-    const unsigned xcd = blockIdx.x & 7, qx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
-    const float relu_lo = p.relu ? 0.f : -3.0e38f;
+    const float relu_lo = p.relu ? 0.f : -65504.f;
 
     for (unsigned it = 0;; ++it) {
         const unsigned j = it * per_xcd + qx;
@@ -158,10 +159,33 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+        // residual tiles are requested ONE STEP before their use (two register sets by the step's parity): output offsets of the planes a
+        // step at input plane zi finishes -- pz = 0 classes: 2 zi; pz = 1 classes: 2 zi - 1 -- and the 4 NF loads
+        u32x4 resv[2][NF][4];
+        auto offsets_of = [&](int zi, bool compute, unsigned (&fo)[NF]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ci = 0; ci < NF; ++ci) {
+                const int c = R.cls[ci], pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+                const int zo = pz ? 2 * zi - 1 : 2 * zi;
+                const bool ok = lane_ok && zo >= 0 && zo < 2 * Di && (compute || pz);
+                fo[ci] = ok ? o_lane + (unsigned)((long)zo * o_planeB + (long)py * o_rowB + px * 16) : 0x80000000u;
+            }
+        };
+        auto request = [&](int zi, auto ST) __attribute__((always_inline)) {        // the residual tiles of the step at input plane zi -> set ST
+            constexpr int S_ = decltype(ST)::value;
+            unsigned fo[NF];
+            offsets_of(zi, zi < Di, fo);
+#pragma unroll
+            for (int ci = 0; ci < NF; ++ci)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)      // q: (lo?, s): chunks s*2 (+g in o_lane), + 4 for lo
+                    resv[S_][ci][q] = __builtin_amdgcn_raw_buffer_load_b128(resr, fo[ci] + (unsigned)(((q >> 1) * 4 + (q & 1) * 2) * o_chunkB), 0, 0);
+        };
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(S16_WAITCNT(63, 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        request(0, std::integral_constant<int, 0>{});
 #pragma unroll
         for (int s_ = 0; s_ + 1 < RING; ++s_) stage(s_, s_);
         __builtin_amdgcn_s_waitcnt(S16_WAITCNT((RING - 2) * NL, 15));      // plane 0 landed (step 0's own wait counts a previous step's stores)
@@ -175,19 +199,10 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
             __builtin_amdgcn_s_waitcnt(S16_WAITCNT((RING - 2) * NL + NS, 0));
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // output planes finished in this step, per class slot: pz = 0: 2 zi; pz = 1: 2 zi - 1
+            // output planes finished in this step (their residual tiles were requested one step ago into set P); the next step's go out now
             unsigned fo[NF];
-            u32x4 resv[NF][4];
-#pragma unroll
-            for (int ci = 0; ci < NF; ++ci) {
-                const int c = R.cls[ci], pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
-                const int zo = pz ? 2 * zi - 1 : 2 * zi;
-                const bool ok = lane_ok && zo >= 0 && (COMPUTE || pz);
-                fo[ci] = ok ? o_lane + (unsigned)((long)zo * o_planeB + (long)py * o_rowB + px * 16) : 0x80000000u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)      // q: (lo?, s): chunks s*2 (+g in o_lane), + 4 for lo
-                    resv[ci][q] = __builtin_amdgcn_raw_buffer_load_b128(resr, fo[ci] + (unsigned)(((q >> 1) * 4 + (q & 1) * 2) * o_chunkB), 0, 0);
-            }
+            offsets_of(zi, COMPUTE, fo);
+            request(zi + 1, std::integral_constant<int, P ^ 1>{});
             {
                 int ns = slot + RING - 1; ns = ns >= RING ? ns - RING : ns;
                 stage(zi + RING - 1, ns);
@@ -212,8 +227,9 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
                 for (int t = 0; t < NT; ++t)
                     if (!TL.t[t].open) run_tap(t);
             }
-            // the residual tiles were requested before this step's DMAs
-            __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));
+            // this step's residual tiles were requested at the head of the PREVIOUS step: younger are that step's DMAs and stores and this step's
+            // requests and DMAs
+            __builtin_amdgcn_s_waitcnt(S16_WAITCNT(2 * NL + 2 * NS, 15));
             __builtin_amdgcn_sched_barrier(0);
             // ---- epilogues of the finished accumulators (in the shadow of the opening taps below)
 #pragma unroll
@@ -226,13 +242,13 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
                 for (int s = 0; s < 2; ++s) {
                     const f32x4 sc0 = *(lds_f4*)(bnl + g * 32 + s * 8), sc1 = *(lds_f4*)(bnl + g * 32 + s * 8 + 4);
                     const f32x4 sh0 = *(lds_f4*)(bnl + g * 32 + 16 + s * 8), sh1 = *(lds_f4*)(bnl + g * 32 + 16 + s * 8 + 4);
-                    const f16x8 rh = __builtin_bit_cast(f16x8, resv[ci][s]), rl_ = __builtin_bit_cast(f16x8, resv[ci][2 + s]);
+                    const f16x8 rh = __builtin_bit_cast(f16x8, resv[P][ci][s]), rl_ = __builtin_bit_cast(f16x8, resv[P][ci][2 + s]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float sc_ = e < 4 ? sc0[e & 3] : sc1[e & 3], sh_ = e < 4 ? sh0[e & 3] : sh1[e & 3];
                         float x_ = a[s * 8 + e] * sc_ + sh_;
                         x_ += (float)rh[e] + (float)rl_[e];
-                        x_ = fmaxf(fminf(fmaxf(x_, relu_lo), 65504.f), -65504.f);
+                        x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);
                         hi[s][e] = (_Float16)x_;
                         lo[s][e] = (_Float16)(x_ - (float)hi[s][e]);
                     }
@@ -291,9 +307,10 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
         attr_done = true;
     }
     const long columns = (long)p.N * ((p.H + RT - 1) / RT) * (p.W / WT);
-    long blocks = 256;
-    while (blocks > 8 && blocks / 2 >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16u_kernel<RT, WT>), dim3((unsigned)blocks, (unsigned)(p.cout / 32)), dim3(256), lds, stream, p);
+    const int n_ct = p.cout / 32;
+    long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
+    while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
+    hipLaunchKernelGGL((convs16u_kernel<RT, WT>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
 

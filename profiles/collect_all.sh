@@ -8,7 +8,7 @@
 # are copied to gpurun_out/profiles_<tag>/ -- copy them from there into profiles/ and commit; profiles/check_profiles.py fails if any
 # <tag>_*_pmc.md came out without rows.
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 ONLY=${2:-}      # optional: space-separated list of workloads
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export PROF_COMMIT=$(cat profiles/.head 2>/dev/null || echo unknown)

@@ -30,8 +30,39 @@ VARIANTS["nofin_nopub_nobar"] = VARIANTS["nofin"] + VARIANTS["nopub"] + VARIANTS
 VARIANTS["mfma_only"] = VARIANTS["nofin"] + VARIANTS["nopub"] + VARIANTS["nobar"] + VARIANTS["nostage"] + VARIANTS["nostore"]
 
 
+# ---- the transposed-conv kernel (convs16u.hip), hourglass conv6 shape (64 -> 32, input 6 x 14 x 14), same method
+SRC_U = os.path.join(ROOT, "disprcnn_amd", "csrc", "convs16u.hip")
+VARIANTS_U = {
+    "u_base": [],
+    "u_nostore": [("                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi[s]), y16r, fo[ci] + (unsigned)((s * 2) * o_chunkB), 0, 0);\n"
+                   "                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo[s]), y16r, fo[ci] + (unsigned)((4 + s * 2) * o_chunkB), 0, 0);",
+                   "                    { const u32x4 h4 = __builtin_bit_cast(u32x4, hi[s]), l4 = __builtin_bit_cast(u32x4, lo[s]);\n"
+                   "                      asm volatile(\"\" :: \"v\"(h4.x), \"v\"(h4.y), \"v\"(h4.z), \"v\"(h4.w), \"v\"(l4.x), \"v\"(l4.y), \"v\"(l4.z), \"v\"(l4.w), \"v\"(fo[ci])); }")],   # (values kept alive: without them the MFMAs are dead code)
+    "u_nores": [("                    resv[S_][ci][q] = __builtin_amdgcn_raw_buffer_load_b128(resr, fo[ci] + (unsigned)(((q >> 1) * 4 + (q & 1) * 2) * o_chunkB), 0, 0);",
+                 "                    resv[S_][ci][q] = (u32x4){0u, 0u, 0u, 0u};")],
+    "u_nobar": [("            __builtin_amdgcn_s_barrier();\n            asm volatile(\"\" ::: \"memory\");\n            // output planes finished in this step", "            asm volatile(\"\" ::: \"memory\");\n            // output planes finished in this step")],
+    "u_nostage": [("                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + srcoff), LDS_PTR(dst + cc * CPB), 16, 0, 0);", "                asm volatile(\"\" :: \"v\"(src), \"s\"(dst));")],
+}
+VARIANTS_U["u_nostore_nores"] = VARIANTS_U["u_nostore"] + VARIANTS_U["u_nores"]
+VARIANTS_U["u_mfma_only"] = VARIANTS_U["u_nostore"] + VARIANTS_U["u_nores"] + VARIANTS_U["u_nobar"] + VARIANTS_U["u_nostage"]
+
+
 def build():
     os.makedirs(OUT, exist_ok=True)
+    if os.environ.get("WHICH") == "u":
+        srcu = open(SRC_U).read().replace('#include "../../include/disprcnn_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "disprcnn_hip.h"))
+        for name, subs in VARIANTS_U.items():
+            s = srcu
+            for a, b in subs:
+                assert a in s, (name, a[:70])
+                s = s.replace(a, b)
+            f = os.path.join(OUT, f"s16_{name}.hip")
+            open(f, "w").write(s)
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-pass-failed", "-shared",
+                                   "-o", os.path.join(OUT, f"libs16_{name}.so"), f])
+            os.remove(f)
+            print("built", name, flush=True)
+        return
     src = open(SRC).read().replace('#include "../../include/disprcnn_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "disprcnn_hip.h"))
     for name, subs in VARIANTS.items():
         s = src
@@ -46,7 +77,45 @@ def build():
         print("built", name, flush=True)
 
 
+def run_u():
+    import torch
+    sys.path.insert(0, ROOT)
+    from disprcnn_amd import s16
+    from disprcnn_amd._lib import DrcS16ConvParams
+    dev = torch.device("cuda:0")
+    N, cin, cout, D, H, W = 1024, 64, 32, 6, 14, 14
+    w = torch.randn(cin, cout, 3, 3, 3) * 0.05
+    wp, wexp = s16.pack_weight_s16(w.to(dev).transpose(0, 1).contiguous())
+    sc = torch.full((cout,), 2.0 ** -wexp, device=dev); sh = torch.zeros(cout, device=dev)
+
+    def rnd(cb, d, h, w_):
+        t = torch.zeros(N, cb, d + 2, h + 2, 8, w_ + 2, 8, dtype=torch.float16, device=dev)
+        t[:, :, 1:d + 1, 1:h + 1, :, 1:w_ + 1].normal_()
+        t[:, :, 1:d + 1, 1:h + 1, 4:, 1:w_ + 1] *= 2.0 ** -11
+        return t
+    x, res = rnd(2, D, H, W), rnd(1, 2 * D, 2 * H, 2 * W)
+    y = torch.zeros_like(res)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    p = DrcS16ConvParams(P(x), P(wp), P(sc), P(sh), P(res), P(y), None, None, None, N, D, H, W, cin, cout, 0, 0)
+    for name in VARIANTS_U:
+        lib = C.CDLL(os.path.join(OUT, f"libs16_{name}.so"))
+        fn = lib.drc_deconv3d_k3s2_s16_fwd
+        fn.restype = C.c_int; fn.argtypes = [C.POINTER(DrcS16ConvParams), C.c_void_p]
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for _ in range(3):
+            assert fn(C.byref(p), st) == 0
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in ev:
+            a.record(); fn(C.byref(p), st); b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in ev)
+        print(f"{name:22s} median {ts[5] * 1e3:8.1f} us  min {ts[0] * 1e3:8.1f} us", flush=True)
+
+
 def run():
+    if os.environ.get("WHICH") == "u":
+        return run_u()
     import torch
     sys.path.insert(0, ROOT)
     from disprcnn_amd import s16
