@@ -102,6 +102,31 @@ __global__ void rs16_to_dense_kernel(const _Float16* __restrict__ y, float* __re
     }
 }
 
+// RS16 -> blocked fp32 [units][CB16 total][D+2pdo][H+2pho][W+2pwo][16] (channel blocks cb16_off .. of it; interior only): where a split-f16
+// layer hands its result to an fp32 kernel (the stride-2 / 1x1 / dilated layers of the 2D CNN, the concat of submodule.py:134-135)
+__global__ void rs16_to_blocked_kernel(const _Float16* __restrict__ y, float* __restrict__ x, int N, int C, int D, int H, int W, int pdo, int pho,
+                                       int pwo, int cb16_total, int cb16_off, int pd) {
+    const long total = (long)N * (C / 32) * D * H * 4 * W;
+    const int Wp = W + 2, Hp = H + 2, Dp = D + 2 * pd;
+    const long xw_ = W + 2 * pwo, xh_ = H + 2 * pho, xd_ = D + 2 * pdo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int sg = (int)(t % 4); t /= 4;
+        const int xw = (int)(t % W); t /= W;
+        const int yh = (int)(t % H); t /= H;
+        const int z = (int)(t % D); t /= D;
+        const int cb = (int)(t % (C / 32));
+        const int n = (int)(t / (C / 32));
+        const int s = sg >> 1, g = sg & 1;
+        const _Float16* row = y + (((((long)n * (C / 32) + cb) * Dp + z + pd) * Hp + yh + 1) * 8) * (long)Wp * 8;
+        const f16x8 hi = *(const f16x8*)(row + ((long)sg * Wp + xw + 1) * 8);
+        const f16x8 lo = *(const f16x8*)(row + ((long)(4 + sg) * Wp + xw + 1) * 8);
+        float* dst = x + (((((long)n * cb16_total + cb16_off + 2 * cb + s) * xd_ + z + pdo) * xh_ + yh + pho) * xw_ + xw + pwo) * 16 + 4 * g;
+        *(f32x4*)dst = (f32x4){(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+        *(f32x4*)(dst + 8) = (f32x4){(float)hi[4] + (float)lo[4], (float)hi[5] + (float)lo[5], (float)hi[6] + (float)lo[6], (float)hi[7] + (float)lo[7]};
+    }
+}
+
 inline unsigned grid_for(long total) {
     long b = (total + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 256 * 32 ? 256 * 32 : b));
@@ -134,5 +159,17 @@ extern "C" int drc_rs16_to_dense(const void* y16, float* x, int N, int C, int D,
     if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1) return -2;
     if (N == 0) return 0;
     hipLaunchKernelGGL(rs16_to_dense_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)y16, x, N, C, D, H, W, pd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int drc_rs16_to_blocked(const void* y16, float* xb, int N, int C, int D, int H, int W, int pd_out, int ph_out, int pw_out, int cb16_total,
+                                   int cb16_off, int pd, void* stream) {
+    if (!xb || !y16) return -1;
+    if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1 || pd_out < 0 || ph_out < 0 || pw_out < 0 || cb16_off < 0 ||
+        cb16_off + C / 16 > cb16_total)
+        return -2;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(rs16_to_blocked_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)y16, xb, N, C,
+                       D, H, W, pd_out, ph_out, pw_out, cb16_total, cb16_off, pd);
     return (int)hipGetLastError();
 }

@@ -89,6 +89,18 @@ class Blocked:
         _lib.check(st, "drc_dense_to_blocked")
         return self
 
+    def to_blocked(self, blk, first_unit=0):
+        """interior -> units [first_unit, first_unit + N) of a blocked fp32 tensor (or channel slice) of the same logical shape."""
+        base = getattr(blk, "base", blk)
+        if (blk.C, blk.D, blk.H, blk.W) != (self.C, self.D, self.H, self.W) or base.N < first_unit + self.N:
+            raise ValueError("RS16.to_blocked: shapes differ")
+        if self.N:
+            dst = C.c_void_p(base.storage.data_ptr() + 4 * first_unit * base.n_stride)
+            st = _lib.lib().drc_rs16_to_blocked(_ptr(self.storage), dst, self.N, self.C, self.D, self.H, self.W, base.pd, base.ph, base.pw, base.cb,
+                                                getattr(blk, "cb_off", 0), self.pd, _stream_ptr(self.device))
+            _lib.check(st, "drc_rs16_to_blocked")
+        return blk
+
     def to_dense(self):
         shape = (self.N, self.C, self.D, self.H, self.W)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -1386,6 +1398,18 @@ class RS16:
             _lib.check(st, "drc_rs16_from_blocked")
         return self
 
+    def to_blocked(self, blk, first_unit=0):
+        """interior -> units [first_unit, first_unit + N) of a blocked fp32 tensor (or channel slice) of the same logical shape."""
+        base = getattr(blk, "base", blk)
+        if (blk.C, blk.D, blk.H, blk.W) != (self.C, self.D, self.H, self.W) or base.N < first_unit + self.N:
+            raise ValueError("RS16.to_blocked: shapes differ")
+        if self.N:
+            dst = C.c_void_p(base.storage.data_ptr() + 4 * first_unit * base.n_stride)
+            st = _lib.lib().drc_rs16_to_blocked(_ptr(self.storage), dst, self.N, self.C, self.D, self.H, self.W, base.pd, base.ph, base.pw, base.cb,
+                                                getattr(blk, "cb_off", 0), self.pd, _stream_ptr(self.device))
+            _lib.check(st, "drc_rs16_to_blocked")
+        return blk
+
     def to_dense(self):
         shape = (self.N, self.C, self.D, self.H, self.W)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -1395,8 +1419,11 @@ class RS16:
         return out
 
 
-def s16_supported(cin, cout, D, H, W, kind="s1"):
-    """kind: "s1" stride-1 conv, "s2" stride-2 conv, "up" transposed conv (D, H, W = the layer's INPUT dims)."""
+def s16_supported(cin, cout, D, H, W, kind="s1", dil=1):
+    """kind: "s1" stride-1 conv, "s2" stride-2 conv, "up" transposed conv (D, H, W = the layer's INPUT dims); "2d": the stride-1 3x3 conv on
+    2D maps (D = 1)."""
+    if kind == "2d":
+        return bool(S16["enabled"] and D == 1 and _lib.lib().drc_conv2d_k3_s16_supported(cin, cout, H, W, dil))
     fn = {"s1": "drc_conv3d_k3_s16_supported", "s2": "drc_conv3d_k3s2_s16_supported", "up": "drc_deconv3d_k3s2_s16_supported"}[kind]
     return bool(S16["enabled"] and getattr(_lib.lib(), fn)(cin, cout, D, H, W))
 
@@ -1404,22 +1431,31 @@ def s16_supported(cin, cout, D, H, W, kind="s1"):
 class ConvPlanS16:
     """One launch of the split-f16 3x3x3 kernels on RS16 tensors (+BN, +residual, +ReLU): kind "s1" drc_conv3d_k3_s16_fwd (cv: the cost
     volume of the left / right 2D feature maps is the virtual input, reference stackhourglass.py:115-130), "s2" drc_conv3d_k3s2_s16_fwd,
-    "up" drc_deconv3d_k3s2_s16_fwd.  D, H, W = the INPUT dims."""
+    "up" drc_deconv3d_k3s2_s16_fwd; "2d": drc_conv2d_k3_s16_fwd on RS16 2D maps (D = 1, no depth halo; the 3x3 stride-1 layers of the feature
+    CNN, reference submodule.py:9-16).  D, H, W = the INPUT dims."""
 
-    def __init__(self, N, cin, cout, D, H, W, relu, cv=False, device=None, kind="s1"):
-        if not s16_supported(cin, cout, D, H, W, kind) or (cv and (cin != 64 or kind != "s1" or W % 28)):
+    def __init__(self, N, cin, cout, D, H, W, relu, cv=False, device=None, kind="s1", dil=1):
+        if not s16_supported(cin, cout, D, H, W, kind, dil) or (cv and (cin != 64 or kind != "s1" or W % 28)) or (dil != 1 and kind != "2d"):
             raise ValueError("ConvPlanS16: unsupported shape")
+        self.dil = dil
         self.N, self.cin, self.cout, self.D, self.H, self.W, self.relu, self.cv, self.device, self.kind = N, cin, cout, D, H, W, bool(relu), cv, device, kind
-        self.out_dhw = {"s1": (D, H, W), "s2": (D // 2, H // 2, W // 2), "up": (2 * D, 2 * H, 2 * W)}[kind]
+        self.out_dhw = {"s1": (D, H, W), "s2": (D // 2, H // 2, W // 2), "up": (2 * D, 2 * H, 2 * W), "2d": (1, H, W)}[kind]
+        self.pd = 0 if kind == "2d" else 1
         vox = D * H * W if kind != "s2" else (D // 2) * (H // 2) * (W // 2)
-        self.flops = 2 * N * vox * 27 * cin * cout
+        self.flops = 2 * N * vox * (9 if kind == "2d" else 27) * cin * cout
         rt, wt = (1, 28)
-        nw = {"s1": W, "s2": W // 2, "up": W}[kind]
+        nw = {"s1": W, "s2": W // 2, "up": W, "2d": W}[kind]
         if nw in (14, 7):
             rt, wt = (2, 14) if nw == 14 else (4, 7)
         if kind == "s1":
             self._kfmt = "convs16_kernel<%d,%s,%d,%d,%%s,%%s>" % (cin // 16, "true" if cv else "false", rt, wt)
             self.kname = self._kfmt % ("false", "false")          # (the residual / blocked-fp32-output template flags follow the call's arguments)
+        elif kind == "2d":
+            # convs16r.hip's dispatch: (waves over K, K slices per wave)
+            wide = cin == 64 and W % 56 == 0 and cout == 128 and N * (H // 28) * (W // 56) * (cout // 32) >= 256
+            kw, ks = {32: (2, 1), 128: (4, 2)}.get(cin, (2, 2) if wide else (4, 1))
+            self._kfmt = "convs16r_kernel<%d,%d,%%s,%d>" % (kw, ks, dil)
+            self.kname = self._kfmt % "false"
         elif kind == "s2":
             ring = 3 if (cin == 32 and nw in (14, 7)) else 2                    # convs16d.hip's dispatch: what fits the LDS
             self.kname = "convs16d_kernel<%d,%d,%d,%d>" % (cin // 16, rt, wt, ring)
@@ -1428,11 +1464,13 @@ class ConvPlanS16:
 
     def run(self, x16, w16, scale, shift, y16=None, y32=None, res=None, left=None, right=None, lo4=0):
         from ._lib import DrcS16ConvParams
-        if x16 is not None and (x16.N < self.N or (x16.C, x16.D, x16.H, x16.W, x16.pd) != (self.cin, self.D, self.H, self.W, 1)):
+        if x16 is not None and (x16.N < self.N or (x16.C, x16.D, x16.H, x16.W, x16.pd) != (self.cin, self.D, self.H, self.W, self.pd)):
             raise ValueError("ConvPlanS16.run: input geometry differs from the plan")
         for t_ in (y16, res):
-            if t_ is not None and (t_.N < self.N or (t_.C, t_.D, t_.H, t_.W, t_.pd) != (self.cout,) + self.out_dhw + (1,)):
+            if t_ is not None and (t_.N < self.N or (t_.C, t_.D, t_.H, t_.W, t_.pd) != (self.cout,) + self.out_dhw + (self.pd,)):
                 raise ValueError("ConvPlanS16.run: output / residual geometry differs from the plan")
+        if self.kind == "2d" and (y16 is None or y32 is not None or x16 is None):
+            raise ValueError("ConvPlanS16.run: the 2D kernel reads and writes RS16 maps")
         if y32 is not None and (self.kind != "s1" or (y32.C, y32.D, y32.H, y32.W, y32.pd, y32.ph, y32.pw) != (self.cout, self.D, self.H, self.W, 1, 1, 1) or getattr(y32, "cb_off", 0)):
             raise ValueError("ConvPlanS16.run: the blocked fp32 output (stride-1 kernel only) must be a whole tensor with halo 1")
         if self.kind != "s1" and (y16 is None or (res is not None and self.kind == "s2")):
@@ -1446,15 +1484,20 @@ class ConvPlanS16:
         p = DrcS16ConvParams(_ptr(x16.storage) if x16 is not None else None, _ptr(w16), _ptr(scale), _ptr(shift),
                              _ptr(res.storage) if res is not None else None, _ptr(y16.storage) if y16 is not None else None,
                              _ptr(y32.storage) if y32 is not None else None, _ptr(left.storage) if self.cv else None,
-                             _ptr(right.storage) if self.cv else None, self.N, self.D, self.H, self.W, self.cin, self.cout, int(self.relu), int(lo4))
+                             _ptr(right.storage) if self.cv else None, self.N, self.D, self.H, self.W, self.cin, self.cout, int(self.relu), int(lo4), int(self.dil))
         dev = self.device
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        fn = {"s1": "drc_conv3d_k3_s16_fwd", "s2": "drc_conv3d_k3s2_s16_fwd", "up": "drc_deconv3d_k3s2_s16_fwd"}[self.kind]
+        fn = {"s1": "drc_conv3d_k3_s16_fwd", "s2": "drc_conv3d_k3s2_s16_fwd", "up": "drc_deconv3d_k3s2_s16_fwd", "2d": "drc_conv2d_k3_s16_fwd"}[self.kind]
         st = getattr(_lib.lib(), fn)(C.byref(p), _stream_ptr(dev))
         _lib.check(st, fn)
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(dev))
-            kn = self._kfmt % ("true" if res is not None else "false", "true" if y32 is not None else "false") if self.kind == "s1" else self.kname
+            if self.kind == "s1":
+                kn = self._kfmt % ("true" if res is not None else "false", "true" if y32 is not None else "false")
+            elif self.kind == "2d":
+                kn = self._kfmt % ("true" if res is not None else "false")
+            else:
+                kn = self.kname
             TIMING.append((kn, self.flops, e0, e1))

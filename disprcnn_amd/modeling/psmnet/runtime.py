@@ -782,6 +782,11 @@ class PSMNetRuntime:
                 sched.append((u + ".conv2", u + ".conv2", mid, u + ".out", res))   # out += x, no trailing relu
                 cur, cur_c, cur_hw = u + ".out", planes, hw
         skip = cur
+        return self._ws_put(key, self._ws2d_tail(t, p, B2, pool, sched, skip, H4, W4))
+
+    @staticmethod
+    def _ws2d_tail(t, p, B2, pool, sched, skip, H4, W4):
+        """The SPP branches and lastconv of a 2D workspace (shared by the fp32 and the split-f16 schedules)."""
         # SPP: concat order (raw, skip, b4, b3, b2, b1) -> channel blocks 0-3, 4-11, 12-13, 14-15, 16-17, 18-19
         slot = {"branch4": 12, "branch3": 14, "branch2": 16, "branch1": 18}
         spp = []
@@ -795,8 +800,141 @@ class PSMNetRuntime:
         t["feat"] = B2(32, H4, W4, 1)
         p["fe.lastconv.0"] = E.plan_conv2d(t["cat"], t["last0"], 3, 1, 1, 1, 128, True)
         p["fe.lastconv.2"] = E.plan_conv2d(t["last0"], t["feat"], 1, 1, 0, 1, 32, False)
-        ws = dict(t=t, p=p, pool=pool, sched=sched, spp=spp, skip=skip, dims=(H4, W4),
-                  flops=sum(pl.flops for pl in p.values()))
+        return dict(t=t, p=p, pool=pool, sched=sched, spp=spp, skip=skip, dims=(H4, W4),
+                    flops=sum(pl.flops for pl in p.values()) + sum(e[1].flops for e in sched if e[0] == "s16"))
+
+    # ------------------------------------------------------------------ split-f16 2D feature CNN (eval; convs16r.hip)
+    def _use_s16_2d(self, training, H, W):
+        """Eval: the stride-1 3x3 layers of feature_extraction but lastconv (firstconv[2], [4], layer1, layer2 but its first conv, layer3, and
+        -- maps of a multiple of 56 rows -- the dilated layer4: 89 % of the CNN's FLOPs) run in split-f16 arithmetic on the f16 matrix cores (convs16r.hip: fp32-class results) when the maps
+        are multiples of 28 rows / 56 columns; PSMNet.feature_math = "f32" keeps the fp32 MFMA kernels for all of them."""
+        mode = getattr(self.model, "feature_math", "auto")
+        if mode not in ("auto", "f32", "f16x2"):
+            raise ValueError("PSMNet.feature_math must be 'auto', 'f32' or 'f16x2'")
+        ok = (not training and self._tape is None and H % 4 == 0 and W % 4 == 0 and H // 4 >= 56 and W // 4 >= 56 and
+              E.s16_supported(32, 32, 1, H // 2, W // 2, "2d") and E.s16_supported(64, 64, 1, H // 4, W // 4, "2d") and
+              E.s16_supported(64, 128, 1, H // 4, W // 4, "2d") and E.s16_supported(128, 128, 1, H // 4, W // 4, "2d"))
+        if mode == "f16x2" and not ok:
+            raise RuntimeError("PSMNet.feature_math = 'f16x2': eval only; H/4 a multiple of 28 and W/4 a multiple of 56")
+        return ok and mode != "f32"
+
+    def _ws2d_eval(self, N, H, W):
+        return self._ws2d_s16(N, H, W) if self._use_s16_2d(False, H, W) else self._ws2d(N, H, W)
+
+    def _ws2d_s16(self, N, H, W):
+        """The schedule of _ws2d with the stride-1 undilated 3x3 layers on RS16 maps.  Entries: ("s16", plan, weight key, x, y, res) a
+        split-f16 layer; ("to16", blocked, rs16) / ("to32", rs16, blocked) the layout converters at the seams to the fp32 kernels (the
+        stride-2 conv and the 1x1 downsamples of layer2 / layer3, the dilated layer4, the concat); 5-tuples: fp32 sites as in _ws2d."""
+        key = self._slotted(("2ds16", N, H, W))
+        ws = self._ws_get(key)
+        if ws is not None:
+            return ws
+        pool = self._pool_for(self._slotted(("2ds16", H, W)), N)
+        names = iter(range(1 << 30))
+        B2 = lambda c, h, w, pad=1: pool.blocked(("t", next(names)), N, c, 1, h, w, 0, pad, pad)
+        S2 = lambda name, c, h, w: pool.rs16(("s", name), N, c, 1, h, w, 0)
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        t, p = {}, {}
+        t["img"] = B2(3, H, W)
+        t["f0"] = B2(32, H2, W2)
+        p["fe.firstconv.0"] = E.plan_conv2d(t["img"], t["f0"], 3, 2, 1, 1, 32, True)
+        t["cat"] = B2(320, H4, W4)
+        sched = []
+        plans = {}
+
+        def s16(wname, x, y, res, cin, cout, h, w, relu):
+            k = (cin, cout, h, w, relu)
+            if k not in plans:
+                plans[k] = E.ConvPlanS16(N, cin, cout, 1, h, w, relu, device=self.device, kind="2d")
+            sched.append(("s16", plans[k], wname, x, y, res))
+
+        # firstconv[2], [4] and layer1: 32 channels at half resolution, three rotating maps
+        for i in range(3):
+            t[f"a{i}"] = S2(f"a{i}", 32, H2, W2)
+        sched.append(("to16", "f0", "a0"))
+        s16("fe.firstconv.2", "a0", "a1", None, 32, 32, H2, W2, True)
+        s16("fe.firstconv.4", "a1", "a2", None, 32, 32, H2, W2, True)
+        cur, free = "a2", ["a0", "a1"]
+        for b in range(TRUNK_STAGES[0][2]):
+            u = f"fe.layer1.{b}"
+            mid, out = free
+            s16(u + ".conv1", cur, mid, None, 32, 32, H2, W2, True)
+            s16(u + ".conv2", mid, out, cur, 32, 32, H2, W2, False)
+            cur, free = out, [mid, cur]
+        # layer2: the stride-2 conv and the 1x1 downsample of its first block stay fp32
+        t["l2in"] = B2(32, H2, W2)
+        t["l2mid"], t["l2sc"] = B2(64, H4, W4), B2(64, H4, W4)
+        sched.append(("to32", cur, "l2in"))
+        u = "fe.layer2.0"
+        p[u + ".conv1"] = E.plan_conv2d(t["l2in"], t["l2mid"], 3, 2, 1, 1, 64, True)
+        sched.append((u + ".conv1", u + ".conv1", "l2in", "l2mid", None))
+        p[u + ".down"] = E.plan_conv2d(t["l2in"], t["l2sc"], 1, 2, 0, 1, 64, False)
+        sched.append((u + ".down", u + ".down", "l2in", "l2sc", None))
+        for i in range(3):
+            t[f"b{i}"] = S2(f"b{i}", 64, H4, W4)
+        sched.append(("to16", "l2mid", "b0"))
+        sched.append(("to16", "l2sc", "b1"))
+        s16(u + ".conv2", "b0", "b2", "b1", 64, 64, H4, W4, False)
+        cur, free = "b2", ["b0", "b1"]
+        for b in range(1, TRUNK_STAGES[1][2]):
+            u = f"fe.layer2.{b}"
+            mid, out = free
+            s16(u + ".conv1", cur, mid, None, 64, 64, H4, W4, True)
+            s16(u + ".conv2", mid, out, cur, 64, 64, H4, W4, False)
+            cur, free = out, [mid, cur]
+        # output_raw -> channels 0..63 of the concat (fp32), which is also the input of layer3's 1x1 downsample
+        t["raw"] = E.BlockedSlice(t["cat"], 0, 64)
+        sched.append(("to32", cur, "raw"))
+        t["l3sc"] = B2(128, H4, W4)
+        u = "fe.layer3.0"
+        p[u + ".down"] = E.plan_conv2d(t["raw"], t["l3sc"], 1, 1, 0, 1, 128, False)
+        sched.append((u + ".down", u + ".down", "raw", "l3sc", None))
+        for i in range(3):
+            t[f"c{i}"] = S2(f"c{i}", 128, H4, W4)
+        sched.append(("to16", "l3sc", "c1"))
+        s16(u + ".conv1", cur, "c0", None, 64, 128, H4, W4, True)
+        s16(u + ".conv2", "c0", "c2", "c1", 128, 128, H4, W4, False)
+        cur, free = "c2", ["c0", "c1"]
+        for b in range(1, TRUNK_STAGES[2][2]):
+            u = f"fe.layer3.{b}"
+            mid, out = free
+            s16(u + ".conv1", cur, mid, None, 128, 128, H4, W4, True)
+            s16(u + ".conv2", mid, out, cur, 128, 128, H4, W4, False)
+            cur, free = out, [mid, cur]
+        # layer4 (dilation 2): the same kernel's dilated form where the map is a multiple of 56 rows, else fp32 on tensors with halo 2
+        name, planes, nblk, stride, dil = TRUNK_STAGES[3]
+        if E.s16_supported(128, 128, 1, H4, W4, "2d", dil):
+            plans4 = {}
+
+            def s16d(wname, x, y, res, relu):
+                if relu not in plans4:
+                    plans4[relu] = E.ConvPlanS16(N, 128, 128, 1, H4, W4, relu, device=self.device, kind="2d", dil=dil)
+                sched.append(("s16", plans4[relu], wname, x, y, res))
+            for b in range(nblk):
+                u = f"fe.{name}.{b}"
+                mid, out = free
+                s16d(u + ".conv1", cur, mid, None, True)
+                s16d(u + ".conv2", mid, out, cur, False)
+                cur, free = out, [mid, cur]
+            t["skip"] = E.BlockedSlice(t["cat"], 4, 128)       # output_skip -> channels 64..191 of the concat
+            sched.append(("to32", cur, "skip"))
+            cur = "skip"
+        else:
+            t["l4in"] = B2(128, H4, W4, 2)
+            sched.append(("to32", cur, "l4in"))
+            cur = "l4in"
+            for b in range(nblk):
+                u = f"fe.{name}.{b}"
+                mid = u + ".mid"
+                t[mid] = B2(planes, H4, W4, 2)
+                p[u + ".conv1"] = E.plan_conv2d(t[cur], t[mid], 3, 1, dil, dil, planes, True)
+                sched.append((u + ".conv1", u + ".conv1", cur, mid, None))
+                t[u + ".out"] = E.BlockedSlice(t["cat"], 4, 128) if b == nblk - 1 else B2(planes, H4, W4, 2)
+                p[u + ".conv2"] = E.plan_conv2d(t[mid], t[u + ".out"], 3, 1, dil, dil, planes, False)
+                sched.append((u + ".conv2", u + ".conv2", mid, u + ".out", cur))
+                cur = u + ".out"
+        ws = self._ws2d_tail(t, p, B2, pool, sched, cur, H4, W4)
+        ws["s16"] = True
         return self._ws_put(key, ws)
 
     def _features(self, ws, W, images):
@@ -823,10 +961,21 @@ class PSMNetRuntime:
         else:
             t["img"].from_dense(images if len(views) == 1 else torch.cat(tuple(views), 0))
             run("fe.firstconv.0", "fe.firstconv.0", "img", "f0")
-        run("fe.firstconv.2", "fe.firstconv.2", "f0", "f1")
-        run("fe.firstconv.4", "fe.firstconv.4", "f1", "f2")
-        for plan, wname, x, y, res in ws["sched"]:
-            run(plan, wname, x, y, res)
+        if not ws.get("s16"):
+            run("fe.firstconv.2", "fe.firstconv.2", "f0", "f1")
+            run("fe.firstconv.4", "fe.firstconv.4", "f1", "f2")
+        for e in ws["sched"]:
+            if e[0] == "s16":
+                _, pl, wname, x, y, res = e
+                c = W[wname]
+                w16, sc16 = c.s16()
+                pl.run(t[x], w16, sc16, c.shift, y16=t[y], res=t[res] if res else None)
+            elif e[0] == "to16":
+                t[e[2]].from_blocked(t[e[1]])
+            elif e[0] == "to32":
+                t[e[1]].to_blocked(t[e[2]])
+            else:
+                run(*e)
         skip = t[ws["skip"]]
         H4, W4 = ws["dims"]
         cat = t["cat"]
@@ -962,7 +1111,7 @@ class PSMNetRuntime:
         self._slot = self._pick_slot()
         if left.is_cuda and left.dim() == 4 and self._graph_mode(left.shape[0], training):
             key = ("img", tuple(left.shape), self.model.maxdisp, self.model.mindisp, getattr(self.model, "regressor_math", "auto"),
-                   getattr(self.model, "regressor_storage", "f32"), getattr(self.model, "feature_storage", "f32"))
+                   getattr(self.model, "regressor_storage", "f32"), getattr(self.model, "feature_storage", "f32"), getattr(self.model, "feature_math", "auto"))
             return self._replay(key, (left, right), lambda a, b: self._forward_images_impl(a, b, False))
         if training and torch.is_grad_enabled():
             params = [p for _, _, p in self._slots("p") if p.requires_grad]
@@ -988,7 +1137,7 @@ class PSMNetRuntime:
                 feat = self._features16(ws2, Wt, torch.cat((left, right), 0))
                 self._costvol16(ws3, mn, mx, feat16=feat, right_first=N)
                 return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
-            ws2 = self._ws2d(2 * N, H, W)
+            ws2 = self._ws2d_eval(2 * N, H, W)
             self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, (left, right))
             fv = feat.storage
@@ -996,7 +1145,7 @@ class PSMNetRuntime:
             return self._heads(self._regress16(ws3, Wt), N, H, W, mx, mn, False)
         if self._use_s16(training, (mx - mn) // 4, H // 4, W // 4):
             ws3 = self._ws3d_s16(N, (mx - mn) // 4, H // 4, W // 4)
-            ws2 = self._ws2d(2 * N, H, W)
+            ws2 = self._ws2d_eval(2 * N, H, W)
             self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, (left, right))
             ws3["t"]["featL"].from_blocked(feat, 0)
@@ -1015,7 +1164,7 @@ class PSMNetRuntime:
             self._last_train_2d = (wsL, wsR)
             self._last_gens = self._generations(ws3, wsL, wsR)
         else:
-            ws2 = self._ws2d(2 * N, H, W)
+            ws2 = self._ws2d_eval(2 * N, H, W)
             self._stamp(ws3, ws2)
             feat = self._features(ws2, Wt, (left, right))
             if self._fuse_costvol(ws3, training):

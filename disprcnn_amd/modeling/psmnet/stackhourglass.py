@@ -53,7 +53,8 @@ class PSMNet(nn.Module):
         # "f32" (the reference's precision, default) or "f16": cost volume + 3D regressor on fp16-storage tensors with fp32
         # accumulation (inference only; BASELINE configs[3]).  Not a constructor argument: the reference signature is kept.
         self.regressor_storage = "f32"
-        self.regressor_math = "auto"          # "f32": every 3D layer on the fp32 MFMA; "auto"/"f16x2": eval runs the full-resolution stride-1 layers in split-f16 (runtime._use_s16)
+        self.regressor_math = "auto"          # "f32": every 3D layer on the fp32 MFMA; "auto"/"f16x2": eval runs the 3x3x3 layers of the regressor in split-f16 (runtime._use_s16)
+        self.feature_math = "auto"            # the same switch for the stride-1 undilated 3x3 layers of the 2D feature CNN (runtime._use_s16_2d)
         self.graph_eval = "auto"              # eval batches of <= runtime.GRAPH_MAX_UNITS units replay a captured HIP graph (True: always, False: never)
         self.feature_storage = "f32"          # "f16" (with regressor_storage "f16"): the 2D feature CNN in fp16 storage as well
 

@@ -66,11 +66,13 @@ def rs16_to_dense(t, pd=1):
 
 
 def pack_weight_s16(w):
-    """[Cout,Cin,3,3,3] fp32 -> (packed halfs [Cout/32][Cin/16][27][2][64][8], wexp): the weights scaled by 2^wexp (largest magnitude in
-    [2^13, 2^14): the lo parts stay normal fp16 numbers) and split; the caller folds 2^-wexp into the epilogue scale."""
+    """[Cout,Cin,3,3,3] (or [Cout,Cin,3,3]: the 2D layers of convs16r.hip) fp32 -> (packed halfs [Cout/32][Cin/16][taps][2][64][8], wexp):
+    the weights scaled by 2^wexp (largest magnitude in [2^13, 2^14): the lo parts stay normal fp16 numbers) and split; the caller folds
+    2^-wexp into the epilogue scale."""
     w = w.detach().float()
     cout, cin = w.shape[:2]
-    assert cout % 32 == 0 and cin % 16 == 0 and tuple(w.shape[2:]) == (3, 3, 3)
+    assert cout % 32 == 0 and cin % 16 == 0 and tuple(w.shape[2:]) in ((3, 3, 3), (3, 3))
+    taps = 27 if w.dim() == 5 else 9
     amax = float(w.abs().max())
     wexp = int(math.floor(math.log2(16384.0 / amax))) if amax > 0 else 0
     wexp = max(min(wexp, 24), -24)
@@ -83,9 +85,9 @@ def pack_weight_s16(w):
     co = (torch.arange(ct_n, device=dev)[:, None] * 32 + (lane & 31)[None, :])                    # [ct, 64]
     kk = torch.arange(kw_n, device=dev)
     ci = ((kk >> 1)[:, None, None] * 32 + 4 * g[None, :, None] + 8 * (2 * (kk & 1)[:, None, None] + (e >> 2)[None, None, :]) + (e & 3)[None, None, :])   # [kw, 64, 8]
-    out = torch.empty(ct_n, kw_n, 27, 2, 64, 8, dtype=torch.float16, device=dev)
+    out = torch.empty(ct_n, kw_n, taps, 2, 64, 8, dtype=torch.float16, device=dev)
     for p_, part in enumerate((hi, lo)):
-        pw = part.reshape(cout, cin, 27)
+        pw = part.reshape(cout, cin, taps)
         # [ct, kw, 64, 8, 27]
         sel = pw[co[:, None, :, None], ci[None, :, :, :]]
         out[:, :, :, p_] = sel.permute(0, 1, 4, 2, 3)
@@ -104,3 +106,12 @@ def conv3d_k3(x16, w_packed, scale, shift, D, H, W, cin, cout, relu, y16=None, y
                          N, D, H, W, cin, cout, int(bool(relu)), int(lo4))
     st = _lib.lib().drc_conv3d_k3_s16_fwd(C.byref(p), C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream))
     _lib.check(st, "drc_conv3d_k3_s16_fwd")
+
+
+def conv2d_k3(x16, w_packed, scale, shift, N, H, W, cin, cout, relu, y16, res=None, form=0, dil=1):
+    """One launch of drc_conv2d_k3_s16_fwd on RS16 2D maps [N][C/32][H+2][8][W+2][8], given as torch half tensors or flat storages (form:
+    0 = the dispatcher's choice for cin 64, 1 = one tile per workgroup, 2 = two tiles)."""
+    p = DrcS16ConvParams(_p(x16), _p(w_packed), _p(scale), _p(shift), _p(res), _p(y16), _p(None), _p(None), _p(None),
+                         N, 1, H, W, cin, cout, int(bool(relu)), int(form), int(dil))
+    st = _lib.lib().drc_conv2d_k3_s16_fwd(C.byref(p), C.c_void_p(torch.cuda.current_stream(x16.device).cuda_stream))
+    _lib.check(st, "drc_conv2d_k3_s16_fwd")

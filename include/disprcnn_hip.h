@@ -376,6 +376,7 @@ typedef struct drc_s16conv_params {
     int32_t N, D, H, W;
     int32_t cin, cout, relu;
     int32_t lo4;         /* cost-volume variant: disparity of volume slice 0 (mindisp/4) */
+    int32_t dil;         /* drc_conv2d_k3_s16_fwd only: dilation (0 or 1: none; 2) */
 } drc_s16conv_params;
 int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
@@ -391,6 +392,14 @@ int drc_conv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* p, void* stream);
 int drc_deconv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_deconv3d_k3s2_s16_fwd(const drc_s16conv_params* p, void* stream);
+/* The 2D member of the family (convs16r.hip, round 5): Conv2d k3 s1 p1 d1 + BN (+ residual, + ReLU) on RS16 2D maps
+ * halfs [N][C/32][H+2][8][W+2][8] -- reference convbn of disprcnn/modeling/psmnet/submodule.py:9-16 at firstconv[2], firstconv[4] and the
+ * BasicBlocks of layer1 / layer2 / layer3 (submodule.py:40-60, 68-95).  Uses the fields x, w, scale, shift, res, y16, N, H, W, cin, cout,
+ * relu of the drc_s16conv_params block -- D is ignored, y32 / left / right must be NULL, lo4 = 0.  Weights: the drc_s16 packing with 9 taps kh*3+kw:
+ * [cout/32][cin/16][9][hi, lo][64][8].  cin, cout in {32, 64, 128}; H % 28 == 0; W % 28 == 0 (W % 56 == 0 for cin = 32).  dil = 2
+ * (padding 2; layer4, submodule.py:73): cin = 128, H % 56 == 0. */
+int drc_conv2d_k3_s16_supported(int cin, int cout, int H, int W, int dil);
+int drc_conv2d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
 /* RS16 converters (s16_ops.hip): interior only, the zero halo is the allocator's.  dense = NCDHW fp32 (D = 1, pd = 0 for 2D maps);
  * blocked = the engine's fp32 blocked tensor, channel blocks [cb16_off, cb16_off + C/16) of a tensor with cb16_total blocks and halos
  * (pd_in, ph_in, pw_in).  They stand where the reference hands fp32 NCHW features to the concat loop, stackhourglass.py:112-128. */
@@ -398,6 +407,8 @@ int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, i
 int drc_rs16_from_blocked(const float* xb, void* y16, int N, int C, int D, int H, int W, int pd_in, int ph_in, int pw_in, int cb16_total,
                           int cb16_off, int pd, void* stream);
 int drc_rs16_to_dense(const void* y16, float* x, int N, int C, int D, int H, int W, int pd, void* stream);
+int drc_rs16_to_blocked(const void* y16, float* xb, int N, int C, int D, int H, int W, int pd_out, int ph_out, int pw_out, int cb16_total,
+                        int cb16_off, int pd, void* stream);
 /* Round 4: the same recipe for the stride-2 and the transposed 3x3x3 layers of the fp16-storage regressor (conv16x.hip; hourglass conv1 /
  * conv3 and conv5 / conv6, stackhourglass.py:11-30): drc_conv16_k3s2_tile_* takes the single-class stride-2 grid (in_mul = 2, canonical
  * weight order), drc_deconv16_k3s2_tile_* the eight output-parity classes of ConvTranspose3d(k3, s2, p1, op1) (out_mul = 2, the classes in

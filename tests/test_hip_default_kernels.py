@@ -33,6 +33,7 @@ def _model(dev, case, mx, mn, math="f32"):
     m = PSMNet(mx, mn)
     m.load_state_dict(state_for(case), strict=True)
     m.regressor_math = math
+    m.feature_math = math           # the same switch for the 2D CNN's stride-1 undilated 3x3 layers (convs16r.hip)
     return m.to(dev).eval()
 
 
@@ -53,6 +54,13 @@ def _assert_bench_kernels_s16(ws):
         for c, kname in S16_HG.items():
             assert p[f"hg{k}.{c}"].kname == kname, (k, c, p[f"hg{k}.{c}"].kname)
     return {n: pl.kname for n, pl in p.items()}
+
+
+def _assert_bench_kernels_s16_b(ws):
+    """Config B's volume (24 x 56 x 56): every layer of the regressor on the split-f16 kernels (1 x 28 tiles at full resolution and in the
+    hourglass' half-resolution maps, 2 x 14 in its quarter-resolution ones)."""
+    for name, pl in ws["p"].items():
+        assert pl.kname.startswith(("convs16_kernel", "convs16d_kernel", "convs16u_kernel")), (name, pl.kname)
 
 
 def _assert_bench_kernels(ws):
@@ -157,18 +165,30 @@ def test_config_a_small_batches_vs_oracle_and_plan_names(dev, N):
     assert got == SMALL_BATCH_PLANS[N], got
 
 
-def test_config_b_golden_replicated_to_16_crops(dev):
-    """Config B (full PSMNet on 224x224 crops, D=96) at the bench extra's batch of 16 ROI pairs = the recorded 2 crops x 8."""
+@pytest.mark.parametrize("math", ["f32", "auto"])
+def test_config_b_golden_replicated_to_16_crops(dev, math):
+    """Config B (full PSMNet on 224x224 crops, D=96) at the bench extra's batch of 16 ROI pairs = the recorded 2 crops x 8; "auto" (the
+    default): the regressor and the 45 stride-1 undilated 3x3 layers of the 2D CNN in split-f16 arithmetic."""
     z = golden_npz()
-    m = _model(dev, "B", 48, -48)
+    m = _model(dev, "B", 48, -48, math)
     left, right = synth.synth_images(2, 224, 224, tag="caseB")
     with torch.no_grad():
         pred = m((left.repeat(8, 1, 1, 1).to(dev), right.repeat(8, 1, 1, 1).to(dev))).cpu()
-    ws3 = m._rt._ws[("3d", 16, 24, 56, 56)]
-    for name in WINO_LAYERS:
-        assert ws3["p"][name].wino, name
-    ws2 = m._rt._ws[("2d", 32, 224, 224)]
-    assert ws2["p"]["fe.firstconv.2"].wino and ws2["p"]["fe.lastconv.0"].wino and ws2["p"]["fe.layer4.0.conv1"].wino and ws2["p"]["fe.layer2.0.conv1"].kname.startswith("conv2ddirect")
+    if math == "f32":
+        ws3 = m._rt._ws[("3d", 16, 24, 56, 56)]
+        for name in WINO_LAYERS:
+            assert ws3["p"][name].wino, name
+        ws2 = m._rt._ws[("2d", 32, 224, 224)]
+        assert ws2["p"]["fe.firstconv.2"].wino and ws2["p"]["fe.layer4.0.conv1"].wino
+    else:
+        _assert_bench_kernels_s16_b(m._rt._ws[("3ds16", 16, 24, 56, 56)])
+        ws2 = m._rt._ws[("2ds16", 32, 224, 224)]
+        names = [e[1].kname for e in ws2["sched"] if e[0] == "s16"]
+        assert len(names) == 51, len(names)
+        assert names.count("convs16r_kernel<2,1,false,1>") == 8 and names.count("convs16r_kernel<4,1,false,1>") == 31, names      # firstconv + layer1; layer2
+        assert names.count("convs16r_kernel<2,2,false,1>") == 1 and names.count("convs16r_kernel<4,2,false,1>") == 5, names       # layer3
+        assert names.count("convs16r_kernel<4,2,false,2>") == 6, names                                                            # layer4 (dilation 2)
+    assert ws2["p"]["fe.lastconv.0"].wino and ws2["p"]["fe.layer2.0.conv1"].kname.startswith("conv2ddirect")
     ref = torch.from_numpy(z["B_pred"])
     err = (pred.view(8, 2, 224, 224) - ref[None]).abs()
     print("B x8 mean/max err px", err.mean().item(), err.max().item())

@@ -225,7 +225,7 @@ def test_f16_feature_cnn_vs_fp32_path(dev):
         got = m16((left.to(dev), right.to(dev))).cpu()
     rt = m16._rt
     ws16 = [w for k, w in rt._ws.items() if k[0] == "2d16"][0]
-    ws32 = m32._rt._ws[("2d", 8, 224, 224)]
+    ws32 = [w for k, w in m32._rt._ws.items() if k[0] in ("2d", "2ds16")][0]        # (the fp32-class CNN: fp32 or split-f16 arithmetic)
     assert ws16["p"]["fe.layer1.0.conv1"].tile and ws16["p"]["fe.lastconv.0"].tile and not ws16["p"]["fe.layer4.0.conv1"].tile
     f32 = ws32["t"]["feat"].to_dense()[:, :, 0].cpu()
     f16 = ws16["t"]["feat"].to_dense()[:, :, 0].cpu()

@@ -580,6 +580,7 @@ def _model(dev, case, mx, mn, math="auto"):
     m = PSMNet(mx, mn)
     m.load_state_dict(state_for(case), strict=True)
     m.regressor_math = math
+    m.feature_math = math           # the same switch for the 2D CNN's stride-1 3x3 layers (convs16r.hip)
     return m.to(dev).eval()
 
 
@@ -619,7 +620,7 @@ def test_config_b_vs_golden(dev, math):
     err = (pred - ref).abs()
     print("B mean/max err px", err.mean().item(), err.max().item())
     assert err.mean().item() < 1e-3 and err.max().item() < 2e-2, (err.mean().item(), err.max().item())
-    feat = m._rt._ws[("2d", 4, 224, 224)]["t"]["feat"].to_dense().cpu()[:, :, 0]
+    feat = m._rt._ws[("2d" if math == "f32" else "2ds16", 4, 224, 224)]["t"]["feat"].to_dense().cpu()[:, :, 0]
     flat = feat[:2].reshape(-1)
     idx = torch.from_numpy(z["B_featL_idx"]); val = torch.from_numpy(z["B_featL_val"])
     assert (flat[idx] - val).abs().max().item() < 1e-4 * max(1.0, val.abs().max().item()) + 1e-4

@@ -59,6 +59,20 @@ def test_rs16_converters_match_the_layout_definition(dev):
     blk2 = E.Blocked(4, 32, 1, 5, 7, 0, 1, 1, dev).from_dense(f.to(dev))
     m = E.RS16(2, 32, 1, 5, 7, 0, dev).from_blocked(blk2, 2)
     assert torch.equal(m.view7().cpu(), s16.rs16_from_dense(f[2:]))
+    # RS16 -> blocked fp32 (the seams of the 2D CNN: convs16r.hip's results handed to fp32 kernels): a whole tensor with another halo, a
+    # channel slice of a wider tensor, a later range of units; exactly hi + lo, everything outside the interior untouched
+    f2 = torch.randn(3, 64, 6, 9, generator=g)
+    r = E.RS16(3, 64, 1, 6, 9, 0, dev).from_dense(f2.to(dev))
+    want2 = s16.rs16_to_dense(s16.rs16_from_dense(f2), pd=0)[:, :, 0]
+    whole = E.Blocked(3, 64, 1, 6, 9, 0, 2, 2, dev)
+    r.to_blocked(whole)
+    assert torch.equal(whole.to_dense().cpu()[:, :, 0], want2)
+    wide = E.Blocked(5, 160, 1, 6, 9, 0, 1, 1, dev)
+    wide.storage.fill_(7.0)
+    r.to_blocked(E.BlockedSlice(wide, 2, 64), 1)
+    got = wide.to_dense().cpu()[:, :, 0]
+    assert torch.equal(got[1:4, 32:96], want2)
+    assert (got[0] == 7).all() and (got[4] == 7).all() and (got[:, :32] == 7).all() and (got[:, 96:] == 7).all()
 
 
 CASES = [
@@ -194,6 +208,122 @@ def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):
 ])
 def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, cout, D, H, W, relu, with_res):
     _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,relu,with_res,form", [
+    (2, 128, 128, 56, 56, True, False, "d2"), (9, 128, 128, 56, 28, False, True, "d2"), (3, 128, 128, 112, 56, True, True, "d2"),   # layer4: dilation 2
+    (2, 32, 32, 28, 56, True, False, 0), (3, 32, 32, 56, 112, False, True, 0),          # firstconv / layer1 (two tiles per workgroup, K over two waves)
+    (9, 64, 64, 28, 28, True, True, 0), (2, 64, 64, 56, 56, True, False, 0),            # layer2: one tile, K over four waves
+    (17, 64, 64, 28, 56, False, True, 2), (2, 64, 64, 56, 56, True, True, 2),           # ... the two-tile form with two K slices per wave
+    (2, 64, 128, 28, 28, True, False, 1), (40, 64, 128, 28, 56, True, False, 0),        # layer3's first conv (four cout tiles side by side)
+    (9, 128, 128, 28, 28, False, True, 0), (2, 128, 128, 56, 56, True, False, 0),       # layer3: two K slices per wave
+    (33, 64, 64, 28, 28, True, True, 1), (40, 32, 32, 28, 56, True, True, 0),           # more images than one pass of the persistent grid's XCD groups
+])
+def test_conv2d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, H, W, relu, with_res, form):
+    """convs16r.hip (the 2D member: 3x3 stride-1 conv + BN (+ residual, + ReLU), reference submodule.py:9-16) against fp64 next to the fp32
+    chain, at the bounds of the 3D cases."""
+    dil = 2 if form == "d2" else 1
+    form = 0 if form == "d2" else form
+    g = torch.Generator().manual_seed(N * 100 + cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(N, cout, H, W, generator=g) if with_res else None
+
+    def chain(dt):
+        y = F.conv2d(x.to(dt), w.to(dt), padding=dil, dilation=dil) * scale.to(dt).view(1, -1, 1, 1) + shift.to(dt).view(1, -1, 1, 1)
+        if with_res:
+            y = y + res.to(dt)
+        return y.clamp_min(0) if relu else y
+    ref = chain(torch.float64)
+    e32 = (chain(torch.float32).double() - ref).abs().max().item()
+    wp, wexp = s16.pack_weight_s16(w.to(dev))
+    assert tuple(wp.shape) == (cout // 32, cin // 16, 9, 2, 64, 8)
+    sc = (scale * (2.0 ** -wexp)).to(dev).contiguous()
+    x16 = E.RS16(N, cin, 1, H, W, 0, dev).from_dense(x.to(dev))
+    y16 = E.RS16(N, cout, 1, H, W, 0, dev)
+    r16 = E.RS16(N, cout, 1, H, W, 0, dev).from_dense(res.to(dev)) if with_res else None
+    if form == 0:
+        E.ConvPlanS16(N, cin, cout, 1, H, W, relu, device=dev, kind="2d", dil=dil).run(x16, wp, sc, shift.to(dev), y16=y16, res=r16)
+    else:
+        s16.conv2d_k3(x16.storage, wp, sc, shift.to(dev), N, H, W, cin, cout, relu, y16.storage, res=None if r16 is None else r16.storage, form=form)
+    got = y16.to_dense().cpu()[:, :, 0]
+    m = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"max|err| {err:.3e} (fp32 chain {e32:.3e}), max|ref| {m:.3f}")
+    assert err <= 2e-5 * m + 1e-5
+    assert err <= 2.0 * e32 + 1e-6 * m, (err, e32)
+    v = y16.view7().clone()
+    v[:, :, :, 1:H + 1, :, 1:W + 1] = 0
+    assert not v.any()                                   # the halo stays zero
+
+
+def test_conv2d_s16_validation(dev):
+    lib = _lib_handle()
+    assert lib.drc_conv2d_k3_s16_supported(64, 64, 56, 56, 1) == 1 and lib.drc_conv2d_k3_s16_supported(32, 32, 112, 112, 1) == 1
+    assert lib.drc_conv2d_k3_s16_supported(32, 32, 28, 28, 1) == 0          # 32 input channels: two tiles per workgroup, W % 56
+    assert lib.drc_conv2d_k3_s16_supported(64, 64, 30, 56, 1) == 0 and lib.drc_conv2d_k3_s16_supported(48, 64, 28, 28, 1) == 0
+    assert lib.drc_conv2d_k3_s16_supported(128, 128, 56, 56, 2) == 1 and lib.drc_conv2d_k3_s16_supported(128, 128, 28, 56, 2) == 0      # dilation 2: 56-row blocks
+    assert lib.drc_conv2d_k3_s16_supported(64, 64, 56, 56, 2) == 0 and lib.drc_conv2d_k3_s16_supported(128, 128, 56, 56, 3) == 0
+    with pytest.raises(ValueError):
+        E.ConvPlanS16(2, 64, 64, 1, 30, 56, True, device=dev, kind="2d")
+    plan = E.ConvPlanS16(2, 64, 64, 1, 28, 28, True, device=dev, kind="2d")
+    w = torch.zeros(2, 4, 9, 2, 64, 8, dtype=torch.float16, device=dev)
+    sc = torch.ones(64, device=dev)
+    with pytest.raises(ValueError):                                      # a volume (depth halo) is not a 2D map
+        plan.run(E.RS16(2, 64, 1, 28, 28, 1, dev), w, sc, sc, y16=E.RS16(2, 64, 1, 28, 28, 0, dev))
+    with pytest.raises(ValueError):
+        plan.run(E.RS16(2, 64, 1, 28, 28, 0, dev), w, sc, sc, y16=E.RS16(2, 32, 1, 28, 28, 0, dev))
+
+
+def _lib_handle():
+    from disprcnn_amd import _lib
+    return _lib.lib()
+
+
+def test_feature_cnn_f16x2_vs_f32_path(dev):
+    """Config B (full PSMNet on 224 x 224 crops): the default path (2D CNN's stride-1 3x3 layers and the regressor in split-f16) against
+    the all-fp32-MFMA 2D CNN: the 32-channel feature maps agree to fp32 rounding (measured 2.8e-5 on a range of 10; bound 1e-4 of the
+    range); the disparities behind the regressor at the bounds every HIP path meets against the reference (mean 1e-3 px, max 2e-2 px;
+    measured 2.3e-4 / 5.1e-3: the regressor amplifies rounding-level feature differences, whichever fp32-class arithmetic made them)."""
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    sd = state_for("B")
+    left, right = synth.synth_images(3, 224, 224, tag="s16_2d")
+    outs, feats = {}, {}
+    for math in ("auto", "f32"):
+        m = PSMNet(48, -48)
+        m.load_state_dict(sd, strict=True)
+        m.feature_math = math
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            outs[math] = m((left.to(dev), right.to(dev))).cpu()
+        keys = [k[0] for k in m._rt._ws]
+        assert ("2ds16" in keys) == (math == "auto") and ("2d" in keys) == (math == "f32"), keys
+        feats[math] = m._rt._ws[("2ds16" if math == "auto" else "2d", 6, 224, 224)]["t"]["feat"].to_dense().cpu()
+    fd = (feats["auto"] - feats["f32"]).abs().max().item()
+    fm = feats["f32"].abs().max().item()
+    d = (outs["auto"] - outs["f32"]).abs()
+    print(f"features: max diff {fd:.3e} (max {fm:.3f}); disparity: mean {d.mean().item():.3e} max {d.max().item():.3e} px")
+    assert fd <= 1e-4 * max(1.0, fm)
+    assert d.mean().item() < 1e-3 and d.max().item() < 2e-2
+
+
+def test_feature_math_validation(dev):
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    m = PSMNet(48, -48).to(dev).eval()
+    left, right = synth.synth_images(1, 256, 256, tag="v2d")             # 64 x 64 maps: not a multiple of 28
+    m.feature_math = "bf16"
+    with pytest.raises(ValueError):
+        m((left.to(dev), right.to(dev)))
+    m.feature_math = "f16x2"
+    with pytest.raises(RuntimeError):
+        m((left.to(dev), right.to(dev)))
+    m.feature_math = "auto"                                              # falls back to the fp32 kernels
+    with torch.no_grad():
+        out = m((left.to(dev), right.to(dev)))
+    assert out.shape == (1, 256, 256) and torch.isfinite(out).all()
+    assert "2d" in [k[0] for k in m._rt._ws]
 
 
 def test_conv3d_s16_small_activations_keep_an_absolute_error_floor(dev):
