@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_tilemap.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int n_ = lane & 31, g = lane >> 5;
-    const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;      // this lane's voxel inside the MFMA tile (lanes >= RT*WT idle)
+    // this lane's voxel inside the MFMA tile: 2 x 14 / 4 x 7 tiles hand whole tile rows to a ds_read_b128 service group (s16_tilemap.h: the B
+    // fragment reads are bank-conflict free); lo4 bit 8 of a non-CV launch = the row-major order (A/B experiments)
+    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, !CV && (p.lo4 & 0x100));
+    const int rl = tln.rl, xl = tln.xl;
     const int r = wave / KW, k = wave % KW;     // MFMA tile of the workgroup, K slice
     const int n_ct = p.cout / 32;
     const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tile of 32: the tiles of one column set run side by side on ONE XCD (block b -> XCD b % 8), so the
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         q.y32b = p.y32 ? (char*)p.y32 + (long)c.n * b_nB : (char*)p.w;
         q.resb = p.res ? (const char*)p.res + (long)c.n * ynB : (const char*)p.w;
         const int yl = c.y0 + r * RT + rl;                                  // this lane's output row
-        q.ok = n_ < RT * TX && yl < H;
+        q.ok = tln.ok && yl < H;
         if constexpr (KW == 2) {
             // own registers 8k..8k+7 = chunk (s = k, g) complete: 16 B hi at chunk k*2+g, lo at 4 + k*2 + g
             q.o16 = (unsigned)((long)ct * xcbB + planeB + (long)(yl + 1) * rowB + (long)(k * 2 + g) * (Wp * 16) + (long)(c.x0 + xl + 1) * 16);

@@ -11,12 +11,22 @@
 //     (9 taps, 27 MFMAs) feeds one accumulator, an odd plane (18 taps, 54 MFMAs) finishes it and opens the next; a pair of planes = one
 //     output plane = 81 MFMAs per wave, published after the odd step and finalized in the shadow of the next even step's MFMAs.
 //   * no residual (the reference's stride-2 layers have none).
+//   * DEI (de-interleaved slab rows): a tap reads every second staged voxel, i.e. 16-byte LDS slots at a stride of two -- 14 lanes on 8 of the
+//     16 slots of a bank row, a 2-way conflict whatever the lane order (42-59 % of these kernels' LDS cycles, profiles/r5_pmc.md at 5429fbb).
+//     The LDS-DMA lanes therefore gather a staged row as [even columns | odd columns] (each lane's global address is its own), so that tap
+//     kw of output column x is position x (kw 0), HALF + x (kw 1), x + 1 (kw 2): unit stride, conflict-free with the tile map of
+//     s16_tilemap.h (4 x 7 tiles: rows padded from 16 to 20 slots so that the two rows of a service group do not alias).
+//   * CS (cout split; cin 32 -> cout 64, the hourglass' conv1): instead of two spatial tiles per workgroup and one workgroup per cout tile
+//     (the input staged -- and, measured, mostly FETCHED -- once per cout tile: 2.9 GB per launch for a 1.65 GB input), the two wave
+//     pairs of a workgroup take the two COUT tiles of ONE spatial tile: one staging of a slab half the size (6 instead of 10 LDS-DMA
+//     instructions per wave and plane for the same MFMAs), the input read once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_tilemap.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,14 +41,29 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// KW = cin / 16 K slices; RT x WT OUTPUT voxels per MFMA tile (1 x 28, 2 x 14, 4 x 7); RING slots of one input-plane slab
-template <int KW, int RT, int WT, int RING>
+// slab geometry shared by the kernel and its launcher
+template <int KW, int RT, int WT, bool DEI, bool CS>
+struct DGeom {
+    static constexpr int RPW = CS ? 1 : 4 / KW;             // spatial MFMA tiles per workgroup
+    static constexpr int SXI = 2 * WT + 2;                  // staged input columns
+    static constexpr int HALF = WT + 1;                     // DEI: positions of the even columns [0, HALF), of the odd ones [HALF, SXI)
+    static constexpr int SXL = (DEI && RT == 4) ? SXI + 4 : SXI;      // LDS row stride in voxels
+    static constexpr int SROWS = 2 * RPW * RT + 1;          // staged input rows
+    // voxels per chunk plane; the row-major forms' idle lanes (28..31) over-read a row further
+    static constexpr int PV = DEI ? (SROWS * SXL + 63) / 64 * 64 : ((SROWS + 1) * SXI + 8 + 63) / 64 * 64;
+    static constexpr int SLAB = (KW / 2) * 8 * PV * 16;
+};
+
+// KW = cin / 16 K slices; RT x WT OUTPUT voxels per MFMA tile (1 x 28, 2 x 14, 4 x 7); RING slots of one input-plane slab; DEI, CS: header
+template <int KW, int RT, int WT, int RING, bool DEI, bool CS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convs16d_kernel(const drc_s16conv_params p) {
-    constexpr int RPW = 4 / KW;                 // MFMA tiles per workgroup
+    using GM = DGeom<KW, RT, WT, DEI, CS>;
+    static_assert(!CS || KW == 2, "the cout split is the two wave pairs of a cin = 32 workgroup");
+    constexpr int RPW = GM::RPW;
     constexpr int CBI = KW / 2;
-    constexpr int SXI = 2 * WT + 2;             // staged input columns
-    constexpr int SROWS = 2 * RPW * RT + 1;     // staged input rows
-    constexpr int PV = ((SROWS + 1) * SXI + 8 + 63) / 64 * 64;     // voxels per chunk plane (+ what the idle lanes over-read)
+    constexpr int SXI = GM::SXI, HALF = GM::HALF, SXL = GM::SXL;
+    constexpr int SROWS = GM::SROWS;
+    constexpr int PV = GM::PV;
     constexpr int CPB = PV * 16;
     constexpr int SLAB = CBI * 8 * CPB;
     constexpr int NPI = PV / 64;                // LDS-DMA instructions per chunk plane
@@ -54,10 +79,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int n_ = lane & 31, g = lane >> 5;
-    const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;
-    const int r = wave / KW, k = wave % KW;
-    const int n_ct = p.cout / 32;
-    const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tiles side by side on one XCD (see convs16.hip)
+    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, p.lo4 & 0x100);      // s16_tilemap.h; lo4 bit 8: row-major order (A/B experiments)
+    const int rl = tln.rl, xl = tln.xl;
+    const int r = wave / KW, k = wave % KW;     // wave pair / K slice
+    const int rs = CS ? 0 : r;                  // spatial tile of the workgroup
+    const int n_ct = CS ? 1 : p.cout / 32;      // cout tiles spread over workgroups
+    const int ct = CS ? r : (int)((blockIdx.x >> 3) % n_ct);   // cout tiles side by side on one XCD (see convs16.hip) -- CS: inside the workgroup
 
     // input geometry (p.D, p.H, p.W) -> output (D/2, H/2, W/2)
     const int Di = p.D, Hi = p.H, Wi = p.W;
@@ -89,12 +116,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int h = 0; h < NPI; ++h) {
         const int v = h * 64 + lane;
-        const bool ok = v < SROWS * SXI;
-        const int rr = ok ? v / SXI : 0;
-        const int xx = ok ? v - rr * SXI : 0;
+        const int rr0 = v / SXL, pp = v - rr0 * SXL;         // LDS position -> (staged row, position in the row)
+        const bool ok = rr0 < SROWS && pp < SXI;
+        const int rr = ok ? rr0 : 0;
+        const int xx = !ok ? 0 : (DEI ? (pp < HALF ? 2 * pp : 2 * (pp - HALF) + 1) : pp);     // its input column
         srcoff[h] = (unsigned)(rr * i_rowB + xx * 16);
     }
-    const unsigned bfrag = (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + ((2 * (r * RT + rl)) * SXI + 2 * xl) * 16);     // hi; lo at + 4*CPB
+    const unsigned bfrag = (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + ((2 * (rs * RT + rl)) * SXL + (DEI ? xl : 2 * xl)) * 16);     // hi; lo at + 4*CPB
+    // byte offset of tap (kh, kw) from there: a uniform immediate
+    auto tapoff = [](int kh, int kw) constexpr { return (kh * SXL + (DEI ? (kw == 1 ? HALF : (kw >> 1)) : kw)) * 16; };
     const __attribute__((address_space(3))) char* ringl = (const __attribute__((address_space(3))) char*)ring;
     typedef const __attribute__((address_space(3))) f16x8 lds_frag;
 
@@ -128,8 +158,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         };
         const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y16 + (long)n * o_nB), 0, 0x7FFFFF00, 0x00020000);
-        const int yl = y0 + r * RT + rl;
-        const bool lane_ok = n_ < RT * WT && yl < Ho;
+        const int yl = y0 + rs * RT + rl;
+        const bool lane_ok = tln.ok && yl < Ho;
         unsigned o16;
         if constexpr (KW == 2)
             o16 = (unsigned)((long)ct * o_cbB + o_planeB + (long)(yl + 1) * o_rowB + (long)(k * 2 + g) * (Wpo * 16) + (long)(x0 + xl + 1) * 16);
@@ -200,8 +230,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         const int kh = q / 3, kw = q - kh * 3;
                         if (q + 1 < 9) {
                             const int kh1 = (q + 1) / 3, kw1 = (q + 1) - kh1 * 3;
-                            bh[(q + 1) & 1] = *(lds_frag*)(sb + (kh1 * SXI + kw1) * 16);
-                            bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + (kh1 * SXI + kw1) * 16);
+                            bh[(q + 1) & 1] = *(lds_frag*)(sb + tapoff(kh1, kw1));
+                            bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + tapoff(kh1, kw1));
                         }
                         const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
                         const int t1 = 9 + kh * 3 + kw;
@@ -238,8 +268,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const int kh = q / 3, kw = q - kh * 3;
                     if (q + 1 < 9) {
                         const int kh1 = (q + 1) / 3, kw1 = (q + 1) - kh1 * 3;
-                        bh[(q + 1) & 1] = *(lds_frag*)(sb + (kh1 * SXI + kw1) * 16);
-                        bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + (kh1 * SXI + kw1) * 16);
+                        bh[(q + 1) & 1] = *(lds_frag*)(sb + tapoff(kh1, kw1));
+                        bl[(q + 1) & 1] = *(lds_frag*)(sb + 4 * CPB + tapoff(kh1, kw1));
                     }
                     const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
                     const int t0 = kh * 3 + kw, t2 = 18 + t0;
@@ -283,24 +313,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template <int KW, int RT, int WT, int RING>
-int launch(const drc_s16conv_params& p, hipStream_t stream) {
-    constexpr int RPW = 4 / KW, CBI = KW / 2, SXI = 2 * WT + 2, SROWS = 2 * RPW * RT + 1;
-    constexpr int PV = ((SROWS + 1) * SXI + 8 + 63) / 64 * 64;
-    constexpr size_t lds = (size_t)RING * CBI * 8 * PV * 16 + 2 * 4 * 4096;
+template <int KW, int RT, int WT, int RING, bool DEI, bool CS>
+int launch2(const drc_s16conv_params& p, hipStream_t stream) {
+    using GM = DGeom<KW, RT, WT, DEI, CS>;
+    constexpr int RPW = GM::RPW;
+    constexpr size_t lds = (size_t)RING * GM::SLAB + 2 * 4 * 4096;
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)convs16d_kernel<KW, RT, WT, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)convs16d_kernel<KW, RT, WT, RING, DEI, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const int Ho = p.H / 2, Wo = p.W / 2;
     const long columns = (long)p.N * ((Ho + RPW * RT - 1) / (RPW * RT)) * (Wo / WT);
-    const int n_ct = p.cout / 32;
+    const int n_ct = CS ? 1 : p.cout / 32;
     long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
     while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16d_kernel<KW, RT, WT, RING>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((convs16d_kernel<KW, RT, WT, RING, DEI, CS>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
+}
+
+// lo4 (unused by the arithmetic of this layer) carries the experiment bits: 0x100 row-major tile lanes, 0x200 interleaved slab rows (no DEI),
+// 0x400 no cout split.  0 = the product forms.
+template <int KW, int RT, int WT, int RING, int RING_CS>
+int launch(const drc_s16conv_params& p, hipStream_t stream) {
+    const bool dei = !(p.lo4 & 0x200);
+    // (ring depth: the preferred one where it fits the 160 KiB LDS next to the 32 KiB exchange buffers, else two slots)
+    constexpr auto ring_of = [](int want, int slab) constexpr { return (size_t)want * slab + 32768 <= 160 * 1024 ? want : 2; };
+    if constexpr (KW == 2) {
+        if (p.cout == 64 && !(p.lo4 & 0x400)) {
+            constexpr int R1 = ring_of(RING_CS, DGeom<KW, RT, WT, true, true>::SLAB), R0 = ring_of(RING_CS, DGeom<KW, RT, WT, false, true>::SLAB);
+            return dei ? launch2<KW, RT, WT, R1, true, true>(p, stream) : launch2<KW, RT, WT, R0, false, true>(p, stream);
+        }
+    }
+    constexpr int R1 = ring_of(RING, DGeom<KW, RT, WT, true, false>::SLAB), R0 = ring_of(RING, DGeom<KW, RT, WT, false, false>::SLAB);
+    return dei ? launch2<KW, RT, WT, R1, true, false>(p, stream) : launch2<KW, RT, WT, R0, false, false>(p, stream);
 }
 
 }  // namespace
@@ -327,7 +374,7 @@ extern "C" int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* pp, void* strea
     hipStream_t s = (hipStream_t)stream;
     const int Wo = p.W / 2;
     // (ring depth by what fits the 160 KiB LDS next to the 32 KiB exchange buffers)
-    if (Wo == 14) return p.cin == 32 ? launch<2, 2, 14, 3>(p, s) : launch<4, 2, 14, 2>(p, s);
-    if (Wo == 7) return p.cin == 32 ? launch<2, 4, 7, 3>(p, s) : launch<4, 4, 7, 2>(p, s);
-    return p.cin == 32 ? launch<2, 1, 28, 2>(p, s) : launch<4, 1, 28, 2>(p, s);
+    if (Wo == 14) return p.cin == 32 ? launch<2, 2, 14, 3, 3>(p, s) : launch<4, 2, 14, 2, 2>(p, s);
+    if (Wo == 7) return p.cin == 32 ? launch<2, 4, 7, 3, 3>(p, s) : launch<4, 4, 7, 2, 2>(p, s);
+    return p.cin == 32 ? launch<2, 1, 28, 2, 3>(p, s) : launch<4, 1, 28, 2, 2>(p, s);
 }

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_tilemap.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -77,7 +78,8 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
     float* bnlds = (float*)(lds + RING * SLAB);   // [2 g][2: scale, shift][16] floats of this cout tile
 
     const int n_ = lane & 31, g = lane >> 5;
-    const int rl = RT == 1 ? 0 : n_ / WT, xl = RT == 1 ? n_ : n_ - (n_ / WT) * WT;
+    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, p.lo4 & 0x100);       // conflict-free B fragment reads (s16_tilemap.h); lo4 bit 8: row-major order
+    const int rl = tln.rl, xl = tln.xl;
     const int n_ct = p.cout / 32;
     const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tiles side by side on one XCD (see convs16.hip)
     const int Di = p.D, Hi = p.H, Wi = p.W;
@@ -147,7 +149,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
         const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(p.res ? (void*)((const char*)p.res + (long)n * o_nB + (long)ct * o_cbB) : (void*)p.w, 0,
                                                                               p.res ? 0x7FFFFF00 : 0, 0x00020000);
         const int yl = y0 + rl;
-        const bool lane_ok = n_ < RT * WT && yl < Hi;
+        const bool lane_ok = tln.ok && yl < Hi;
         // this lane's even-corner output voxel (2 yl, 2 (x0 + xl)), chunk (s = 0, g), hi, in output plane 0 (padded + 1)
         const unsigned o_lane = (unsigned)(o_planeB + (long)(2 * yl + 1) * o_rowB + (long)g * o_chunkB + (long)(2 * (x0 + xl) + 1) * 16);
 

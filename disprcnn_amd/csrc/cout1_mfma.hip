@@ -33,7 +33,11 @@ __global__ __launch_bounds__(64 * C1M_WAVES) void cout1_mfma_kernel(const float*
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
     const int n_rt = (H + R - 1) / R;
-    const int col = blockIdx.x * C1M_WAVES + wave;       // (n, row tile)
+    // XCD-aware order: workgroup b runs on XCD b % 8, each XCD has its own L2.  In launch order the row tiles of one ROI -- which share their
+    // halo rows -- went to eight different L2s and the halo rows came from HBM once per XCD (fetch 1.37x the tensor, profiles/r5_pmc.md at
+    // 5429fbb); here XCD q takes the q-th contiguous eighth of the columns (gridDim.x is a multiple of 8).
+    const unsigned bx = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int col = (int)bx * C1M_WAVES + wave;          // (n, row tile)
     if (col >= N * n_rt) return;                         // wave-uniform; no workgroup barrier
     const int n = col / n_rt, oh0 = (col - n * n_rt) * R;
     const int o0 = (int)((long)blockIdx.y * D / segs), o1 = (int)((long)(blockIdx.y + 1) * D / segs);   // output slices of this segment
@@ -186,7 +190,8 @@ extern "C" int drc_conv3d_cout1_mfma_try(const float* x, const float* w, const f
     long segs = cols >= 1024 ? 1 : (2048 + cols - 1) / cols;          // (one wave per SIMD or more: the extra slices cost more than they fill)
     if (segs > D / 4) segs = D / 4;
     if (segs < 1) segs = 1;
-    hipLaunchKernelGGL(cout1_mfma_kernel, dim3((unsigned)((cols + C1M_WAVES - 1) / C1M_WAVES), (unsigned)segs), dim3(64 * C1M_WAVES), lds,
+    const long gx = ((cols + C1M_WAVES - 1) / C1M_WAVES + 7) / 8 * 8;   // a multiple of 8 (XCD-aware order; surplus waves return at once)
+    hipLaunchKernelGGL(cout1_mfma_kernel, dim3((unsigned)gx, (unsigned)segs), dim3(64 * C1M_WAVES), lds,
                        (hipStream_t)stream, x, w, res, out, N, D, H, W, R, (int)segs);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

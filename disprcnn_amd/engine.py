@@ -1353,6 +1353,7 @@ def cost_volume16_blocked(left, right, out, lo4, hi4, in_blocked_pad=-1):
 
 
 # ------------------------------------------------------------------------------------------- split-f16 ("f16x2") path, round 5
+LASTCONV_S16 = {"enabled": True}     # eval, split-f16 2D schedule: lastconv[0] (320 -> 128) as three chained split-f16 launches over the concat's parts (runtime._ws2d_s16)
 S16 = {"enabled": True}       # eval: the stride-1 3x3x3 layers at full resolution on the f16 matrix cores in split arithmetic (convs16.hip)
 
 
@@ -1457,8 +1458,11 @@ class ConvPlanS16:
             self._kfmt = "convs16r_kernel<%d,%d,%%s,%d>" % (kw, ks, dil)
             self.kname = self._kfmt % "false"
         elif kind == "s2":
-            ring = 3 if (cin == 32 and nw in (14, 7)) else 2                    # convs16d.hip's dispatch: what fits the LDS
-            self.kname = "convs16d_kernel<%d,%d,%d,%d>" % (cin // 16, rt, wt, ring)
+            # convs16d.hip's dispatch: cin 32 -> cout 64 runs the cout-split form (one slab, both cout tiles), slab rows de-interleaved; ring
+            # depth by what fits the LDS
+            cs = cin == 32 and cout == 64
+            ring = 3 if (cs or (cin == 32 and nw == 14)) else 2
+            self.kname = "convs16d_kernel<%d,%d,%d,%d,true,%s>" % (cin // 16, rt, wt, ring, "true" if cs else "false")
         else:
             self.kname = "convs16u_kernel<%d,%d>" % (rt, wt)
 

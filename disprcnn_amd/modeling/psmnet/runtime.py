@@ -52,6 +52,7 @@ class _Conv:
         self._s16 = None                    # (split-f16 packing, wexp), built on first use (engine.ConvPlanS16)
         self._s16_scale = None              # (scale tensor it was derived from, scale * 2^-wexp)
         self._stem = None                   # firstconv[0] only: the packing of stemconv.hip, built on first use
+        self._s16_parts = self._s16_parts_scale = None      # lastconv[0] only: split-f16 packings per input-channel slice (s16_cin_slices)
         cout_pad = E.cout_pad_of(self.cout)
         self.cout_pad, self.device = cout_pad, device
         self.bn = bn
@@ -95,6 +96,20 @@ class _Conv:
         if self._s16_scale is None or self._s16_scale[0] is not self.scale:
             self._s16_scale = (self.scale, (self.scale * (2.0 ** -self._s16[1])).contiguous())
         return self._s16[0], self._s16_scale[1]
+
+    def s16_cin_slices(self, bounds):
+        """[(packed split-f16 weights of the input channels [a, b), their epilogue scale = folded BN scale * 2^-wexp of the slice)] -- for a
+        layer whose cin is not one the kernel takes (lastconv[0]: 320 = 64 + 128 + 128) and that runs as chained partial launches:
+        BatchNorm is affine, scale * (c1 + c2 + c3) + shift = (scale * c1 + shift) + scale * c2 + scale * c3."""
+        from ... import s16 as S
+        key = tuple(bounds)
+        if self._s16_parts is None or self._s16_parts[0] != key:
+            w = self.conv.weight.detach().to(device=self.device, dtype=torch.float32)
+            self._s16_parts = (key, [S.pack_weight_s16(w[:, a:b].contiguous()) for a, b in bounds])
+            self._s16_parts_scale = None
+        if self._s16_parts_scale is None or self._s16_parts_scale[0] is not self.scale:
+            self._s16_parts_scale = (self.scale, [(self.scale * (2.0 ** -wexp)).contiguous() for _, wexp in self._s16_parts[1]])
+        return [(wp, sc) for (wp, _), sc in zip(self._s16_parts[1], self._s16_parts_scale[1])]
 
     def refold(self):
         """Eval-mode BatchNorm folded into per-cout scale/shift from the module's current running statistics."""
@@ -885,6 +900,7 @@ class PSMNetRuntime:
         # output_raw -> channels 0..63 of the concat (fp32), which is also the input of layer3's 1x1 downsample
         t["raw"] = E.BlockedSlice(t["cat"], 0, 64)
         sched.append(("to32", cur, "raw"))
+        raw16 = cur                                            # (its RS16 map stays: layer3 rotates its own three maps)
         t["l3sc"] = B2(128, H4, W4)
         u = "fe.layer3.0"
         p[u + ".down"] = E.plan_conv2d(t["raw"], t["l3sc"], 1, 1, 0, 1, 128, False)
@@ -918,8 +934,10 @@ class PSMNetRuntime:
                 cur, free = out, [mid, cur]
             t["skip"] = E.BlockedSlice(t["cat"], 4, 128)       # output_skip -> channels 64..191 of the concat
             sched.append(("to32", cur, "skip"))
+            last16 = (raw16, cur, free[0], free[1])            # RS16 maps of raw and skip, two free 128-channel maps
             cur = "skip"
         else:
+            last16 = None
             t["l4in"] = B2(128, H4, W4, 2)
             sched.append(("to32", cur, "l4in"))
             cur = "l4in"
@@ -935,6 +953,19 @@ class PSMNetRuntime:
                 cur = u + ".out"
         ws = self._ws2d_tail(t, p, B2, pool, sched, cur, H4, W4)
         ws["s16"] = True
+        if last16 is not None and E.LASTCONV_S16["enabled"]:
+            # lastconv[0] (3x3, 320 -> 128, submodule.py:125-128; 10.5 % of the CNN's FLOPs) as three chained split-f16 launches over the
+            # concat's parts -- raw (64), skip (128), the four upsampled SPP branches (128) -- each adding the previous partial sum as its
+            # residual (BN is affine: its scale goes to every part, its shift to the first, the ReLU to the last).  The parts' RS16 maps exist
+            # already (raw, skip) or are converted from the concat's branch slice; the fp32 concat is still what the 1x1 / pooling kernels read.
+            t["br32"] = E.BlockedSlice(t["cat"], 12, 128)
+            t["br16"] = S2("br16", 128, H4, W4)
+            raw16, skip16, lp0, lp1 = last16
+            ws["last16"] = dict(
+                bounds=((0, 64), (64, 192), (192, 320)),
+                steps=((E.ConvPlanS16(N, 64, 128, 1, H4, W4, False, device=self.device, kind="2d"), raw16, lp0, None),
+                       (E.ConvPlanS16(N, 128, 128, 1, H4, W4, False, device=self.device, kind="2d"), skip16, lp1, lp0),
+                       (E.ConvPlanS16(N, 128, 128, 1, H4, W4, True, device=self.device, kind="2d"), "br16", lp0, lp1)))
         return self._ws_put(key, ws)
 
     def _features(self, ws, W, images):
@@ -1001,7 +1032,16 @@ class PSMNetRuntime:
             st = lib.drc_bilinear_up_blocked(E._ptr(conv.storage), E._ptr(cat.storage), cat.N, 2, oh, ow, 0, H4, W4, cat.ph,
                                              cat.cb, cb_off, sp)
             _lib.check(st, "drc_bilinear_up_blocked")
-        run("fe.lastconv.0", "fe.lastconv.0", "cat", "last0")
+        l16 = ws.get("last16")
+        if l16 is not None:
+            c = W["fe.lastconv.0"]
+            t["br16"].from_blocked(t["br32"])
+            parts = c.s16_cin_slices(l16["bounds"])
+            for i, ((pl, x, y, res), (w16, sc16)) in enumerate(zip(l16["steps"], parts)):
+                pl.run(t[x], w16, sc16, c.shift if i == 0 else c.zero_shift, y16=t[y], res=t[res] if res else None)
+            t[l16["steps"][-1][2]].to_blocked(t["last0"])
+        else:
+            run("fe.lastconv.0", "fe.lastconv.0", "cat", "last0")
         run("fe.lastconv.2", "fe.lastconv.2", "last0", "feat")
         return t["feat"]
 

@@ -144,7 +144,7 @@ def test_conv3d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, D, H, W, r
     assert not v.any()
 
 
-def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):
+def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed, lo4=0):
     """One launch of the kind's kernel against fp64 next to the fp32 chain (torch CPU); D, H, W = the input dims."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, cin, D, H, W, generator=g)
@@ -175,7 +175,7 @@ def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):
     y16 = E.RS16(N, cout, *od, 1, dev)
     plan = E.ConvPlanS16(N, cin, cout, D, H, W, relu, device=dev, kind=kind)
     r16 = E.RS16(N, cout, *od, 1, dev).from_dense(res.to(dev)) if with_res else None
-    plan.run(E.RS16(N, cin, D, H, W, 1, dev).from_dense(x.to(dev)), wp, sc, shift.to(dev), y16=y16, res=r16)
+    plan.run(E.RS16(N, cin, D, H, W, 1, dev).from_dense(x.to(dev)), wp, sc, shift.to(dev), y16=y16, res=r16, lo4=lo4)
     got = y16.to_dense().cpu()
     m = ref.abs().max().item()
     err = (got.double() - ref).abs().max().item()
@@ -199,6 +199,8 @@ def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):
     ("s2", 2, 64, 32, 2, 14, 14, False, False),
     ("s2", 2, 32, 32, 6, 14, 14, True, False),
     ("s2", 1, 64, 64, 4, 8, 56, True, False),
+    ("s2", 2, 32, 64, 6, 14, 14, True, False),       # cout-split form on 4 x 7 tiles (ragged row tile)
+    ("s2", 2, 32, 64, 4, 6, 56, False, False),       # cout-split form on 1 x 28 tiles, odd row count
     ("up", 3, 64, 64, 3, 7, 7, True, True),          # hourglass conv5, Config A
     ("up", 3, 64, 32, 6, 14, 14, False, True),       # hourglass conv6, Config A
     ("up", 1, 64, 32, 12, 28, 28, False, True),      # hourglass conv6, Config B
@@ -208,6 +210,20 @@ def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed):
 ])
 def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, cout, D, H, W, relu, with_res):
     _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
+
+
+# the forms the product kernels replaced stay selectable (lo4 bits of a non-cost-volume launch: 0x100 row-major tile lanes instead of the
+# conflict-free map of s16_tilemap.h, 0x200 interleaved slab rows and 0x400 no cout split in the stride-2 kernel) and must stay correct: the
+# A/B timings of tools/experiments/exp_s16_forms.py compare like with like
+@pytest.mark.parametrize("kind,N,cin,cout,D,H,W,relu,with_res,lo4", [
+    ("s1", 3, 64, 64, 6, 14, 14, True, True, 0x100), ("s1", 5, 64, 64, 3, 7, 7, True, False, 0x100), ("s1", 2, 32, 32, 3, 6, 14, False, True, 0x100),
+    ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x100), ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x200), ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x400),
+    ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x700), ("s2", 3, 64, 64, 6, 14, 14, True, False, 0x100), ("s2", 3, 64, 64, 6, 14, 14, True, False, 0x200),
+    ("s2", 1, 32, 64, 24, 56, 56, True, False, 0x600), ("s2", 2, 32, 32, 6, 14, 14, True, False, 0x300),
+    ("up", 3, 64, 64, 3, 7, 7, True, True, 0x100), ("up", 3, 64, 32, 6, 14, 14, False, True, 0x100),
+])
+def test_hourglass_layers_s16_experiment_forms(dev, kind, N, cin, cout, D, H, W, relu, with_res, lo4):
+    _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000, lo4=lo4)
 
 
 @pytest.mark.parametrize("N,cin,cout,H,W,relu,with_res,form", [
@@ -307,6 +323,33 @@ def test_feature_cnn_f16x2_vs_f32_path(dev):
     print(f"features: max diff {fd:.3e} (max {fm:.3f}); disparity: mean {d.mean().item():.3e} max {d.max().item():.3e} px")
     assert fd <= 1e-4 * max(1.0, fm)
     assert d.mean().item() < 1e-3 and d.max().item() < 2e-2
+
+
+def test_lastconv_as_chained_split_f16_launches(dev):
+    """lastconv[0] (3x3, 320 -> 128 on the concat; reference submodule.py:125-128) runs as three chained split-f16 launches over the concat's
+    parts (raw 64, skip 128, SPP branches 128), each adding the previous partial sum as its residual.  Against the same schedule with that
+    layer on the fp32 Winograd kernel (engine.LASTCONV_S16 off) the features agree to fp32 rounding."""
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    sd = state_for("B")
+    left, right = synth.synth_images(2, 224, 224, tag="s16_last")
+    feats = {}
+    for on in (True, False):
+        E.LASTCONV_S16["enabled"] = on
+        try:
+            m = PSMNet(48, -48)
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).eval()
+            with torch.no_grad():
+                m((left.to(dev), right.to(dev)))
+            ws = m._rt._ws[("2ds16", 4, 224, 224)]
+            assert ("last16" in ws) == on
+            feats[on] = ws["t"]["feat"].to_dense().cpu()
+        finally:
+            E.LASTCONV_S16["enabled"] = True
+    fd = (feats[True] - feats[False]).abs().max().item()
+    fm = feats[False].abs().max().item()
+    print(f"features: chained split-f16 lastconv[0] vs fp32 Winograd: max diff {fd:.3e} (max {fm:.3f})")
+    assert fd <= 5e-5 * max(1.0, fm)
 
 
 def test_feature_math_validation(dev):
