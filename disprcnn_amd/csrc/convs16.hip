@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int n_ = lane & 31, g = lane >> 5;
-    // this lane's voxel inside the MFMA tile: 2 x 14 / 4 x 7 tiles hand whole tile rows to a ds_read_b128 service group (s16_tilemap.h: the B
-    // fragment reads are bank-conflict free); lo4 bit 8 of a non-CV launch = the row-major order (A/B experiments)
-    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, !CV && (p.lo4 & 0x100));
+    // this lane's voxel inside the MFMA tile: row-major (lanes >= RT * WT idle).  lo4 bit 8 of a non-CV launch selects the bank-conflict-free
+    // order of s16_tilemap.h -- measured slower (its stores are less coalesced, the LDS reads were not the limit): an experiment, not the product
+    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, CV || !(p.lo4 & 0x100));
     const int rl = tln.rl, xl = tln.xl;
     const int r = wave / KW, k = wave % KW;     // MFMA tile of the workgroup, K slice
     const int n_ct = p.cout / 32;

@@ -14,12 +14,13 @@
 //   * DEI (de-interleaved slab rows): a tap reads every second staged voxel, i.e. 16-byte LDS slots at a stride of two -- 14 lanes on 8 of the
 //     16 slots of a bank row, a 2-way conflict whatever the lane order (42-59 % of these kernels' LDS cycles, profiles/r5_pmc.md at 5429fbb).
 //     The LDS-DMA lanes therefore gather a staged row as [even columns | odd columns] (each lane's global address is its own), so that tap
-//     kw of output column x is position x (kw 0), HALF + x (kw 1), x + 1 (kw 2): unit stride, conflict-free with the tile map of
-//     s16_tilemap.h (4 x 7 tiles: rows padded from 16 to 20 slots so that the two rows of a service group do not alias).
+//     kw of output column x is position x (kw 0), HALF + x (kw 1), x + 1 (kw 2): unit stride (4 x 7 tiles: rows padded from 16 to 20
+//     slots).  Measured (tools/experiments/exp_s16_forms.py, us per launch): 32 -> 64 on 24x56x56, 64 units: 232 against 256 interleaved.
 //   * CS (cout split; cin 32 -> cout 64, the hourglass' conv1): instead of two spatial tiles per workgroup and one workgroup per cout tile
 //     (the input staged -- and, measured, mostly FETCHED -- once per cout tile: 2.9 GB per launch for a 1.65 GB input), the two wave
 //     pairs of a workgroup take the two COUT tiles of ONE spatial tile: one staging of a slab half the size (6 instead of 10 LDS-DMA
-//     instructions per wave and plane for the same MFMAs), the input read once.
+//     instructions per wave and plane for the same MFMAs), the input read once.  Measured, Config A conv1 at 1024 / 256 units: 549 / 121 us
+//     against 609 / 153 us for the form it replaced (two spatial tiles per workgroup, interleaved rows).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int n_ = lane & 31, g = lane >> 5;
-    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, p.lo4 & 0x100);      // s16_tilemap.h; lo4 bit 8: row-major order (A/B experiments)
+    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, !(p.lo4 & 0x100));   // row-major tile lanes; lo4 bit 8: the conflict-free order of s16_tilemap.h (experiment)
     const int rl = tln.rl, xl = tln.xl;
     const int r = wave / KW, k = wave % KW;     // wave pair / K slice
     const int rs = CS ? 0 : r;                  // spatial tile of the workgroup
@@ -333,8 +334,8 @@ int launch2(const drc_s16conv_params& p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-// lo4 (unused by the arithmetic of this layer) carries the experiment bits: 0x100 row-major tile lanes, 0x200 interleaved slab rows (no DEI),
-// 0x400 no cout split.  0 = the product forms.
+// lo4 (unused by the arithmetic of this layer) carries the experiment bits: 0x100 the conflict-free tile lanes of s16_tilemap.h, 0x200 interleaved
+// slab rows (no DEI), 0x400 no cout split.  0 = the product forms.
 template <int KW, int RT, int WT, int RING, int RING_CS>
 int launch(const drc_s16conv_params& p, hipStream_t stream) {
     const bool dei = !(p.lo4 & 0x200);

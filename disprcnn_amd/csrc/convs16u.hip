@@ -78,7 +78,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
     float* bnlds = (float*)(lds + RING * SLAB);   // [2 g][2: scale, shift][16] floats of this cout tile
 
     const int n_ = lane & 31, g = lane >> 5;
-    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, p.lo4 & 0x100);       // conflict-free B fragment reads (s16_tilemap.h); lo4 bit 8: row-major order
+    const S16TileLane tln = s16_tile_lane<RT, WT>(n_, !(p.lo4 & 0x100));    // row-major tile lanes; lo4 bit 8: the conflict-free order of s16_tilemap.h (experiment)
     const int rl = tln.rl, xl = tln.xl;
     const int n_ct = p.cout / 32;
     const int ct = (int)((blockIdx.x >> 3) % n_ct);   // cout tiles side by side on one XCD (see convs16.hip)

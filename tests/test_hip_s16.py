@@ -212,9 +212,9 @@ def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, 
     _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
 
 
-# the forms the product kernels replaced stay selectable (lo4 bits of a non-cost-volume launch: 0x100 row-major tile lanes instead of the
-# conflict-free map of s16_tilemap.h, 0x200 interleaved slab rows and 0x400 no cout split in the stride-2 kernel) and must stay correct: the
-# A/B timings of tools/experiments/exp_s16_forms.py compare like with like
+# the forms measured against the product kernels stay selectable (lo4 bits of a non-cost-volume launch: 0x100 the bank-conflict-free tile
+# lanes of s16_tilemap.h -- slower, see there --, 0x200 interleaved slab rows and 0x400 no cout split in the stride-2 kernel) and must stay
+# correct: the A/B timings of tools/experiments/exp_s16_forms.py compare like with like
 @pytest.mark.parametrize("kind,N,cin,cout,D,H,W,relu,with_res,lo4", [
     ("s1", 3, 64, 64, 6, 14, 14, True, True, 0x100), ("s1", 5, 64, 64, 3, 7, 7, True, False, 0x100), ("s1", 2, 32, 32, 3, 6, 14, False, True, 0x100),
     ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x100), ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x200), ("s2", 3, 32, 64, 12, 28, 28, True, False, 0x400),

@@ -1,7 +1,8 @@
 """A/B of the hourglass kernels' forms at the bench's shapes (Config A, 1024 and 256 ROIs; Config B, 16 and 64 ROIs): the product forms
-(lo4 = 0: conflict-free tile lanes of s16_tilemap.h, de-interleaved slab rows and the cout split of convs16d.hip) against the forms they
-replaced (lo4 bits 0x100 row-major tile lanes, 0x200 interleaved rows, 0x400 no cout split).  Prints us per launch and the results' identity
-(the forms compute the same sums in the same order: bit-identical outputs expected).
+(lo4 = 0: row-major tile lanes, de-interleaved slab rows and the cout split of convs16d.hip) against the alternatives (lo4 bits 0x100 the
+bank-conflict-free tile lanes of s16_tilemap.h, 0x200 interleaved rows, 0x400 no cout split).  Prints us per launch and the results' identity
+(the forms compute the same sums in the same order: bit-identical outputs expected).  Results of the run that set the defaults:
+profiles/r5_exp_s16_forms.log (there 0x100 still meant ROW-MAJOR lanes: the grouped order was the default under test).
     python tools/experiments/exp_s16_forms.py            (on an MI355X)
 """
 import os
