@@ -104,8 +104,8 @@ def max_over_ranks(elapsed, world, dev):
     return elapsed
 
 
-DTYPE = ("f32 (every 3x3x3 / transposed layer of the regressor: split-f16 -- each fp32 value carried as hi + lo fp16, 3 f16-MFMA products per "
-         "fp32 product, f32 accumulate; fp32-class error, tests/test_hip_s16.py.  The two 32->1 layers and the soft-argmin: f32 VALU)")
+DTYPE = ("f32 (every convolution of the regressor, the three 32->1 heads included: split-f16 -- each fp32 value carried as hi + lo fp16, 3 f16-MFMA "
+         "products per fp32 product, f32 accumulate; fp32-class error, tests/test_hip_s16.py.  Head gather and soft-argmin: f32 VALU)")
 
 
 def headline(total_rois, elapsed, args, world, N, roofline, cpu, extra):

@@ -49,7 +49,8 @@ class DrcS16ConvParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("res", C.c_void_p),
                 ("y16", C.c_void_p), ("y32", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
                 ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("lo4", C.c_int32), ("dil", C.c_int32)]
+                ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("lo4", C.c_int32), ("dil", C.c_int32),
+                ("head", C.c_void_p), ("w1", C.c_void_p)]
 
 
 class DrcFpnPyramid(C.Structure):
@@ -154,6 +155,7 @@ _SIGS = {
     "drc_rs16_from_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_rs16_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "drc_rs16_to_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_head_gather_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_float, _P]),
     "drc_conv2d_k3_s16_supported": (_I, [_I, _I, _I, _I, _I]),
     "drc_conv2d_k3_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
     "drc_deconv3d_k3s2_direct_s16_fwd": (_I, [C.POINTER(DrcTapconvParams), _P, _P]),

@@ -62,8 +62,17 @@ constexpr int RING = 3;
 // hourglass' half- and quarter-resolution maps: 28 of 32 lanes busy there as well).
 // RES: a residual tensor is added; Y32: the output is the blocked fp32 tensor (cout-1 head's input) instead of RS16.  Template flags, not
 // run-time ones: a step issues exactly the loads / stores it needs (the counted waits depend on the numbers) and no dropped ones.
-template <int KW, bool CV, int RT = 1, int WT = 28, bool RES = false, bool Y32 = false>
+// HEAD (classif[0] of a head; KW == 2, full-resolution tiles): the layer's output is NOT stored.  The 32 -> 1 convolution that follows it
+// (classif[2], stackhourglass.py:78-88) is linear, out[o] = sum_t sum_c w1[t][c] a[c][o + off(t)] = sum_t P[t][o + off(t)] with the pointwise
+// product P[t][v] = sum_c w1[t][c] a[c][v] -- and a finishing wave holds exactly the B fragment of its 16 channels of a[.][v] (the hi / lo
+// halfs it would store).  So each K-slice wave runs three more MFMAs per plane (A = w1's 27 taps as rows, split-f16 like every product
+// here), the slice-1 half goes through LDS to the slice-0 wave, which sums the three depth taps over the walk and stores, per SOURCE voxel,
+// the nine in-plane partial sums S[kh*3+kw][v] = sum_kd P[kd,kh,kw][z + kd - 1 plane of v] (48-byte slots [N][D][H][W][12] floats: j 0..4
+// at 0..4, j 5..8 at 8..11).  drc_head_gather_fwd then adds the nine shifted S values per output voxel (+ the previous head's cost).
+// HBM per voxel: 48 B written + 48 read instead of 128 written (blocked fp32) + ~175 read by the stand-alone cout-1 kernel.
+template <int KW, bool CV, int RT = 1, int WT = 28, bool RES = false, bool Y32 = false, bool HEAD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convs16_kernel(const drc_s16conv_params p) {
+    static_assert(!HEAD || (KW == 2 && !CV && RT == 1 && !RES && !Y32), "the fused cout-1 head is a form of the 32 -> 32 full-resolution layer");
     constexpr int TX = WT;                      // output columns per tile
     constexpr int SX = WT + 2;                  // staged columns (TX + halo)
     constexpr int RPW = 4 / KW;                 // MFMA tiles per workgroup (RPW * RT output rows)
@@ -81,6 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* ring = lds;
     char* xchg = lds + RING * SLAB;             // [2 parities][4 waves][XW]
+    char* pbuf = xchg + 2 * 4 * XW;             // HEAD: [2 parities][2 tiles][XW] the K-slice-1 halves of P
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -124,6 +134,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int co = ct * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
         sc[e] = p.scale[co];
         sh[e] = p.shift[co];
+    }
+    // ---- HEAD: the 32 -> 1 layer's weights as an A operand, [K slice][hi, lo][lane][8 halfs] (s16.pack_head_weight_s16: MFMA row
+    // (r&3) + 8(r>>2) + 4g' = tap (kd = r % 3, j = 5g' + r / 3), so lane half g' of the product holds P[kd][j] in register 3(j - 5g') + kd)
+    f16x8 w1h = {}, w1l = {};
+    if constexpr (HEAD) {
+        const char* wb = (const char*)p.w1 + (long)k * 2048 + lane * 16;
+        w1h = *(const f16x8*)wb;
+        w1l = *(const f16x8*)(wb + 1024);
     }
     // ---- LDS-DMA geometry (column independent): this wave's instructions id = wave*NL + i -> (cb, chunk, half of the plane)
     int srcrow[2], srcx[2];
@@ -210,9 +228,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // output context of a column: unit bases + this lane's voxel offsets (plane 0, padded coordinates + 1)
-    struct Ctx { char* y16b; char* y32b; const char* resb; unsigned o16, o32; bool ok; };
+    const long hs_planeB = (long)H * W * 48, hs_nB = (long)D * hs_planeB;          // HEAD: float [N][D][H][W][12]
+    struct Ctx { char* y16b; char* y32b; const char* resb; char* hsb; unsigned o16, o32, ohs; bool ok; };
     auto ctx_of = [&](const Col& c) __attribute__((always_inline)) {
         Ctx q;
+        q.hsb = HEAD ? (char*)p.head + (long)c.n * hs_nB : (char*)p.w;
+        q.ohs = (unsigned)(((long)(c.y0 + r * RT + rl) * W + (c.x0 + xl)) * 48 + g * 32);
         q.y16b = p.y16 ? (char*)p.y16 + (long)c.n * ynB : (char*)p.w;
         q.y32b = p.y32 ? (char*)p.y32 + (long)c.n * b_nB : (char*)p.w;
         q.resb = p.res ? (const char*)p.res + (long)c.n * ynB : (const char*)p.w;
@@ -248,6 +269,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int e = 0; e < 16; ++e) acc[a_][e] = 0.f;
 #pragma unroll
     for (int a_ = 0; a_ < 3; ++a_) resv[a_][0] = resv[a_][1] = (u32x4){0u, 0u, 0u, 0u};
+    // HEAD: the P of the plane finalized in the previous step (this wave's K slice) and the running depth sums of the two output planes
+    // still open (SC: the next to complete; SB: the one after), five (kh, kw) per lane
+    f32x16 pkeep = {};
+    float SC[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, SB[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     stage(s_cur, 0, 0);
     stage(s_cur, 1 < D ? 1 : 0, 1);
     __builtin_amdgcn_s_waitcnt(S16_WAITCNT(NL, 15));      // plane 0 landed (step 0's own wait assumes a full previous step)
@@ -320,6 +345,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int q = 0; q < 4; ++q) part[q] = *(const f32x4*)(xb + q * XW + k * 1024);
             }
         }
+        f32x4 pin[4];
+        if constexpr (HEAD) {       // the other K slice's half of the P computed in the previous step
+            const char* pb = pbuf + ((gs - 1) & 1) * (2 * XW) + r * XW + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pin[q] = *(const f32x4*)(pb + q * 1024);
+        }
         // its residual was requested at the head of the previous step: younger are that step's DMAs and stores and this step's requests
         if constexpr (RES) {
             __builtin_amdgcn_s_waitcnt(S16_WAITCNT(2 * NL + NS + NR, 15));
@@ -373,6 +404,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[A2][e] = 0.f;
         };
+        // HEAD, two parts, both where the other forms store.  (1) The P of the plane finalized in the PREVIOUS step is complete (own K slice in
+        // pkeep, the other in pin): source plane s = t - 3 of this column (t < 3: the previous column's D - 3 + t).  It closes output plane
+        // s - 1 (kd = 2), adds to plane s (kd = 1) and opens s + 1 (kd = 0); s == 0 (t == 3) instead closes the previous column's last plane
+        // and drops what its last source plane opened.  One plane is stored per step: this column's t - 4, or the previous one's D - 4 + t.
+        // (2) The P of the plane finalized in THIS step from the hi / lo halfs just computed.
+        auto head = [&]() __attribute__((always_inline)) {
+          if constexpr (HEAD) {
+            const bool scur = t >= 4, first = t == 3;
+            const int ps = scur ? t - 4 : D - 4 + t;
+            float o_[5];
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const float p0 = pkeep[3 * jj] + pin[(3 * jj) >> 2][(3 * jj) & 3];
+                const float p1 = pkeep[3 * jj + 1] + pin[(3 * jj + 1) >> 2][(3 * jj + 1) & 3];
+                const float p2 = pkeep[3 * jj + 2] + pin[(3 * jj + 2) >> 2][(3 * jj + 2) & 3];
+                o_[jj] = SC[jj] + (first ? 0.f : p2);
+                SC[jj] = (first ? 0.f : SB[jj]) + p1;
+                SB[jj] = p0;
+            }
+            const bool ok_ = k == 0 && (scur ? cx_cur.ok : cx_prev.ok) && ps >= 0 && ps < D;
+            const __amdgpu_buffer_rsrc_t hsr = __builtin_amdgcn_make_buffer_rsrc(scur ? cx_cur.hsb : cx_prev.hsb, 0, 0x7FFFFF00, 0x00020000);
+            const unsigned oh_ = scur ? cx_cur.ohs : cx_prev.ohs;
+            const unsigned po = ok_ ? (unsigned)((long)ps * hs_planeB) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){o_[0], o_[1], o_[2], o_[3]}), hsr, oh_ + po, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o_[4]), hsr, oh_ + 16 + (g ? 0x80000000u : po), 0, 0);
+            f16x8 bh_, bl_;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bh_[e] = vh[e]; bl_[e] = vl[e]; }
+            f32x16 z_ = {};
+            z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bh_, z_, 0, 0, 0);
+            z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bl_, z_, 0, 0, 0);
+            z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bh_, z_, 0, 0, 0);
+            pkeep = z_;
+            if (k == 1) {
+                char* pb = pbuf + (gs & 1) * (2 * XW) + r * XW + lane * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(pb + q * 1024) = (f32x4){z_[q * 4], z_[q * 4 + 1], z_[q * 4 + 2], z_[q * 4 + 3]};
+            }
+          }
+        };
         if constexpr (COMPUTE) {
             constexpr bool K0 = KIND != 2, K2 = KIND != 1;          // taps kd = 0 (plane t+1 exists), kd = 2 (plane t-1 exists)
             const __attribute__((address_space(3))) char* sb = ringl + J * SLAB + bfrag;
@@ -389,7 +460,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
                 const int t0 = kh * 3 + kw, t1 = 9 + t0, t2 = 18 + t0;       // taps kd = 0, 1, 2
-                if (q == OWN) stores();
+                if (q == OWN) {
+                    if constexpr (HEAD) head();
+                    else stores();
+                }
                 if (q < 8) {
                     if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
                     acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
@@ -420,7 +494,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else {
 #pragma unroll
             for (int e = 0; e < OWN; ++e) fin(e);
-            stores();
+            if constexpr (HEAD) head();
+            else stores();
             publish();
         }
         ++gs;
@@ -457,18 +532,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // drain: publish the last plane, finalize the last two
     step(D, I0{}, I3{});
     step(D + 1, I1{}, I3{});
+    if constexpr (HEAD) {
+        // the P of the last plane arrives a step after its finalize (it closes plane D - 2); then the column's last plane is complete
+        step(D + 2, I2{}, I3{});
+        const bool ok_ = k == 0 && cx_cur.ok;
+        const __amdgpu_buffer_rsrc_t hsr = __builtin_amdgcn_make_buffer_rsrc(cx_cur.hsb, 0, 0x7FFFFF00, 0x00020000);
+        const unsigned po = ok_ ? (unsigned)((long)(D - 1) * hs_planeB) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){SC[0], SC[1], SC[2], SC[3]}), hsr, cx_cur.ohs + po, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, SC[4]), hsr, cx_cur.ohs + 16 + (g ? 0x80000000u : po), 0, 0);
+    }
 }
 
-template <int KW, bool CV, int RT, int WT, bool RES, bool Y32>
+template <int KW, bool CV, int RT, int WT, bool RES, bool Y32, bool HEAD = false>
 int launch2(const drc_s16conv_params& p, hipStream_t stream) {
     constexpr int CBI = KW / 2;
     constexpr int SLAB = CBI * 8 * CPB;
     constexpr int XW = 4096;
-    constexpr size_t lds = RING * SLAB + 2 * 4 * XW;
+    constexpr size_t lds = RING * SLAB + 2 * 4 * XW + (HEAD ? 2 * 2 * XW : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)convs16_kernel<KW, CV, RT, WT, RES, Y32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)convs16_kernel<KW, CV, RT, WT, RES, Y32, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     constexpr int rows = (4 / KW) * RT;
@@ -477,12 +561,16 @@ int launch2(const drc_s16conv_params& p, hipStream_t stream) {
     const int n_ct = p.cout / 32;
     long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
     while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
-    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT, RES, Y32>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((convs16_kernel<KW, CV, RT, WT, RES, Y32, HEAD>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
 
 template <int KW, bool CV, int RT = 1, int WT = 28>
 int launch(const drc_s16conv_params& p, hipStream_t stream) {
+    if (p.head) {
+        if constexpr (KW == 2 && !CV && RT == 1) return launch2<KW, CV, RT, WT, false, false, true>(p, stream);
+        else return -4;
+    }
     if (p.y32) {
         if constexpr (KW == 2 && !CV && RT == 1) return launch2<KW, CV, RT, WT, false, true>(p, stream);
         else return -4;
@@ -508,7 +596,12 @@ extern "C" int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* pp, void* stream)
     if (!pp) return -1;
     const drc_s16conv_params& p = *pp;
     const bool cv = p.left || p.right;
-    if (!p.w || !p.scale || !p.shift || (!p.y16 == !p.y32)) return -1;          // exactly one output
+    if (!p.w || !p.scale || !p.shift) return -1;
+    if (p.head) {                                                                   // fused cout-1 head: no tensor output, 32 -> 32 at full resolution
+        if (!p.w1 || p.y16 || p.y32 || p.res || cv) return -1;
+        if (p.cin != 32 || p.cout != 32 || p.W % 28 || p.D < 6) return -4;
+        if ((long)p.D * p.H * p.W * 48 >= 0x7FFFFF00L) return -5;
+    } else if (!p.y16 == !p.y32) return -1;                                         // exactly one output
     if (p.y32 && (p.res || p.cin != 32 || p.W % 28)) return -4;                     // blocked fp32 output: the 32-channel full-resolution layers without residual
     if (cv && p.res) return -4;
     if (cv ? (!p.left || !p.right || p.cin != 64) : !p.x) return -1;

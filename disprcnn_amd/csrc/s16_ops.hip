@@ -173,3 +173,42 @@ extern "C" int drc_rs16_to_blocked(const void* y16, float* xb, int N, int C, int
                        D, H, W, pd_out, ph_out, pw_out, cb16_total, cb16_off, pd);
     return (int)hipGetLastError();
 }
+
+// ---- the second half of a fused cout-1 head (convs16.hip, HEAD form): nine shifted in-plane partial sums per output voxel
+namespace {
+__global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ S, const float* __restrict__ res, float* __restrict__ cost,
+                                                          long total, int H, int W, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W);
+    const long row = i / W;                 // (n * D + z) * H + y
+    const int y = (int)(row % H);
+    float a = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int yy = y + kh - 1;
+        if (yy < 0 || yy >= H) continue;
+        const float* sr = S + ((row + (kh - 1)) * W) * 12;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int xx = x + kw - 1;
+            if (xx < 0 || xx >= W) continue;
+            const int j = kh * 3 + kw;
+            a += sr[(long)xx * 12 + (j < 5 ? j : j + 3)];
+        }
+    }
+    a *= scale;
+    cost[i] = res ? a + res[i] : a;
+}
+}  // namespace
+
+extern "C" int drc_head_gather_fwd(const float* S, const float* res, float* cost, int N, int D, int H, int W, float scale, void* stream) {
+    if (!S || !cost) return -1;
+    if (N < 0 || D <= 0 || H <= 0 || W <= 0) return -2;
+    if (N == 0) return 0;
+    const long total = (long)N * D * H * W;
+    const long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffL) return -3;
+    hipLaunchKernelGGL(head_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, S, res, cost, total, H, W, scale);
+    return (int)hipGetLastError();
+}

@@ -983,6 +983,14 @@ def conv3d_cout1(x, w27, res, out):
     _lib.check(st, "drc_conv3d_cout1_fwd")
 
 
+def head_gather(S, scale, res, out):
+    """The second half of a fused cout-1 head (ConvPlanS16.run(head=...)): out dense [N,D,H,W] = (res or 0) + scale * the nine shifted
+    in-plane partial sums of S (fp32 [N][D][H][W][12])."""
+    N, D, H, W = out.shape
+    st = _lib.lib().drc_head_gather_fwd(_ptr(S), _ptr(res), _ptr(out), N, D, H, W, C.c_float(scale), _stream_ptr(out.device))
+    _lib.check(st, "drc_head_gather_fwd")
+
+
 def upsample_softargmin(cost, disp, maxdisp, mindisp):
     N, Dp, Hp, Wp = cost.shape
     _, H, W = disp.shape
@@ -1353,6 +1361,7 @@ def cost_volume16_blocked(left, right, out, lo4, hi4, in_blocked_pad=-1):
 
 
 # ------------------------------------------------------------------------------------------- split-f16 ("f16x2") path, round 5
+HEAD_FUSED = {"enabled": True}       # eval, split-f16 regressor: classif[0] + the 32 -> 1 layer as one fused launch + a gather (convs16.hip HEAD form) instead of a blocked fp32 tensor + cout1_mfma.hip
 LASTCONV_S16 = {"enabled": True}     # eval, split-f16 2D schedule: lastconv[0] (320 -> 128) as three chained split-f16 launches over the concat's parts (runtime._ws2d_s16)
 S16 = {"enabled": True}       # eval: the stride-1 3x3x3 layers at full resolution on the f16 matrix cores in split arithmetic (convs16.hip)
 
@@ -1449,8 +1458,8 @@ class ConvPlanS16:
         if nw in (14, 7):
             rt, wt = (2, 14) if nw == 14 else (4, 7)
         if kind == "s1":
-            self._kfmt = "convs16_kernel<%d,%s,%d,%d,%%s,%%s>" % (cin // 16, "true" if cv else "false", rt, wt)
-            self.kname = self._kfmt % ("false", "false")          # (the residual / blocked-fp32-output template flags follow the call's arguments)
+            self._kfmt = "convs16_kernel<%d,%s,%d,%d,%%s,%%s,%%s>" % (cin // 16, "true" if cv else "false", rt, wt)
+            self.kname = self._kfmt % ("false", "false", "false")  # (the residual / blocked-fp32-output / fused-head template flags follow the call's arguments)
         elif kind == "2d":
             # convs16r.hip's dispatch: (waves over K, K slices per wave)
             wide = cin == 64 and W % 56 == 0 and cout == 128 and N * (H // 28) * (W // 56) * (cout // 32) >= 256
@@ -1466,8 +1475,15 @@ class ConvPlanS16:
         else:
             self.kname = "convs16u_kernel<%d,%d>" % (rt, wt)
 
-    def run(self, x16, w16, scale, shift, y16=None, y32=None, res=None, left=None, right=None, lo4=0):
+    def run(self, x16, w16, scale, shift, y16=None, y32=None, res=None, left=None, right=None, lo4=0, head=None):
+        """head = (packed 32 -> 1 weights of s16.pack_head_weight_s16, S buffer fp32 of >= N*D*H*W*12 floats): the layer is classif[0] of a
+        head, its output is not stored, the partial sums of the cout-1 layer behind it are (head_gather finishes it)."""
         from ._lib import DrcS16ConvParams
+        if head is not None:
+            if self.kind != "s1" or self.cv or (self.cin, self.cout) != (32, 32) or self.W % 28 or self.D < 6 or y16 is not None or y32 is not None or res is not None:
+                raise ValueError("ConvPlanS16.run: the fused head is the 32 -> 32 full-resolution layer without another output")
+            if head[1].dtype != torch.float32 or head[1].numel() < self.N * self.D * self.H * self.W * 12 or head[0].dtype != torch.float16 or head[0].numel() != 2048:
+                raise ValueError("ConvPlanS16.run: head = (halfs [2][2][64][8], fp32 buffer of N*D*H*W*12)")
         if x16 is not None and (x16.N < self.N or (x16.C, x16.D, x16.H, x16.W, x16.pd) != (self.cin, self.D, self.H, self.W, self.pd)):
             raise ValueError("ConvPlanS16.run: input geometry differs from the plan")
         for t_ in (y16, res):
@@ -1488,7 +1504,8 @@ class ConvPlanS16:
         p = DrcS16ConvParams(_ptr(x16.storage) if x16 is not None else None, _ptr(w16), _ptr(scale), _ptr(shift),
                              _ptr(res.storage) if res is not None else None, _ptr(y16.storage) if y16 is not None else None,
                              _ptr(y32.storage) if y32 is not None else None, _ptr(left.storage) if self.cv else None,
-                             _ptr(right.storage) if self.cv else None, self.N, self.D, self.H, self.W, self.cin, self.cout, int(self.relu), int(lo4), int(self.dil))
+                             _ptr(right.storage) if self.cv else None, self.N, self.D, self.H, self.W, self.cin, self.cout, int(self.relu), int(lo4), int(self.dil),
+                             _ptr(head[1]) if head is not None else None, _ptr(head[0]) if head is not None else None)
         dev = self.device
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1499,7 +1516,7 @@ class ConvPlanS16:
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(dev))
             if self.kind == "s1":
-                kn = self._kfmt % ("true" if res is not None else "false", "true" if y32 is not None else "false")
+                kn = self._kfmt % ("true" if res is not None else "false", "true" if y32 is not None else "false", "true" if head is not None else "false")
             elif self.kind == "2d":
                 kn = self._kfmt % ("true" if res is not None else "false")
             else:

@@ -472,8 +472,15 @@ class PSMNetRuntime:
         for k in (1, 2, 3):
             S(f"hg{k}.c1", 64, *half); S(f"hg{k}.pre", 64, *half); S(f"hg{k}.post", 64, *half)
             S(f"hg{k}.c3", 64, *quart); S(f"hg{k}.c4", 64, *quart)
-            t[f"cls_t{k}"] = pool.blocked(f"cls_t{k}", N, 32, *full, 1, 1, 1)        # fp32: the cout-1 head reads it
             t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
+        # the heads: classif[0] + the 32 -> 1 layer fused (convs16.hip HEAD form: partial sums S, 48 B per voxel, one buffer for the three
+        # heads) where the map is a multiple of 28 columns; else classif[0] writes a blocked fp32 tensor that cout1_mfma.hip reads
+        fused = E.HEAD_FUSED["enabled"] and Wp % 28 == 0 and Dp >= 6
+        if fused:
+            t["hs"] = pool.dense("hs", N, Dp, Hp, Wp, 12)
+        else:
+            for k in (1, 2, 3):
+                t[f"cls_t{k}"] = pool.blocked(f"cls_t{k}", N, 32, *full, 1, 1, 1)    # fp32: the cout-1 head reads it
         dev = self.device
         P = lambda kind, ci, co, dims, relu, cv=False: E.ConvPlanS16(N, ci, co, *dims, relu, cv=cv, device=dev, kind=kind)
         p = {}
@@ -489,8 +496,20 @@ class PSMNetRuntime:
             p[f"hg{k}.conv5"] = P("up", 64, 64, quart, True)
             p[f"hg{k}.conv6"] = P("up", 64, 32, half, False)
             p[f"classif{k}.0"] = P("s1", 32, 32, full, True)
-        ws = dict(t=t, p=p, pool=pool, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
+        ws = dict(t=t, p=p, pool=pool, fused_heads=fused, flops=sum(pl.flops for pl in p.values()) + 3 * 2 * 27 * 32 * N * Dp * Hp * Wp)
         return self._ws_put(key, ws)
+
+    def _head_weights_s16(self):
+        """{k: (packed 32 -> 1 weights of the fused head, 2^-wexp)} for classif1..3[2], rebuilt with the packed fp32 weights."""
+        if getattr(self, "_h16_version", None) == self._weights_version and getattr(self, "_h16", None) is not None:
+            return self._h16
+        from ... import s16 as S
+        out = {}
+        for k in (1, 2, 3):
+            wp, wexp = S.pack_head_weight_s16(getattr(self.model, f"classif{k}")[2].weight)
+            out[k] = (wp.to(self.device), 2.0 ** -wexp)
+        self._h16, self._h16_version = out, self._weights_version
+        return out
 
     def _regress_s16(self, ws, W, lo4):
         """The schedule of _regress on RS16 tensors, every layer but the cout-1 heads in split-f16 arithmetic; ws['t']['featL'/'featR'] hold
@@ -517,9 +536,14 @@ class PSMNetRuntime:
             run(f"hg{k}.conv5", hg + ".conv5", f"hg{k}.c4", y16=f"hg{k}.post", res=presqu)      # relu(conv5 + presqu|pre)
             run(f"hg{k}.conv6", hg + ".conv6", f"hg{k}.post", y16=f"out{k}", res="cost0")       # out_k = conv6 + cost0
         prev = None
+        h16 = self._head_weights_s16() if ws["fused_heads"] else None
         for k in (1, 2, 3):
-            run(f"classif{k}.0", f"classif{k}.0", f"out{k}", y32=f"cls_t{k}")
-            E.conv3d_cout1(t[f"cls_t{k}"], W[f"classif{k}.2"], prev, t[f"costk{k}"])            # cumulative heads
+            if h16 is not None:
+                run(f"classif{k}.0", f"classif{k}.0", f"out{k}", head=(h16[k][0], t["hs"]))
+                E.head_gather(t["hs"], h16[k][1], prev, t[f"costk{k}"])                         # cumulative heads
+            else:
+                run(f"classif{k}.0", f"classif{k}.0", f"out{k}", y32=f"cls_t{k}")
+                E.conv3d_cout1(t[f"cls_t{k}"], W[f"classif{k}.2"], prev, t[f"costk{k}"])
             prev = t[f"costk{k}"]
         return t["costk1"], t["costk2"], t["costk3"]
 

@@ -94,6 +94,45 @@ def pack_weight_s16(w):
     return out.contiguous(), wexp
 
 
+def head_rows():
+    """[32] (kd, j) or None: which tap of the 32 -> 1 layer sits in MFMA row m of the fused head's A operand (convs16.hip, HEAD form).  The
+    product's lane half g' holds rows (r&3) + 8(r>>2) + 4g' in register r; register 3jj + kd is tap (kd, j = 5g' + jj), so that the three depth
+    taps of one in-plane tap sit in one lane: g' = 0 takes j 0..4 (15 rows), g' = 1 takes j 5..8 (12 rows), the other rows are zero."""
+    rows = [None] * 32
+    for g in range(2):
+        for r in range(16):
+            m = (r & 3) + 8 * (r >> 2) + 4 * g
+            jj, kd = divmod(r, 3)
+            if jj < (5 if g == 0 else 4):
+                rows[m] = (kd, 5 * g + jj)
+    return rows
+
+
+def pack_head_weight_s16(w1):
+    """[1,32,3,3,3] fp32 (classif[2], reference stackhourglass.py:78-88) -> (halfs [2 K slices][hi, lo][64 lanes][8], wexp): the A operand
+    of the fused head, rows by head_rows(), k element e of lane group g of slice s = channel 4g + 8(2s + (e>>2)) + (e&3) (the RS16 chunk
+    a finishing wave of the 32 -> 32 layer holds), scaled by 2^wexp like pack_weight_s16."""
+    w1 = w1.detach().float().cpu()
+    assert tuple(w1.shape) == (1, 32, 3, 3, 3)
+    amax = float(w1.abs().max())
+    wexp = int(math.floor(math.log2(16384.0 / amax))) if amax > 0 else 0
+    wexp = max(min(wexp, 24), -24)
+    ws = w1[0] * (2.0 ** wexp)                       # [32, 3, 3, 3]
+    full = torch.zeros(2, 64, 8, dtype=torch.float32)
+    rows = head_rows()
+    for s_ in range(2):
+        for lane in range(64):
+            m, g = lane & 31, lane >> 5
+            if rows[m] is None:
+                continue
+            kd, j = rows[m]
+            for e in range(8):
+                c = 4 * g + 8 * (2 * s_ + (e >> 2)) + (e & 3)
+                full[s_, lane, e] = ws[c, kd, j // 3, j % 3]
+    hi, lo = split(full)
+    return torch.stack((hi, lo), 1).contiguous(), wexp            # [2][2][64][8]
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 

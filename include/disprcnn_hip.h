@@ -377,9 +377,18 @@ typedef struct drc_s16conv_params {
     int32_t cin, cout, relu;
     int32_t lo4;         /* cost-volume variant: disparity of volume slice 0 (mindisp/4) */
     int32_t dil;         /* drc_conv2d_k3_s16_fwd only: dilation (0 or 1: none; 2) */
+    float* head;         /* drc_conv3d_k3_s16_fwd, cin = cout = 32, W % 28 == 0, D >= 6, y16 = y32 = res = NULL: the layer is classif[0] of a head and
+                            its output is not stored; the in-plane partial sums of the 32 -> 1 convolution behind it (classif[2],
+                            stackhourglass.py:78-88) are: float [N][D][H][W][12], S[kh*3+kw] of the SOURCE voxel summed over the depth taps
+                            (j 0..4 at floats 0..4, j 5..8 at 8..11), scaled by 2^wexp of w1.  drc_head_gather_fwd finishes the layer. */
+    const void* w1;      /* with head: the 32 -> 1 weights as the MFMA A operand, halfs [2 K slices][hi, lo][64][8] (4 KiB) */
 } drc_s16conv_params;
 int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
+/* The second half of a fused head (p->head above): cost[n][z][y][x] = (res ? res[..] : 0) + scale * sum_{kh,kw} S[n][z][y+kh-1][x+kw-1][kh*3+kw]
+ * (sources outside the volume contribute zero: the convolution's zero padding); cost, res: dense float [N][D][H][W] (res = the previous
+ * head's cost, stackhourglass.py:142-144, or NULL); scale = 2^-wexp of the packed 32 -> 1 weights. */
+int drc_head_gather_fwd(const float* S, const float* res, float* cost, int N, int D, int H, int W, float scale, void* stream);
 /* The hourglass' other 3x3x3 layers in the same arithmetic and layout (x, y16, res: RS16; no blocked fp32 output, no cost-volume form):
  *   drc_conv3d_k3s2_s16_fwd   -- Conv3d k3 s2 p1 + BN + ReLU (convs16d.hip; reference hourglass conv1 / conv3, stackhourglass.py:9-12,17-19).
  *                                D, H, W = the INPUT dims (even); y16 has (D/2, H/2, W/2); no residual.

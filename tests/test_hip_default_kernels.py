@@ -38,12 +38,12 @@ def _model(dev, case, mx, mn, math="f32"):
 
 
 # (plan names: the last two template flags -- residual, blocked fp32 output -- follow the call's arguments and read false,false here)
-S16_LAYERS = {"dres0.0": "convs16_kernel<4,true,1,28,false,false>", "dres0.2": "convs16_kernel<2,false,1,28,false,false>",
-              "dres1.0": "convs16_kernel<2,false,1,28,false,false>", "dres1.2": "convs16_kernel<2,false,1,28,false,false>",
-              "classif1.0": "convs16_kernel<2,false,1,28,false,false>", "classif2.0": "convs16_kernel<2,false,1,28,false,false>",
-              "classif3.0": "convs16_kernel<2,false,1,28,false,false>"}
-S16_HG = {"conv1": "convs16d_kernel<2,2,14,3,true,true>", "conv2": "convs16_kernel<4,false,2,14,false,false>", "conv3": "convs16d_kernel<4,4,7,2,true,false>",
-          "conv4": "convs16_kernel<4,false,4,7,false,false>", "conv5": "convs16u_kernel<4,7>", "conv6": "convs16u_kernel<2,14>"}
+S16_LAYERS = {"dres0.0": "convs16_kernel<4,true,1,28,false,false,false>", "dres0.2": "convs16_kernel<2,false,1,28,false,false,false>",
+              "dres1.0": "convs16_kernel<2,false,1,28,false,false,false>", "dres1.2": "convs16_kernel<2,false,1,28,false,false,false>",
+              "classif1.0": "convs16_kernel<2,false,1,28,false,false,false>", "classif2.0": "convs16_kernel<2,false,1,28,false,false,false>",
+              "classif3.0": "convs16_kernel<2,false,1,28,false,false,false>"}
+S16_HG = {"conv1": "convs16d_kernel<2,2,14,3,true,true>", "conv2": "convs16_kernel<4,false,2,14,false,false,false>", "conv3": "convs16d_kernel<4,4,7,2,true,false>",
+          "conv4": "convs16_kernel<4,false,4,7,false,false,false>", "conv5": "convs16u_kernel<4,7>", "conv6": "convs16u_kernel<2,14>"}
 
 
 def _assert_bench_kernels_s16(ws):

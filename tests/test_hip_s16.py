@@ -212,6 +212,64 @@ def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, 
     _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
 
 
+@pytest.mark.parametrize("N,D,H,W,with_prev", [
+    (3, 12, 28, 28, True),          # Config A volume
+    (40, 12, 28, 28, False),        # a workgroup walks several columns: the depth sums cross column boundaries
+    (2, 6, 6, 56, True),            # two x tiles per row: the gather crosses tile boundaries; shortest supported depth
+    (9, 24, 4, 84, True),           # more units than XCDs, Config B depth
+    (1, 24, 56, 56, False),         # Config B volume
+])
+def test_fused_cout1_head_vs_fp64(dev, N, D, H, W, with_prev):
+    """classif[0] (3x3x3 32 -> 32 + BN + ReLU) and classif[2] (3x3x3 32 -> 1), stackhourglass.py:78-88, + the cumulative head add of
+    :142-144 as ONE split-f16 launch that stores per-source-voxel partial sums + drc_head_gather_fwd, against the two convolutions in fp64,
+    next to the fp32 chain of the same two layers (torch CPU)."""
+    g = torch.Generator().manual_seed(N * 1000 + D + H + W)
+    x = torch.randn(N, 32, D, H, W, generator=g)
+    w0 = torch.randn(32, 32, 3, 3, 3, generator=g) * (2.0 / (27 * 32)) ** 0.5
+    w1 = torch.randn(1, 32, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    scale = torch.rand(32, generator=g) + 0.5
+    shift = torch.randn(32, generator=g) * 0.1
+    prev = torch.randn(N, D, H, W, generator=g) if with_prev else None
+
+    def chain(dt):
+        a = F.conv3d(x.to(dt), w0.to(dt), padding=1) * scale.to(dt).view(1, -1, 1, 1, 1) + shift.to(dt).view(1, -1, 1, 1, 1)
+        y = F.conv3d(a.clamp_min(0), w1.to(dt), padding=1)[:, 0]
+        return y + prev.to(dt) if with_prev else y
+    ref = chain(torch.float64)
+    e32 = (chain(torch.float32).double() - ref).abs().max().item()
+    wp, wexp = s16.pack_weight_s16(w0.to(dev))
+    sc = (scale * (2.0 ** -wexp)).to(dev).contiguous()
+    hp, hexp = s16.pack_head_weight_s16(w1)
+    S = torch.full((N, D, H, W, 12), float("nan"), device=dev)          # every slot the gather reads must have been written
+    plan = E.ConvPlanS16(N, 32, 32, D, H, W, True, device=dev, kind="s1")
+    plan.run(E.RS16(N, 32, D, H, W, 1, dev).from_dense(x.to(dev)), wp, sc, shift.to(dev), head=(hp.to(dev), S))
+    out = torch.empty(N, D, H, W, device=dev)
+    E.head_gather(S, 2.0 ** -hexp, prev.to(dev) if with_prev else None, out)
+    got = out.cpu()
+    m = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"fused head N={N} {D}x{H}x{W}: max|err| {err:.3e} (fp32 chain {e32:.3e}), max|ref| {m:.3f}")
+    assert torch.isfinite(got).all()
+    assert err <= 2e-5 * m + 1e-5
+    assert err <= 2.0 * e32 + 1e-6 * m, (err, e32)
+
+
+def test_fused_head_validation(dev):
+    x = E.RS16(2, 32, 12, 28, 28, 1, dev)
+    w0 = torch.randn(32, 32, 3, 3, 3, device=dev)
+    wp, _ = s16.pack_weight_s16(w0)
+    one, zero = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    hp, _ = s16.pack_head_weight_s16(torch.randn(1, 32, 3, 3, 3))
+    plan = E.ConvPlanS16(2, 32, 32, 12, 28, 28, True, device=dev, kind="s1")
+    with pytest.raises(ValueError):
+        plan.run(x, wp, one, zero, head=(hp.to(dev), torch.empty(2 * 12 * 28 * 28 * 12 - 1, device=dev)))          # S too small
+    with pytest.raises(ValueError):
+        plan.run(x, wp, one, zero, y16=E.RS16(2, 32, 12, 28, 28, 1, dev), head=(hp.to(dev), torch.empty(2, 12, 28, 28, 12, device=dev)))
+    with pytest.raises(ValueError):
+        E.ConvPlanS16(2, 32, 32, 3, 28, 28, True, device=dev, kind="s1").run(E.RS16(2, 32, 3, 28, 28, 1, dev), wp, one, zero,
+                                                                            head=(hp.to(dev), torch.empty(2, 3, 28, 28, 12, device=dev)))   # D < 6
+
+
 # the forms measured against the product kernels stay selectable (lo4 bits of a non-cost-volume launch: 0x100 the bank-conflict-free tile
 # lanes of s16_tilemap.h -- slower, see there --, 0x200 interleaved slab rows and 0x400 no cout split in the stride-2 kernel) and must stay
 # correct: the A/B timings of tools/experiments/exp_s16_forms.py compare like with like
