@@ -404,18 +404,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[A2][e] = 0.f;
         };
-        // HEAD, two parts, both where the other forms store.  (1) The P of the plane finalized in the PREVIOUS step is complete (own K slice in
-        // pkeep, the other in pin): source plane s = t - 3 of this column (t < 3: the previous column's D - 3 + t).  It closes output plane
-        // s - 1 (kd = 2), adds to plane s (kd = 1) and opens s + 1 (kd = 0); s == 0 (t == 3) instead closes the previous column's last plane
-        // and drops what its last source plane opened.  One plane is stored per step: this column's t - 4, or the previous one's D - 4 + t.
-        // (2) The P of the plane finalized in THIS step from the hi / lo halfs just computed.
-        auto head = [&]() __attribute__((always_inline)) {
-          if constexpr (HEAD) {
-            const bool scur = t >= 4, first = t == 3;
-            const int ps = scur ? t - 4 : D - 4 + t;
-            float o_[5];
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj) {
+        // HEAD.  (1) The P of the plane finalized in the PREVIOUS step is complete (own K slice in pkeep, the other in pin): source plane
+        // s = t - 3 of this column (t < 3: the previous column's D - 3 + t).  It closes output plane s - 1 (kd = 2), adds to plane s (kd = 1) and
+        // opens s + 1 (kd = 0); s == 0 (t == 3) instead closes the previous column's last plane and drops what its last source plane opened.
+        // One plane is stored per step: this column's t - 4, or the previous one's D - 4 + t.  The five (kh, kw) of a lane are updated one per
+        // tap group (head_update(jj) in group jj), the stores go out in group 5.  (2) The P of the plane finalized in THIS step from the hi / lo
+        // halfs just computed: three MFMAs between those of the last tap group (head_mfma).
+        float o_[5];
+        f32x16 z_ = {};
+        f16x8 bh_ = {}, bl_ = {};
+        auto head_update = [&](int jj) __attribute__((always_inline)) {
+            if constexpr (HEAD) {
+                const bool first = t == 3;
                 const float p0 = pkeep[3 * jj] + pin[(3 * jj) >> 2][(3 * jj) & 3];
                 const float p1 = pkeep[3 * jj + 1] + pin[(3 * jj + 1) >> 2][(3 * jj + 1) & 3];
                 const float p2 = pkeep[3 * jj + 2] + pin[(3 * jj + 2) >> 2][(3 * jj + 2) & 3];
@@ -423,26 +423,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 SC[jj] = (first ? 0.f : SB[jj]) + p1;
                 SB[jj] = p0;
             }
-            const bool ok_ = k == 0 && (scur ? cx_cur.ok : cx_prev.ok) && ps >= 0 && ps < D;
-            const __amdgpu_buffer_rsrc_t hsr = __builtin_amdgcn_make_buffer_rsrc(scur ? cx_cur.hsb : cx_prev.hsb, 0, 0x7FFFFF00, 0x00020000);
-            const unsigned oh_ = scur ? cx_cur.ohs : cx_prev.ohs;
-            const unsigned po = ok_ ? (unsigned)((long)ps * hs_planeB) : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){o_[0], o_[1], o_[2], o_[3]}), hsr, oh_ + po, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o_[4]), hsr, oh_ + 16 + (g ? 0x80000000u : po), 0, 0);
-            f16x8 bh_, bl_;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bh_[e] = vh[e]; bl_[e] = vl[e]; }
-            f32x16 z_ = {};
-            z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bh_, z_, 0, 0, 0);
-            z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bl_, z_, 0, 0, 0);
-            z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bh_, z_, 0, 0, 0);
-            pkeep = z_;
-            if (k == 1) {
-                char* pb = pbuf + (gs & 1) * (2 * XW) + r * XW + lane * 16;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *(f32x4*)(pb + q * 1024) = (f32x4){z_[q * 4], z_[q * 4 + 1], z_[q * 4 + 2], z_[q * 4 + 3]};
+        };
+        auto head_store = [&]() __attribute__((always_inline)) {
+            if constexpr (HEAD) {
+                const bool scur = t >= 4;
+                const int ps = scur ? t - 4 : D - 4 + t;
+                const bool ok_ = k == 0 && (scur ? cx_cur.ok : cx_prev.ok) && ps >= 0 && ps < D;
+                const __amdgpu_buffer_rsrc_t hsr = __builtin_amdgcn_make_buffer_rsrc(scur ? cx_cur.hsb : cx_prev.hsb, 0, 0x7FFFFF00, 0x00020000);
+                const unsigned oh_ = scur ? cx_cur.ohs : cx_prev.ohs;
+                const unsigned po = ok_ ? (unsigned)((long)ps * hs_planeB) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){o_[0], o_[1], o_[2], o_[3]}), hsr, oh_ + po, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o_[4]), hsr, oh_ + 16 + (g ? 0x80000000u : po), 0, 0);
             }
-          }
+        };
+        auto head_mfma = [&](int i) __attribute__((always_inline)) {
+            if constexpr (HEAD) {
+                if (i == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { bh_[e] = vh[e]; bl_[e] = vl[e]; }
+                    z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bh_, z_, 0, 0, 0);
+                } else if (i == 1) {
+                    z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bl_, z_, 0, 0, 0);
+                } else {
+                    z_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bh_, z_, 0, 0, 0);
+                    pkeep = z_;                  // (the previous P was consumed by head_update in groups 0..4)
+                    if (k == 1) {
+                        char* pb = pbuf + (gs & 1) * (2 * XW) + r * XW + lane * 16;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *(f32x4*)(pb + q * 1024) = (f32x4){z_[q * 4], z_[q * 4 + 1], z_[q * 4 + 2], z_[q * 4 + 3]};
+                    }
+                }
+            }
         };
         if constexpr (COMPUTE) {
             constexpr bool K0 = KIND != 2, K2 = KIND != 1;          // taps kd = 0 (plane t+1 exists), kd = 2 (plane t-1 exists)
@@ -460,10 +471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 const f16x8 h_ = bh[q & 1], l_ = bl[q & 1];
                 const int t0 = kh * 3 + kw, t1 = 9 + t0, t2 = 18 + t0;       // taps kd = 0, 1, 2
-                if (q == OWN) {
-                    if constexpr (HEAD) head();
-                    else stores();
-                }
+                if (q == OWN && !HEAD) stores();
                 if (q < 8) {
                     if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
                     acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
@@ -475,27 +483,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A1], 0, 0, 0);
                     if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A2], 0, 0, 0);
                     if (q < OWN) fin(q);
+                    if (q < 5) head_update(q);
+                    if (q == 5) head_store();
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
-                    // last group: the finished plane's accumulator first, its publication in the shadow of the rest
+                    // last group: the finished plane's accumulator first, its publication in the shadow of the rest (HEAD: the three MFMAs of
+                    // the cout-1 product in between: a dependent chain, each link behind independent work)
                     if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], h_, acc[A2], 0, 0, 0);
                     if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], h_, acc[A0], 0, 0, 0);
+                    head_mfma(0);
                     if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t2], l_, acc[A2], 0, 0, 0);
                     acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], h_, acc[A1], 0, 0, 0);
                     if (K2) acc[A2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t2], h_, acc[A2], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    head_mfma(1);
                     if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t0], l_, acc[A0], 0, 0, 0);
                     acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t1], l_, acc[A1], 0, 0, 0);
                     if (K0) acc[A0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t0], h_, acc[A0], 0, 0, 0);
                     acc[A1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t1], h_, acc[A1], 0, 0, 0);
                     publish();
+                    head_mfma(2);
                 }
             }
         } else {
 #pragma unroll
             for (int e = 0; e < OWN; ++e) fin(e);
-            if constexpr (HEAD) head();
-            else stores();
+            if constexpr (HEAD) {
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) head_update(jj);
+                head_store();
+                head_mfma(0); head_mfma(1); head_mfma(2);
+            } else {
+                stores();
+            }
             publish();
         }
         ++gs;

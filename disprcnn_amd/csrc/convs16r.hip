@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
     const __attribute__((address_space(3))) char* ringl = (const __attribute__((address_space(3))) char*)ring;
     typedef const __attribute__((address_space(3))) f16x8 lds_frag;
 
-    const int n_xg = W / (28 * TPW), n_rb = H / RB;       // row blocks x parities: H / (RB * DIL) * DIL
+    // x groups and row blocks (DIL 2: row blocks x parities, H / (RB * DIL) * DIL).  DIL 1 takes ANY map size (round 5b: the trunk's and the
+    // FPN's maps, 94 x 310 ...): the last x group / row block is ragged -- its staged voxels beyond the row's end are the next chunk plane's
+    // data (finite, they only reach output columns that are not stored), its rows beyond the bottom halo are clamped onto the halo row, and
+    // the stores / residual loads of lanes and rows outside the map are dropped
+    const int n_xg = (W + 28 * TPW - 1) / (28 * TPW), n_rb = (H + RB - 1) / RB;
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_rb * n_xg;
 
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
     };
     auto stage = [&](const Src& q, int prow, int slot) __attribute__((always_inline)) {
         char* dst = ring + slot * SLAB;
-        if constexpr (DIL > 1) prow = prow < 0 ? 0 : (prow > H + 1 ? H + 1 : prow);       // rows beyond the stored halo: any zero row
+        prow = prow < 0 ? 0 : (prow > H + 1 ? H + 1 : prow);       // rows beyond the stored halo (dilated taps; a ragged last row block): any zero row
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)q.a, 0, 0x7FFFFF00, 0x00020000);
         const unsigned vo = q.v;        // a local: with the member access as the builtin's operand the host pass drops the kernel's stub (clang 19, ROCm 7.2)
 #pragma unroll
@@ -146,12 +150,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(dst + pl0 * CPB), 16, vo, so, 0, 0);
         }
     };
-    struct Ctx { char* y16b; const char* resb; unsigned o16; bool ok; };
+    struct Ctx { char* y16b; const char* resb; unsigned o16; bool ok; int rows; };
     auto ctx_of = [&](const Col& c) __attribute__((always_inline)) {
         Ctx q;
         q.y16b = (char*)p.y16 + (long)c.n * ynB;
         q.resb = p.res ? (const char*)p.res + (long)c.n * ynB : (const char*)p.w;
-        q.ok = n_ < 28;
+        q.ok = n_ < 28 && c.x0 + r * 28 + n_ < W;
+        q.rows = DIL == 1 ? (H - c.row0 < RB ? H - c.row0 : RB) : RB;          // output rows of this column inside the map
         const long base = (long)ct * cbB + (long)(c.row0 + 1) * rowB + (long)(c.x0 + r * 28 + n_ + 1) * 16;
         if constexpr (KW == 2) q.o16 = (unsigned)(base + (long)(k * 2 + g) * (Wp * 16));
         else q.o16 = (unsigned)(base + (long)((k >> 1) * 2 + g) * (Wp * 16) + (k & 1) * 8);
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
         asm volatile("" ::: "memory");
         const bool fcur = t >= 3;
         const int qf = fcur ? t - 3 : RB - 1, qp = t - 2;
-        const bool p_ok = cx_cur.ok && qp >= 0 && qp < RB;
+        const bool p_ok = cx_cur.ok && qp >= 0 && qp < cx_cur.rows;
         if constexpr (RES) {
             const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc((void*)cx_cur.resb, 0, nres, 0x00020000);
             const unsigned po = p_ok ? (unsigned)((long)qp * DIL * rowB) : 0x80000000u;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
         }
         const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc(fcur ? cx_cur.y16b : cx_prev.y16b, 0, 0x7FFFFF00, 0x00020000);
         const unsigned f_o16 = fcur ? cx_cur.o16 : cx_prev.o16;
-        const bool f_ok = (fcur ? cx_cur.ok : cx_prev.ok && t == 0) && qf < RB;
+        const bool f_ok = (fcur ? cx_cur.ok : cx_prev.ok && t == 0) && qf < (fcur ? cx_cur.rows : cx_prev.rows);
         f32x4 part[4];
         {
             const char* xb = xchg + ((gs - 1) & 1) * (4 * XW) + (r * KW) * XW + lane * 16;
@@ -368,7 +373,7 @@ int launch2(const drc_s16conv_params& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)convs16r_kernel<KW, KS, RES, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const long columns = (long)p.N * (p.H / RB) * (p.W / (28 * TPW));
+    const long columns = DIL == 1 ? (long)p.N * ((p.H + RB - 1) / RB) * ((p.W + 28 * TPW - 1) / (28 * TPW)) : (long)p.N * (p.H / RB) * (p.W / (28 * TPW));
     const int n_ct = p.cout / 32;
     // persistent grid: two workgroups per CU where the registers allow (KS == 1: one hides the other's barriers and waits), else one
     long blocks = (KS == 1 && !(p.lo4 & 4)) ? 512 : 256;
@@ -387,10 +392,9 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
 extern "C" int drc_conv2d_k3_s16_supported(int cin, int cout, int H, int W, int dil) {
     if (dil == 2) return cin == 128 && (cout == 32 || cout == 64 || cout == 128) && H > 0 && H % (2 * RB) == 0 && W > 0 && W % 28 == 0;
     if (dil != 1) return 0;
-    if (cin != 32 && cin != 64 && cin != 128) return 0;
-    if (cout != 32 && cout != 64 && cout != 128) return 0;
-    if (H <= 0 || H % RB || W <= 0 || W % 28) return 0;
-    if (cin == 32 && W % 56) return 0;
+    if (cin != 32 && cin != 64 && cin != 128) return 0;            // (a wider layer runs as chained launches over 128-channel input slices: the
+    if (cout <= 0 || cout % 32 || cout > 512) return 0;            //  previous partial sum is the next launch's residual)
+    if (H <= 0 || W <= 0) return 0;
     return 1;
 }
 

@@ -983,6 +983,61 @@ def conv3d_cout1(x, w27, res, out):
     _lib.check(st, "drc_conv3d_cout1_fwd")
 
 
+TRUNK_S16 = {"enabled": True, "min_tiles": 96, "min_rows": 24}     # eval: the 3x3 layers of ResNet-FPN on large maps through BridgedConv2dS16
+
+
+class BridgedConv2dS16:
+    """A 3x3 stride-1 pad-1 convolution (+BN / bias, +ReLU) between BLOCKED fp32 tensors on the split-f16 kernel (convs16r.hip, any map
+    size): the input is converted to RS16 in slices of <= 128 channels, one launch per slice -- a launch adds the previous partial sum as its
+    residual; the folded BN scale goes to every launch, the shift to the first, the ReLU to the last (BN is affine) -- and the result is
+    converted back.  Reference layers: Bottleneck.conv2 (backbone/resnet.py:274-316), the FPN output blocks (backbone/fpn.py:44-77).
+    `cache`: a dict the RS16 maps of equal shape are shared through (layers run one after the other)."""
+
+    @staticmethod
+    def slices(cin):
+        if cin in (32, 64, 128):
+            return ((0, cin),)
+        if cin in (256, 384, 512):
+            return tuple((a, a + 128) for a in range(0, cin, 128))
+        return None
+
+    @staticmethod
+    def worth(N, cin, cout, H, W):
+        """Large maps only: a column of the kernel is 28 rows x 28 columns x 32 couts, and the converters at both ends are extra launches."""
+        if not TRUNK_S16["enabled"] or BridgedConv2dS16.slices(cin) is None or cout % 32 or cout > 512 or not S16["enabled"]:
+            return False
+        tiles = N * -(-H // 28) * -(-W // 28) * (cout // 32)
+        return H >= TRUNK_S16["min_rows"] and tiles >= TRUNK_S16["min_tiles"]
+
+    def __init__(self, N, cin, cout, H, W, relu, device, cache):
+        self.bounds = self.slices(cin)
+        if self.bounds is None or not s16_supported(self.bounds[0][1] - self.bounds[0][0], cout, 1, H, W, "2d"):
+            raise ValueError("BridgedConv2dS16: unsupported shape")
+        self.N, self.cin, self.cout, self.H, self.W, self.device = N, cin, cout, H, W, device
+
+        def shared(tag, ch):
+            k = (tag, N, ch, H, W)
+            if k not in cache:
+                cache[k] = RS16(N, ch, 1, H, W, 0, device)
+            return cache[k]
+        self.x16 = [shared(("x", i), b - a) for i, (a, b) in enumerate(self.bounds)]
+        self.y16 = [shared(("y", i), cout) for i in range(min(2, len(self.bounds)))]
+        last = len(self.bounds) - 1
+        self.plans = [ConvPlanS16(N, b - a, cout, 1, H, W, bool(relu) and i == last, device=device, kind="2d") for i, (a, b) in enumerate(self.bounds)]
+
+    def run(self, x, packs, shift, zero_shift, y):
+        """x, y: Blocked fp32 (x: halo >= 0 of any width); packs: [(packed split-f16 weights of the slice, its epilogue scale)]."""
+        if (x.C, x.H, x.W, y.C, y.H, y.W) != (self.cin, self.H, self.W, self.cout, self.H, self.W) or x.N < self.N or y.N < self.N:
+            raise ValueError("BridgedConv2dS16.run: tensors differ from the plan")
+        prev = None
+        for i, ((a, b), pl, (w16, sc16)) in enumerate(zip(self.bounds, self.plans, packs)):
+            self.x16[i].from_blocked(x if len(self.bounds) == 1 else BlockedSlice(x, a // CB, b - a))
+            out = self.y16[i & 1]
+            pl.run(self.x16[i], w16, sc16, shift if i == 0 else zero_shift, y16=out, res=prev)
+            prev = out
+        prev.to_blocked(y)
+
+
 def head_gather(S, scale, res, out):
     """The second half of a fused cout-1 head (ConvPlanS16.run(head=...)): out dense [N,D,H,W] = (res or 0) + scale * the nine shifted
     in-plane partial sums of S (fp32 [N][D][H][W][12])."""

@@ -29,7 +29,7 @@ class _Site:
             w = weight_fn(w)
         self.w = E.pack_conv_weight(w)
         self.w16 = E.pack_weight_t16(w) if tuple(w.shape[2:]) == (3, 3) else None      # 3x3 layers: LDS-free kernel's packing
-        self._weight, self._ww = w, None
+        self._weight, self._ww, self._s16 = w, None, None
         cp = E.cout_pad_of(w.shape[0])
         if bn is not None:
             self.scale, self.shift = E.fold_bn(bn.weight.detach().to(device).float(), bn.bias.detach().to(device).float(),
@@ -40,6 +40,16 @@ class _Site:
             self.shift = torch.zeros(cp, device=device)
             if conv.bias is not None:
                 self.shift[: conv.bias.numel()] = conv.bias.detach().to(device).float()
+
+
+def _s16_slices(site, bounds):
+    """[(split-f16 packing of the input channels [a, b), epilogue scale = folded BN scale * 2^-wexp)] of a 3x3 site (engine.BridgedConv2dS16)."""
+    from ... import s16 as S
+    key = tuple(bounds)
+    if site._s16 is None or site._s16[0] != key:
+        packs = [S.pack_weight_s16(site._weight[:, a:b].contiguous()) for a, b in bounds]
+        site._s16 = (key, [(wp, (site.scale * (2.0 ** -wexp)).contiguous()) for wp, wexp in packs], torch.zeros_like(site.shift))
+    return site._s16[1], site._s16[2]
 
 
 def _w16_for(site, plan):
@@ -89,6 +99,12 @@ class BackboneRuntime:
         dev, body = self.device, self.model.body
         B2 = lambda c, h, w, pad: E.Blocked(N, c, 1, h, w, 0, pad, pad, dev)
         t, p, sched = {}, {}, []
+        s16b, s16cache = {}, {}
+
+        def bridge(name, cin, cout, h, w, relu):
+            # the 3x3 layers on large maps run on the split-f16 kernel (fp32-class results on the f16 matrix cores) between the same tensors
+            if E.BridgedConv2dS16.worth(N, cin, cout, h, w):
+                s16b[name] = E.BridgedConv2dS16(N, cin, cout, h, w, relu, dev, s16cache)
         h1, w1 = _half(H), _half(W_)                                    # 7x7 s2 p3
         t["img"] = B2(12, h1, w1, 2)                                    # 2x2 pixel-unshuffled image (see _stem_s2d_weight)
         t["stem"] = B2(64, h1, w1, 0)
@@ -119,6 +135,7 @@ class BackboneRuntime:
                     sched.append((q + ".ds", cur, q + ".s", None))
                     res = q + ".s"
                 sched += [(q + ".c1", cur, q + ".a", None), (q + ".c2", q + ".a", q + ".b", None), (q + ".c3", q + ".b", q + ".o", res)]
+                bridge(q + ".c2", mid, mid, ohw[0], ohw[1], True)
                 cur, ch, hw = q + ".o", cout, ohw
             stage_out.append((cur, ch, hw))
         # FPN (top-down)
@@ -139,11 +156,12 @@ class BackboneRuntime:
             fsched.append(("resize", last, f"td{i}", lhw, fhw))
             fsched.append(("conv", f"inner{i}", feat, f"sum{i}", f"td{i}"))      # inner_lateral + inner_top_down
             fsched.append(("conv", f"layer{i}", f"sum{i}", f"out{i}", None))
+            bridge(f"layer{i}", 256, 256, fhw[0], fhw[1], False)
             outs[i - 1] = f"out{i}"
             last, lhw = f"out{i}", fhw                                  # reference: last_inner = layer_block(lateral + top_down)
         t["p6"] = B2(256, _half(thw[0]), _half(thw[1]), 1)
         outs[4] = "p6"
-        ws = dict(t=t, p=p, sched=sched, fsched=fsched, outs=outs, pool=(h1, w1, ph, pw), thw=thw,
+        ws = dict(t=t, p=p, sched=sched, fsched=fsched, outs=outs, pool=(h1, w1, ph, pw), thw=thw, s16=s16b,
                   flops=sum(pl.flops for pl in p.values()))
         self._ws[key] = ws
         return ws
@@ -160,7 +178,12 @@ class BackboneRuntime:
 
         def conv(plan, x_, y_, res=None):
             c = Wt[plan]
-            p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None, w16=_w16_for(c, p[plan]))
+            br = ws["s16"].get(plan)
+            if br is not None and res is None:
+                packs, zero = _s16_slices(c, br.bounds)
+                br.run(t[x_], packs, c.shift, zero, t[y_])
+            else:
+                p[plan].run(t[x_], c.w, c.scale, c.shift, t[y_], t[res] if res else None, w16=_w16_for(c, p[plan]))
 
         if (H | W_) & 1:
             x = torch.nn.functional.pad(x, (0, W_ & 1, 0, H & 1))

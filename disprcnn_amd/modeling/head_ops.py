@@ -124,8 +124,36 @@ class BlockedConv2d:
         f = lambda n: (n + 2 * self.pad - self.dil * (self.k - 1) - 1) // self.stride + 1
         return f(h), f(w)
 
+    def _bridge(self, xb, yb):
+        """Large maps of a 3x3 stride-1 layer (the RPN head's 256 -> 512 convolution on P2..P4: 137 GFLOP of the 2D stage's heads) run on the
+        split-f16 kernel between the same blocked tensors (engine.BridgedConv2dS16); None where that does not apply."""
+        if (self.k, self.stride, self.pad, self.dil) != (3, 1, 1, 1) or type(xb) is not E.Blocked or type(yb) is not E.Blocked:
+            return None
+        if xb.n_stride != xb.cb * xb.cb_stride or yb.n_stride != yb.cb * yb.cb_stride or (yb.H, yb.W, xb.D, yb.D) != (xb.H, xb.W, 1, 1) or xb.N != yb.N:
+            return None
+        if not E.BridgedConv2dS16.worth(xb.N, xb.C, self.cout, xb.H, xb.W):
+            return None
+        if not hasattr(self, "_s16"):
+            self._s16 = dict(cache={}, bridges=OrderedDict(), packs=None)
+        key = (xb.N, xb.C, xb.H, xb.W)
+        br = self._s16["bridges"].get(key)
+        if br is None:
+            br = self._s16["bridges"][key] = E.BridgedConv2dS16(xb.N, xb.C, self.cout, xb.H, xb.W, self.relu, xb.device, self._s16["cache"])
+            while len(self._s16["bridges"]) > self.MAX_PLANS:
+                self._s16["bridges"].popitem(last=False)
+        return br
+
     def __call__(self, xb, yb):
         wp, sc, sh = self._weights(xb.device)
+        br = self._bridge(xb, yb)
+        if br is not None:
+            from .. import s16 as S
+            pk = self._s16["packs"]
+            if pk is None or pk[0] is not self._w32 or pk[1] != br.bounds:
+                packs = [S.pack_weight_s16(self._w32[:, a:b].contiguous()) for a, b in br.bounds]
+                pk = self._s16["packs"] = (self._w32, br.bounds, [(w16, (sc * (2.0 ** -wexp)).contiguous()) for w16, wexp in packs], torch.zeros_like(sh))
+            br.run(xb, pk[2], sh, pk[3], yb)
+            return yb
         key = (xb.N, xb.C, xb.H, xb.W, xb.ph, xb.pw, xb.n_stride, yb.H, yb.W, yb.ph, yb.pw, yb.n_stride)
         plan = self._plans.get(key)
         if plan is None:

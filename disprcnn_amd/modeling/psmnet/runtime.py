@@ -851,6 +851,7 @@ class PSMNetRuntime:
         if mode not in ("auto", "f32", "f16x2"):
             raise ValueError("PSMNet.feature_math must be 'auto', 'f32' or 'f16x2'")
         ok = (not training and self._tape is None and H % 4 == 0 and W % 4 == 0 and H // 4 >= 56 and W // 4 >= 56 and
+              (H // 4) % 28 == 0 and (W // 4) % 56 == 0 and           # (the kernel takes ragged maps too -- the trunk's; this CNN keeps whole tiles)
               E.s16_supported(32, 32, 1, H // 2, W // 2, "2d") and E.s16_supported(64, 64, 1, H // 4, W // 4, "2d") and
               E.s16_supported(64, 128, 1, H // 4, W // 4, "2d") and E.s16_supported(128, 128, 1, H // 4, W // 4, "2d"))
         if mode == "f16x2" and not ok:

@@ -292,6 +292,9 @@ def test_hourglass_layers_s16_experiment_forms(dev, kind, N, cin, cout, D, H, W,
     (2, 64, 128, 28, 28, True, False, 1), (40, 64, 128, 28, 56, True, False, 0),        # layer3's first conv (four cout tiles side by side)
     (9, 128, 128, 28, 28, False, True, 0), (2, 128, 128, 56, 56, True, False, 0),       # layer3: two K slices per wave
     (33, 64, 64, 28, 28, True, True, 1), (40, 32, 32, 28, 56, True, True, 0),           # more images than one pass of the persistent grid's XCD groups
+    # any map size (the trunk's / FPN's maps): ragged last x group and row block, maps smaller than one tile, cout up to 512
+    (2, 64, 64, 30, 40, True, True, 0), (3, 32, 32, 10, 60, False, True, 0), (2, 64, 64, 5, 7, True, False, 0), (1, 128, 128, 94, 100, True, True, 0),
+    (2, 128, 256, 47, 155, True, False, 0), (2, 64, 64, 30, 61, False, True, 2), (1, 128, 512, 24, 78, True, True, 0), (9, 32, 32, 29, 57, True, False, 0),
 ])
 def test_conv2d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, H, W, relu, with_res, form):
     """convs16r.hip (the 2D member: 3x3 stride-1 conv + BN (+ residual, + ReLU), reference submodule.py:9-16) against fp64 next to the fp32
@@ -333,15 +336,51 @@ def test_conv2d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, H, W, relu
     assert not v.any()                                   # the halo stays zero
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W,relu,ph", [(2, 256, 64, 30, 61, True, 1), (1, 512, 96, 24, 78, False, 1), (2, 64, 64, 47, 155, True, 1),
+                                                     (2, 128, 256, 33, 40, True, 0)])
+def test_bridged_conv2d_s16_between_blocked_tensors(dev, N, cin, cout, H, W, relu, ph):
+    """engine.BridgedConv2dS16: a 3x3 layer of the trunk / FPN / RPN head between BLOCKED fp32 tensors through the split-f16 kernel -- input
+    converted per 128-channel slice, chained launches (partial sum as the next residual), output converted back -- against fp64."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+
+    def chain(dt):
+        y = F.conv2d(x.to(dt), w.to(dt), padding=1) * scale.to(dt).view(1, -1, 1, 1) + shift.to(dt).view(1, -1, 1, 1)
+        return y.clamp_min(0) if relu else y
+    ref = chain(torch.float64)
+    e32 = (chain(torch.float32).double() - ref).abs().max().item()
+    xb = E.Blocked(N, cin, 1, H, W, 0, ph, ph, dev).from_dense(x.to(dev))
+    yb = E.Blocked(N, cout, 1, H, W, 0, 1, 1, dev)
+    br = E.BridgedConv2dS16(N, cin, cout, H, W, relu, dev, {})
+    packs = []
+    for a, b in br.bounds:
+        wp, wexp = s16.pack_weight_s16(w[:, a:b].contiguous().to(dev))
+        packs.append((wp, (scale * 2.0 ** -wexp).to(dev).contiguous()))
+    br.run(xb, packs, shift.to(dev), torch.zeros(cout, device=dev), yb)
+    got = yb.to_dense().cpu()[:, :, 0]
+    m = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"bridged {cin}->{cout} {H}x{W}: max|err| {err:.3e} (fp32 chain {e32:.3e}), max|ref| {m:.3f}")
+    assert err <= 2e-5 * m + 1e-5
+    assert err <= 2.5 * e32 + 1e-6 * m, (err, e32)
+    v = yb.view6().clone()
+    v[:, :, :, 1:H + 1, 1:W + 1] = 0
+    assert not v.any()                                   # the blocked output's halo stays zero
+
+
 def test_conv2d_s16_validation(dev):
     lib = _lib_handle()
     assert lib.drc_conv2d_k3_s16_supported(64, 64, 56, 56, 1) == 1 and lib.drc_conv2d_k3_s16_supported(32, 32, 112, 112, 1) == 1
-    assert lib.drc_conv2d_k3_s16_supported(32, 32, 28, 28, 1) == 0          # 32 input channels: two tiles per workgroup, W % 56
-    assert lib.drc_conv2d_k3_s16_supported(64, 64, 30, 56, 1) == 0 and lib.drc_conv2d_k3_s16_supported(48, 64, 28, 28, 1) == 0
+    assert lib.drc_conv2d_k3_s16_supported(32, 32, 28, 28, 1) == 1 and lib.drc_conv2d_k3_s16_supported(64, 64, 30, 57, 1) == 1        # any map size (ragged tiles)
+    assert lib.drc_conv2d_k3_s16_supported(128, 512, 12, 39, 1) == 1 and lib.drc_conv2d_k3_s16_supported(128, 544, 12, 39, 1) == 0
+    assert lib.drc_conv2d_k3_s16_supported(48, 64, 28, 28, 1) == 0 and lib.drc_conv2d_k3_s16_supported(256, 64, 28, 28, 1) == 0       # cin: 32, 64, 128 (wider: chained launches)
     assert lib.drc_conv2d_k3_s16_supported(128, 128, 56, 56, 2) == 1 and lib.drc_conv2d_k3_s16_supported(128, 128, 28, 56, 2) == 0      # dilation 2: 56-row blocks
     assert lib.drc_conv2d_k3_s16_supported(64, 64, 56, 56, 2) == 0 and lib.drc_conv2d_k3_s16_supported(128, 128, 56, 56, 3) == 0
     with pytest.raises(ValueError):
-        E.ConvPlanS16(2, 64, 64, 1, 30, 56, True, device=dev, kind="2d")
+        E.ConvPlanS16(2, 48, 64, 1, 28, 56, True, device=dev, kind="2d")
     plan = E.ConvPlanS16(2, 64, 64, 1, 28, 28, True, device=dev, kind="2d")
     w = torch.zeros(2, 4, 9, 2, 64, 8, dtype=torch.float16, device=dev)
     sc = torch.ones(64, device=dev)
