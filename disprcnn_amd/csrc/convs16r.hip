@@ -117,14 +117,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
 
     struct Col { unsigned n; int row0, x0; bool valid; };      // row0: first output row (logical)
     auto col_of = [&](unsigned it) __attribute__((always_inline)) {
-        const unsigned j = it * per_xcd + qx;
+        // many units (ROI crops): XCD q walks the units n % 8 == q, so that the row blocks and x groups of a unit (shared halo rows / columns)
+        // meet in one L2.  Few units (the two images of a stereo pair in the trunk: only two of eight XCDs would get work): the columns
+        // are dealt to all workers in turn
+        const bool flat = (unsigned)p.N < 16u;
+        const unsigned j = flat ? (it * per_xcd + qx) * 8 + xcd : it * per_xcd + qx;
         const unsigned nl = j / cols_unit;
         const unsigned rem = j - nl * cols_unit;
         Col c;
         const int rb = (int)(rem / n_xg);                      // DIL = 2: (56-row block, parity)
         c.row0 = (rb / DIL) * RB * DIL + rb % DIL;
         c.x0 = (int)(rem - (unsigned)rb * n_xg) * 28 * TPW;
-        c.n = nl * 8 + xcd;
+        c.n = flat ? nl : nl * 8 + xcd;
         c.valid = c.n < (unsigned)p.N;
         return c;
     };

@@ -983,7 +983,10 @@ def conv3d_cout1(x, w27, res, out):
     _lib.check(st, "drc_conv3d_cout1_fwd")
 
 
-TRUNK_S16 = {"enabled": True, "min_tiles": 96, "min_rows": 24}     # eval: the 3x3 layers of ResNet-FPN on large maps through BridgedConv2dS16
+# eval: the 3x3 layers of ResNet-FPN / the RPN head on large maps through BridgedConv2dS16.  OFF by default: measured on the KITTI pair
+# (tools/experiments/exp_trunk_s16.py, profiles/r5_exp_trunk_s16.log) the converters at both ends and the chained launches cost more than the
+# fp32 Winograd kernels they replace
+TRUNK_S16 = {"enabled": False, "min_tiles": 96, "min_rows": 24}
 
 
 class BridgedConv2dS16:
