@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
     const int n_xg = (W + 28 * TPW - 1) / (28 * TPW), n_rb = (H + RB - 1) / RB;
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_rb * n_xg;
+    if (per_xcd == 0) return;                              // (a grid that is not 8 x workers x cout tiles: nothing to walk -- never an endless loop)
 
     struct Col { unsigned n; int row0, x0; bool valid; };      // row0: first output row (logical)
     auto col_of = [&](unsigned it) __attribute__((always_inline)) {
@@ -379,9 +380,13 @@ int launch2(const drc_s16conv_params& p, hipStream_t stream) {
     }
     const long columns = DIL == 1 ? (long)p.N * ((p.H + RB - 1) / RB) * ((p.W + 28 * TPW - 1) / (28 * TPW)) : (long)p.N * (p.H / RB) * (p.W / (28 * TPW));
     const int n_ct = p.cout / 32;
-    // persistent grid: two workgroups per CU where the registers allow (KS == 1: one hides the other's barriers and waits), else one
-    long blocks = (KS == 1 && !(p.lo4 & 4)) ? 512 : 256;
-    while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
+    // persistent grid: two workgroups per CU where the registers allow (KS == 1: one hides the other's barriers and waits), else one;
+    // 8 XCDs x wpx column workers x n_ct cout tiles (the kernel derives wpx = gridDim / 8 / n_ct: it must divide), halved while there are
+    // twice as many workers as columns
+    long wpx = ((KS == 1 && !(p.lo4 & 4)) ? 512 : 256) / (8 * n_ct);
+    if (wpx < 1) wpx = 1;
+    while (wpx > 1 && 4 * wpx >= columns) wpx /= 2;
+    const long blocks = 8 * n_ct * wpx;
     hipLaunchKernelGGL((convs16r_kernel<KW, KS, RES, DIL>), dim3((unsigned)blocks), dim3(256), lds, stream, p);
     return (int)hipGetLastError();
 }
@@ -397,7 +402,7 @@ extern "C" int drc_conv2d_k3_s16_supported(int cin, int cout, int H, int W, int 
     if (dil == 2) return cin == 128 && (cout == 32 || cout == 64 || cout == 128) && H > 0 && H % (2 * RB) == 0 && W > 0 && W % 28 == 0;
     if (dil != 1) return 0;
     if (cin != 32 && cin != 64 && cin != 128) return 0;            // (a wider layer runs as chained launches over 128-channel input slices: the
-    if (cout <= 0 || cout % 32 || cout > 512) return 0;            //  previous partial sum is the next launch's residual)
+    if (cout != 32 && cout != 64 && cout != 128 && cout != 256 && cout != 512) return 0;      //  previous partial sum is the next launch's residual)
     if (H <= 0 || W <= 0) return 0;
     return 1;
 }

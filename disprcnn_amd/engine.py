@@ -983,10 +983,11 @@ def conv3d_cout1(x, w27, res, out):
     _lib.check(st, "drc_conv3d_cout1_fwd")
 
 
-# eval: the 3x3 layers of ResNet-FPN / the RPN head on large maps through BridgedConv2dS16.  OFF by default: measured on the KITTI pair
-# (tools/experiments/exp_trunk_s16.py, profiles/r5_exp_trunk_s16.log) the converters at both ends and the chained launches cost more than the
-# fp32 Winograd kernels they replace
-TRUNK_S16 = {"enabled": False, "min_tiles": 96, "min_rows": 24}
+# eval: the 3x3 layers of ResNet-FPN / the RPN head on LARGE maps through BridgedConv2dS16.  Measured on the KITTI pair
+# (tools/experiments/exp_trunk_s16.py, profiles/r5_exp_trunk_s16_flat.log): with min_tiles 192 -- layer1's 3x3 layers, the FPN blocks of P2 / P3,
+# the RPN head's convolution on P2 / P3 -- trunk 3.07 -> 2.78 ms, 2D stage 7.08 -> 6.76 ms; lower thresholds lose (the converters at both ends
+# and the chained launches cost more than the fp32 Winograd kernels they replace on smaller maps)
+TRUNK_S16 = {"enabled": True, "min_tiles": 192, "min_rows": 24}
 
 
 class BridgedConv2dS16:
@@ -1007,7 +1008,7 @@ class BridgedConv2dS16:
     @staticmethod
     def worth(N, cin, cout, H, W):
         """Large maps only: a column of the kernel is 28 rows x 28 columns x 32 couts, and the converters at both ends are extra launches."""
-        if not TRUNK_S16["enabled"] or BridgedConv2dS16.slices(cin) is None or cout % 32 or cout > 512 or not S16["enabled"]:
+        if not TRUNK_S16["enabled"] or BridgedConv2dS16.slices(cin) is None or cout not in (32, 64, 128, 256, 512) or not S16["enabled"]:
             return False
         tiles = N * -(-H // 28) * -(-W // 28) * (cout // 32)
         return H >= TRUNK_S16["min_rows"] and tiles >= TRUNK_S16["min_tiles"]

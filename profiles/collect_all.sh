@@ -15,16 +15,21 @@ export PROF_COMMIT=$(cat profiles/.head 2>/dev/null || echo unknown)
 PMC_SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 PMC_LDS="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SALU SQ_INSTS_LDS"
 PMC_CACHE="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"
+LIGHT=${LIGHT:-}     # workloads that get the kernel-trace pass only (no counters): a partial re-collection under a tight GPU budget
+NOFULL=${NOFULL:-}   # workloads whose LDS / cache passes are skipped
 run() {   # name, suffix of the summary files, description, full (1: also LDS + cache passes), command...
   if [ -n "$ONLY" ] && [[ " $ONLY " != *" $1 "* ]]; then return; fi
   local name=$1 sfx=$2 desc=$3 full=$4; shift 4
+  if [[ " $NOFULL " == *" $name "* ]]; then full=0; fi
   local OUT=/tmp/prof_${TAG}_$name
   rm -rf "$OUT"; mkdir -p "$OUT"
   local t0=$SECONDS
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- "$@" > "$OUT/trace.log" 2>&1
+  if [[ " $LIGHT " != *" $name "* ]]; then
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT" -o fetch -- "$@" > "$OUT/fetch.log" 2>&1
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT" -o write -- "$@" > "$OUT/write.log" 2>&1
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $PMC_SQ -d "$OUT" -o sq -- "$@" > "$OUT/sq.log" 2>&1
+  fi
   if [ "$full" = 1 ]; then
     timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $PMC_LDS -d "$OUT" -o lds -- "$@" > "$OUT/lds.log" 2>&1
     timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $PMC_CACHE -d "$OUT" -o cache -- "$@" > "$OUT/cache.log" 2>&1
