@@ -254,6 +254,30 @@ def test_fused_cout1_head_vs_fp64(dev, N, D, H, W, with_prev):
     assert err <= 2.0 * e32 + 1e-6 * m, (err, e32)
 
 
+@pytest.mark.parametrize("N,D,H,W", [(2, 3, 5, 7), (1, 2, 30, 57), (3, 2, 28, 28), (1, 1, 3, 400), (2, 1, 56, 56)])
+def test_head_gather_vs_torch(dev, N, D, H, W):
+    """drc_head_gather_fwd alone: cost = res + scale * sum_{kh,kw} S[.., y+kh-1, x+kw-1][slot(kh*3+kw)], zero outside the map (slot j for j < 5,
+    j + 3 above); LDS-staged bands, whole planes, and the one-thread-per-voxel form very wide maps fall back to (W = 400)."""
+    g = torch.Generator().manual_seed(N + D + H + W)
+    S = torch.randn(N, D, H, W, 12, generator=g)
+    res = torch.randn(N, D, H, W, generator=g)
+    ref = torch.zeros(N, D, H, W, dtype=torch.float64)
+    Sp = F.pad(S.double(), (0, 0, 1, 1, 1, 1))                      # zero border in x and y
+    for kh in range(3):
+        for kw in range(3):
+            j = kh * 3 + kw
+            ref += Sp[:, :, kh:kh + H, kw:kw + W, j if j < 5 else j + 3]
+    ref = ref * 0.375 + res.double()
+    S_dev = S.to(dev)
+    S_dev[..., 5:8] = float("nan")                                  # the slots' padding floats are never read
+    out = torch.empty(N, D, H, W, device=dev)
+    E.head_gather(S_dev, 0.375, res.to(dev), out)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    out2 = torch.empty(N, D, H, W, device=dev)
+    E.head_gather(S_dev, 0.375, None, out2)
+    assert (out2.cpu().double() - (ref - res.double())).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
 def test_fused_head_validation(dev):
     x = E.RS16(2, 32, 12, 28, 28, 1, dev)
     w0 = torch.randn(32, 32, 3, 3, 3, device=dev)
