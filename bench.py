@@ -225,7 +225,7 @@ def main():
         # HBM bytes per launch of the same kernel from the committed PMC pass of this command (profiles/collect.sh):
         # FETCH_SIZE (x2: gfx950 128-B request correction) + WRITE_SIZE; null if that profile is absent
         traffic, traffic_src = None, "no committed PMC pass"
-        for prof in ("r5b_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for prof in ("r5c_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 key = [k for k in tj if k.replace(" ", "") == dom.replace(" ", "")]
