@@ -369,6 +369,51 @@ def test_packed_weight_cache_is_tied_to_the_live_parameter():
     assert k not in H._PACKED_W
 
 
+def test_fused_head_weight_packing_puts_the_depth_taps_of_a_tap_in_one_lane():
+    """s16.pack_head_weight_s16 (the 32 -> 1 layer as the MFMA A operand of the fused head, convs16.hip HEAD form): emulating the MFMA's
+    row / k-group layout, product row m of a voxel is tap head_rows()[m] applied to the voxel's 32 channels; every tap appears once; lane
+    half g' holds (kd, j) in register 3 (j - 5 g') + kd."""
+    from disprcnn_amd import s16
+    rows = s16.head_rows()
+    taps = [r for r in rows if r is not None]
+    assert len(taps) == 27 and len(set(taps)) == 27
+    for g in range(2):
+        for r in range(16):
+            m = (r & 3) + 8 * (r >> 2) + 4 * g
+            jj, kd = divmod(r, 3)
+            assert rows[m] == ((kd, 5 * g + jj) if jj < (5 if g == 0 else 4) else None)
+    w1 = torch.randn(1, 32, 3, 3, 3, generator=torch.Generator().manual_seed(5))
+    hp, wexp = s16.pack_head_weight_s16(w1)
+    assert tuple(hp.shape) == (2, 2, 64, 8) and hp.dtype == torch.float16
+    a = torch.randn(32, generator=torch.Generator().manual_seed(6)).double()
+    A = (hp[:, 0].double() + hp[:, 1].double()) * 2.0 ** -wexp                     # [slice][lane][e]
+    P = torch.zeros(32, dtype=torch.float64)
+    for s_ in range(2):
+        for g in range(2):
+            for e in range(8):
+                c = 4 * g + 8 * (2 * s_ + (e >> 2)) + (e & 3)                      # the channel a finishing wave holds in (slice, g, e)
+                P += A[s_, 32 * g: 32 * g + 32, e] * a[c]
+    for m, r in enumerate(rows):
+        want = 0.0 if r is None else float((w1[0, :, r[0], r[1] // 3, r[1] % 3].double() * a).sum())
+        assert abs(float(P[m]) - want) < 1e-5 * max(1.0, abs(want))               # (hi + lo carries 22 bits of the scaled weight)
+
+
+def test_bridged_conv_slices_and_threshold():
+    """engine.BridgedConv2dS16: input-channel slices of the chained launches and the large-maps-only rule (TRUNK_S16)."""
+    from disprcnn_amd import engine as E
+    B = E.BridgedConv2dS16
+    assert B.slices(64) == ((0, 64),) and B.slices(256) == ((0, 128), (128, 256)) and B.slices(512)[-1] == (384, 512) and B.slices(96) is None
+    saved = dict(E.TRUNK_S16)
+    try:
+        E.TRUNK_S16.update(enabled=True, min_tiles=192, min_rows=24)
+        assert B.worth(2, 256, 256, 94, 310) and B.worth(2, 256, 512, 47, 155) and B.worth(2, 64, 64, 94, 310)       # FPN P2, RPN on P3, layer1
+        assert not B.worth(2, 256, 256, 24, 78) and not B.worth(2, 512, 512, 12, 39) and not B.worth(2, 256, 96, 94, 310)
+        E.TRUNK_S16["enabled"] = False
+        assert not B.worth(2, 256, 256, 94, 310)
+    finally:
+        E.TRUNK_S16.update(saved)
+
+
 def test_newest_profile_set_is_complete_and_from_one_commit():
     """VERDICT r3 #9-10: no empty PMC tables, every summary of a round's set from the same commit (profiles/collect_all.sh writes it)."""
     import importlib.util
@@ -378,3 +423,4 @@ def test_newest_profile_set_is_complete_and_from_one_commit():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check("r4") == []
+    assert mod.check("r5c") == []                # the final set of round 5 (seven workloads, one commit)
