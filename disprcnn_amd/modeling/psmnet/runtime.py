@@ -440,9 +440,10 @@ class PSMNetRuntime:
                 ("s1", 64, 64, quart), ("up", 64, 64, quart), ("up", 64, 32, half)]
 
     def _use_s16(self, training, Dp, Hp, Wp):
-        """Eval: every 3x3x3 layer of the regressor but the cout-1 heads runs in split-f16 arithmetic on the f16 matrix cores (convs16*.hip:
-        fp32-class results) when the volume's shape is one the kernels take; PSMNet.regressor_math = "f32" keeps the fp32 MFMA
-        kernels of rounds 1-4."""
+        """Eval: every 3x3x3 layer of the regressor runs in split-f16 arithmetic on the f16 matrix cores (convs16*.hip: fp32-class results,
+        DESIGN 3.7) when the volume's shape is one the kernels take -- the three cout-1 heads fused into the layer in front of them where the
+        map is a multiple of 28 columns (_ws3d_s16), else on cout1_mfma.hip; PSMNet.regressor_math = "f32" keeps the fp32 MFMA kernels of
+        rounds 1-4."""
         mode = getattr(self.model, "regressor_math", "auto")
         if mode not in ("auto", "f32", "f16x2"):
             raise ValueError("PSMNet.regressor_math must be 'auto', 'f32' or 'f16x2'")
@@ -844,9 +845,10 @@ class PSMNetRuntime:
 
     # ------------------------------------------------------------------ split-f16 2D feature CNN (eval; convs16r.hip)
     def _use_s16_2d(self, training, H, W):
-        """Eval: the stride-1 3x3 layers of feature_extraction but lastconv (firstconv[2], [4], layer1, layer2 but its first conv, layer3, and
-        -- maps of a multiple of 56 rows -- the dilated layer4: 89 % of the CNN's FLOPs) run in split-f16 arithmetic on the f16 matrix cores (convs16r.hip: fp32-class results) when the maps
-        are multiples of 28 rows / 56 columns; PSMNet.feature_math = "f32" keeps the fp32 MFMA kernels for all of them."""
+        """Eval: the stride-1 3x3 layers of feature_extraction (firstconv[2], [4], layer1, layer2 but its first conv, layer3, -- maps of a
+        multiple of 56 rows -- the dilated layer4, and lastconv[0] as three chained launches: 99 % of the CNN's FLOPs) run in split-f16
+        arithmetic on the f16 matrix cores (convs16r.hip: fp32-class results, DESIGN 3.7) when the maps are multiples of 28 rows / 56 columns;
+        PSMNet.feature_math = "f32" keeps the fp32 MFMA kernels for all of them."""
         mode = getattr(self.model, "feature_math", "auto")
         if mode not in ("auto", "f32", "f16x2"):
             raise ValueError("PSMNet.feature_math must be 'auto', 'f32' or 'f16x2'")
