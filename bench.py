@@ -254,7 +254,8 @@ def main():
                     "direct_conv_equivalent_flops_per_launch": flops / calls,
                     "note": (("achieved = the layer's algorithmic fp32 flops (SURVEY 8d: 2*27*Cin*Cout per voxel) / launch time; the kernel spends three "
                               "v_mfma_f32_32x32x16_f16 products per fp32 product (hi*hi + lo*hi + hi*lo, fp32 accumulate), so peak = 2500 TFLOP/s dense f16 "
-                              "MFMA / 3; 12.5 % of the issued MFMA columns (lanes 28..31 of a 28-voxel row) are idle on top") if s16_dom else
+                              "MFMA / 3; 12.5 % of the issued MFMA columns (lanes 28..31 of a 28-voxel row) are idle on top.  A '...,true>' instantiation is the "
+                              "32->32 layer with the 32->1 head fused behind it: its flops are those of both layers") if s16_dom else
                              ("achieved/frac = executed MFMA flops (Winograd: 64/216 of the direct convolution's) vs the fp32 MFMA peak; "
                               "direct_conv_equivalent_* = SURVEY 8d's algorithmic conv flops / time, not a roofline fraction"))}
         if s16_dom:

@@ -1580,4 +1580,5 @@ class ConvPlanS16:
                 kn = self._kfmt % ("true" if res is not None else "false")
             else:
                 kn = self.kname
-            TIMING.append((kn, self.flops, e0, e1))
+            # (a fused-head launch also computes the 32 -> 1 layer behind it: 2 * 27 * 32 flops per voxel on top of the layer's own)
+            TIMING.append((kn, self.flops + (2 * 27 * 32 * self.N * self.D * self.H * self.W if head is not None else 0), e0, e1))
