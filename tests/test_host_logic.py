@@ -398,6 +398,24 @@ def test_fused_head_weight_packing_puts_the_depth_taps_of_a_tap_in_one_lane():
         assert abs(float(P[m]) - want) < 1e-5 * max(1.0, abs(want))               # (hi + lo carries 22 bits of the scaled weight)
 
 
+def test_split_f16_shape_rules_through_the_c_abi():
+    """The *_supported entry points of the split-f16 kernels are host code: their shape rules hold without a GPU (the launch entries repeat
+    them and return -4)."""
+    from disprcnn_amd import _lib
+    lib = _lib.lib()
+    s1, s2, up, c2 = lib.drc_conv3d_k3_s16_supported, lib.drc_conv3d_k3s2_s16_supported, lib.drc_deconv3d_k3s2_s16_supported, lib.drc_conv2d_k3_s16_supported
+    # 3D stride 1: cin / cout in {32, 64}, D % 3 == 0, W = 7 | 14 | multiple of 28 (cin 32: even H)
+    assert s1(32, 32, 12, 28, 28) and s1(64, 32, 24, 56, 56) and s1(64, 64, 6, 14, 14) and s1(64, 64, 3, 7, 7) and s1(32, 64, 6, 5, 7)
+    assert not s1(32, 32, 10, 28, 28) and not s1(32, 32, 12, 27, 28) and not s1(48, 32, 12, 28, 28) and not s1(32, 32, 12, 28, 30)
+    # stride 2 / transposed: the narrower map 7, 14 or a multiple of 28 wide; even input dims for stride 2; cin 64 for the transposed layer
+    assert s2(32, 64, 12, 28, 28) and s2(64, 64, 6, 14, 14) and s2(32, 64, 24, 56, 56) and not s2(32, 64, 12, 28, 30) and not s2(32, 64, 11, 28, 28)
+    assert up(64, 32, 6, 14, 14) and up(64, 64, 3, 7, 7) and up(64, 32, 12, 28, 28) and not up(32, 32, 6, 14, 14) and not up(64, 32, 6, 14, 15)
+    # 2D: any map size at dilation 1, cin in {32, 64, 128} (wider layers: chained launches), cout a power of two in 32..512; dilation 2: cin 128, 56-row blocks
+    assert c2(64, 64, 56, 56, 1) and c2(32, 32, 29, 57, 1) and c2(128, 512, 12, 39, 1) and c2(128, 256, 94, 310, 1)
+    assert not c2(256, 64, 28, 28, 1) and not c2(128, 96, 28, 28, 1) and not c2(128, 1024, 28, 28, 1) and not c2(64, 64, 0, 28, 1)
+    assert c2(128, 128, 56, 56, 2) and not c2(128, 128, 28, 56, 2) and not c2(64, 64, 56, 56, 2) and not c2(128, 128, 56, 56, 3)
+
+
 def test_bridged_conv_slices_and_threshold():
     """engine.BridgedConv2dS16: input-channel slices of the chained launches and the large-maps-only rule (TRUNK_S16)."""
     from disprcnn_amd import engine as E
