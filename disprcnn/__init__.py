@@ -36,11 +36,27 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return importlib.util.spec_from_loader(fullname, self, is_package=True)
 
     def create_module(self, spec):
-        return importlib.import_module(_TARGET + spec.name[len(_PREFIX):])      # the implementation's own module object
+        # the implementation's own module object.  importlib's module_from_spec stamps the alias spec (and, for `is_package`, an empty
+        # __path__) onto whatever create_module returns: what the real module had is put back in exec_module, so that its relative imports
+        # (`from .. import _lib`) keep resolving through ITS package
+        real = importlib.import_module(_TARGET + spec.name[len(_PREFIX):])
+        _SAVED[spec.name] = (real, real.__spec__, getattr(real, "__package__", None), hasattr(real, "__path__"))
+        return real
 
     def exec_module(self, module):
-        pass
+        alias = getattr(module, "__spec__", None)
+        saved = _SAVED.pop(getattr(alias, "name", None), None)
+        if saved is None or saved[0] is not module:
+            return
+        _, spec, package, had_path = saved
+        module.__spec__ = spec
+        if package is not None:
+            module.__package__ = package
+        if not had_path and hasattr(module, "__path__"):
+            del module.__path__
 
+
+_SAVED = {}
 
 if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
     sys.meta_path.insert(0, _AliasFinder())

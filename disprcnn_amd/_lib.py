@@ -50,7 +50,7 @@ class DrcS16ConvParams(C.Structure):
                 ("y16", C.c_void_p), ("y32", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
                 ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("lo4", C.c_int32), ("dil", C.c_int32),
-                ("head", C.c_void_p), ("w1", C.c_void_p)]
+                ("head", C.c_void_p), ("w1", C.c_void_p), ("ovf", C.c_void_p)]
 
 
 class DrcFpnPyramid(C.Structure):
@@ -151,14 +151,14 @@ _SIGS = {
     "drc_conv3d_k3s2_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
     "drc_deconv3d_k3s2_s16_supported": (_I, [_I, _I, _I, _I, _I]),
     "drc_deconv3d_k3s2_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
-    "drc_rs16_from_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "drc_rs16_from_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "drc_rs16_from_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "drc_rs16_from_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "drc_rs16_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "drc_rs16_to_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_head_gather_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_float, _P]),
     "drc_conv2d_k3_s16_supported": (_I, [_I, _I, _I, _I, _I]),
     "drc_conv2d_k3_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
-    "drc_deconv3d_k3s2_direct_s16_fwd": (_I, [C.POINTER(DrcTapconvParams), _P, _P]),
+    "drc_deconv3d_k3s2_direct_s16_fwd": (_I, [C.POINTER(DrcTapconvParams), _P, _P, _P]),
     "drc_nms_sorted_fwd": (_I, [_P, _I, C.c_float, _I, _P, _P, _P]),
     "drc_nms_sorted_batch_fwd": (_I, [_P, _I, _I, C.c_float, _I, _P, _P, _P]),
     "drc_nms_sorted_pair_joint_fwd": (_I, [_P, _I, C.c_float, _I, _I, _P, _P, _P]),

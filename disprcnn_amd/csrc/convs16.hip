@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_ovf.h"
 #include "s16_tilemap.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     Col ccur = col_of(0);
     if (!ccur.valid) return;
+    S16Ovf og;                                              // range guard (s16_ovf.h): the largest |value| this lane finalized before the clamp
     Src s_cur = src_of(ccur), s_next = s_cur;
     Ctx cx_cur = ctx_of(ccur), cx_prev = cx_cur;
     cx_prev.ok = false;
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         float v[OWN];
         _Float16 vh[OWN], vl[OWN];
+        const unsigned long long og_keep = S16Ovf::lanes(f_ok);       // idle lanes / dropped planes hold over-read data: not a value of the map
         auto fin = [&](int e) __attribute__((always_inline)) {
             float s_;
             if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const _Float16 rh = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][0])[e], rl_ = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][1])[e];
                 x_ += (float)rh + (float)rl_;
             }
+            og.see(x_, og_keep);
             x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);    // ReLU (relu_lo = 0) or the fp16 range of the hi part (relu_lo = -65504)
             v[e] = x_;
             vh[e] = (_Float16)x_;
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){SC[0], SC[1], SC[2], SC[3]}), hsr, cx_cur.ohs + po, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, SC[4]), hsr, cx_cur.ohs + 16 + (g ? 0x80000000u : po), 0, 0);
     }
+    og.flush(p.ovf);
 }
 
 template <int KW, bool CV, int RT, int WT, bool RES, bool Y32, bool HEAD = false>

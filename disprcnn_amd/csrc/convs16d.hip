@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_ovf.h"
 #include "s16_tilemap.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int n_xt = Wo / WT, n_yt = (Ho + RPW * RT - 1) / (RPW * RT);
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
-    const float relu_lo = p.relu ? 0.f : -3.0e38f;
+    const float relu_lo = p.relu ? 0.f : -65504.f;
+    S16Ovf og;                                        // range guard (s16_ovf.h)
 
     for (unsigned it = 0;; ++it) {
         const unsigned j = it * per_xcd + qx;
@@ -211,11 +213,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int q = 0; q < 4; ++q) part[q] = *(const f32x4*)(xb + q * XW + k * 1024);
                 }
                 _Float16 vh[OWN], vl[OWN];
+                const unsigned long long og_keep = S16Ovf::lanes(lane_ok && zo >= 1);      // dropped lanes / the step before the first plane: not values of the map
                 auto fin = [&](int e) __attribute__((always_inline)) {
                     float s_;
                     if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
                     else s_ = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-                    float x_ = fmaxf(s_ * sc[e] + sh[e], relu_lo);
+                    float x_ = s_ * sc[e] + sh[e];
+                    og.see(x_, og_keep);
+                    x_ = fmaxf(x_, relu_lo);
                     x_ = fminf(x_, 65504.f);
                     vh[e] = (_Float16)x_;
                     vl[e] = (_Float16)(x_ - (float)vh[e]);
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // drain: finalize the last plane (an even step without MFMAs)
         step(2 * zo, zo, I0{}, F{}, F{});
     }
+    og.flush(p.ovf);
 }
 
 template <int KW, int RT, int WT, int RING, bool DEI, bool CS>

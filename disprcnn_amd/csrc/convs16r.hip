@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_ovf.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
 
     Col ccur = col_of(0);
     if (!ccur.valid) return;
+    S16Ovf og;                                              // range guard (s16_ovf.h)
     Src s_cur = src_of(ccur), s_next = s_cur;
     Ctx cx_cur = ctx_of(ccur), cx_prev = cx_cur;
     cx_prev.ok = false;
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
             __builtin_amdgcn_sched_barrier(0);
         }
         _Float16 vh[OWN], vl[OWN];
+        const unsigned long long og_keep = S16Ovf::lanes(f_ok);       // idle lanes / rows outside the map hold over-read data
         auto fin = [&](int e) __attribute__((always_inline)) {
             float s_;
             if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
                 const _Float16 rh = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][0])[e], rl_ = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][1])[e];
                 x_ += (float)rh + (float)rl_;
             }
+            og.see(x_, og_keep);
             x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);
             vh[e] = (_Float16)x_;
             vl[e] = (_Float16)(x_ - (float)vh[e]);
@@ -364,6 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
         s_cur = s_next;
     }
     step(STEPS, I0{}, F_{}, F_{}, F_{});       // drain: the last row (published in the step before) is finalized
+    og.flush(p.ovf);
 }
 
 template <int KW, int KS, bool RES, int DIL = 1>

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_ovf.h"
 #include "s16_tilemap.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -123,6 +124,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
     const float relu_lo = p.relu ? 0.f : -65504.f;
+    S16Ovf og;                                        // range guard (s16_ovf.h)
 
     for (unsigned it = 0;; ++it) {
         const unsigned j = it * per_xcd + qx;
@@ -239,6 +241,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
                 const int pz = R.cls[ci] >> 2;
                 const int ai = pz ? P : 0;
                 const f32x16 a = acc[ci][ai];
+                const unsigned long long og_keep = S16Ovf::lanes(fo[ci] != 0x80000000u);      // dropped lanes / planes hold over-read data
                 f16x8 hi[2], lo[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -250,6 +253,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
                         const float sc_ = e < 4 ? sc0[e & 3] : sc1[e & 3], sh_ = e < 4 ? sh0[e & 3] : sh1[e & 3];
                         float x_ = a[s * 8 + e] * sc_ + sh_;
                         x_ += (float)rh[e] + (float)rl_[e];
+                        og.see(x_, og_keep);
                         x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);
                         hi[s][e] = (_Float16)x_;
                         lo[s][e] = (_Float16)(x_ - (float)hi[s][e]);
@@ -287,6 +291,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
             step(zi, I0{}, F{});
         }
     }
+    og.flush(p.ovf);
 }
 
 template <int RT, int WT>

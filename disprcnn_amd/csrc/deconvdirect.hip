@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_ovf.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -62,7 +63,8 @@ constexpr ComboTable kTab = make_table();
 // S16 (round 5): the result (also) goes out as an RS16 tensor (convs16.hip's input layout): lane (voxel j, g) of cout tile t holds couts
 // 16t + 4g .. +3 = half a chunk: chunk (s = t & 1, g' = g & 1) of the 32-channel block t >> 1, bytes (g >> 1)*8 .. -- 8 B hi + 8 B lo.
 template <int VT, int CT, bool S16 = false>
-__global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_tapconv_params p, char* y16) {
+__global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_tapconv_params p, char* y16, uint32_t* ovf) {
+    S16Ovf og;                                        // range guard of the RS16 epilogue (s16_ovf.h)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
                                 f16x4 hi, lo;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
+                                    og.see(v_[e]);
                                     const float x_ = fminf(fmaxf(v_[e], -65504.f), 65504.f);
                                     hi[e] = (_Float16)x_;
                                     lo[e] = (_Float16)(x_ - (float)hi[e]);
@@ -230,17 +233,18 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
         }
         block(bA, p.cb_in - 1, std::true_type{});
     }
+    if constexpr (S16) og.flush(ovf);
 }
 
 template <int VT, int CT, bool S16 = false>
-int launch(const drc_tapconv_params& p, hipStream_t stream, char* y16 = nullptr) {
+int launch(const drc_tapconv_params& p, hipStream_t stream, char* y16 = nullptr, uint32_t* ovf = nullptr) {
     const long voxels = (long)p.N * p.OD * p.OH * p.OW;
     const long items = ((voxels + VT * 16 - 1) / (VT * 16)) * (p.cout_pad / 16 / CT);
     long workers = 256L * DD_WAVES;                      // one wave per SIMD (the two B sets + 8 accumulator classes fill the file)
     if (workers > items) workers = items;
     if (workers < 1) workers = 1;
     dim3 grid((unsigned)((workers + DD_WAVES - 1) / DD_WAVES), 1, 1);
-    hipLaunchKernelGGL((deconvdirect_kernel<VT, CT, S16>), grid, dim3(64 * DD_WAVES), 0, stream, p, y16);
+    hipLaunchKernelGGL((deconvdirect_kernel<VT, CT, S16>), grid, dim3(64 * DD_WAVES), 0, stream, p, y16, ovf);
     return (int)hipGetLastError();
 }
 
@@ -264,7 +268,7 @@ extern "C" int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* pp, int co
     return -2;
 }
 
-extern "C" int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* pp, void* y16, void* stream) {
+extern "C" int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* pp, void* y16, uint32_t* ovf, void* stream) {
     if (!pp || !y16) return -1;
     const drc_tapconv_params& p = *pp;
     if (!p.x || !p.w || !p.scale || !p.shift) return -1;
@@ -276,5 +280,5 @@ extern "C" int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* pp, vo
     if ((int64_t)p.N * p.x_n_stride * 4 >= (1LL << 32) || (p.y && (int64_t)p.N * p.y_n_stride * 4 >= (1LL << 32)) ||
         (p.res && (int64_t)p.N * p.r_n_stride * 4 >= (1LL << 32)) || (int64_t)p.N * unit16 >= (1LL << 32))
         return -5;
-    return launch<2, 2, true>(p, (hipStream_t)stream, (char*)y16);
+    return launch<2, 2, true>(p, (hipStream_t)stream, (char*)y16, ovf);
 }

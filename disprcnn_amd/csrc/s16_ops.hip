@@ -9,15 +9,17 @@
 #include <stdint.h>
 
 #include "../../include/disprcnn_hip.h"
+#include "s16_ovf.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-__device__ inline void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+__device__ inline void split8(const float (&v)[8], f16x8& hi, f16x8& lo, S16Ovf& og) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+        og.see(v[e]);
         float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
         hi[e] = (_Float16)x;
         lo[e] = (_Float16)(x - (float)hi[e]);
@@ -25,7 +27,8 @@ __device__ inline void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
 }
 
 // dense [N,C,D,H,W] fp32 -> RS16 (interior only; the halo stays as allocated: zero)
-__global__ void rs16_from_dense_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int N, int C, int D, int H, int W, int pd) {
+__global__ void rs16_from_dense_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int N, int C, int D, int H, int W, int pd, uint32_t* ovf) {
+    S16Ovf og;
     const long total = (long)N * (C / 32) * D * H * 4 * W;
     const int Wp = W + 2, Hp = H + 2, Dp = D + 2 * pd;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -44,16 +47,18 @@ __global__ void rs16_from_dense_kernel(const float* __restrict__ x, _Float16* __
             v[e] = x[((((long)n * C + c) * D + z) * H + yh) * W + xw];
         }
         f16x8 hi, lo;
-        split8(v, hi, lo);
+        split8(v, hi, lo, og);
         _Float16* row = y + (((((long)n * (C / 32) + cb) * Dp + z + pd) * Hp + yh + 1) * 8) * (long)Wp * 8;
         *(f16x8*)(row + ((long)sg * Wp + xw + 1) * 8) = hi;
         *(f16x8*)(row + ((long)(4 + sg) * Wp + xw + 1) * 8) = lo;
     }
+    og.flush(ovf);
 }
 
 // blocked fp32 [units][CB16 total][D+2pdi][H+2phi][W+2pwi][16] (channel blocks cb16_off .. of it) -> RS16
 __global__ void rs16_from_blocked_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int N, int C, int D, int H, int W, int pdi, int phi,
-                                         int pwi, int cb16_total, int cb16_off, int pd) {
+                                         int pwi, int cb16_total, int cb16_off, int pd, uint32_t* ovf) {
+    S16Ovf og;
     const long total = (long)N * (C / 32) * D * H * 4 * W;
     const int Wp = W + 2, Hp = H + 2, Dp = D + 2 * pd;
     const long xw_ = W + 2 * pwi, xh_ = H + 2 * phi, xd_ = D + 2 * pdi;
@@ -71,11 +76,12 @@ __global__ void rs16_from_blocked_kernel(const float* __restrict__ x, _Float16* 
         const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 8);
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         f16x8 hi, lo;
-        split8(v, hi, lo);
+        split8(v, hi, lo, og);
         _Float16* row = y + (((((long)n * (C / 32) + cb) * Dp + z + pd) * Hp + yh + 1) * 8) * (long)Wp * 8;
         *(f16x8*)(row + ((long)sg * Wp + xw + 1) * 8) = hi;
         *(f16x8*)(row + ((long)(4 + sg) * Wp + xw + 1) * 8) = lo;
     }
+    og.flush(ovf);
 }
 
 // RS16 -> dense fp32 [N,C,D,H,W]
@@ -134,23 +140,23 @@ inline unsigned grid_for(long total) {
 
 }  // namespace
 
-extern "C" int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, int W, int pd, void* stream) {
+extern "C" int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, int W, int pd, uint32_t* ovf, void* stream) {
     if (!x || !y16) return -1;
     if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1) return -2;
     if (N == 0) return 0;
-    hipLaunchKernelGGL(rs16_from_dense_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y16, N, C, D, H, W, pd);
+    hipLaunchKernelGGL(rs16_from_dense_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y16, N, C, D, H, W, pd, ovf);
     return (int)hipGetLastError();
 }
 
 extern "C" int drc_rs16_from_blocked(const float* xb, void* y16, int N, int C, int D, int H, int W, int pd_in, int ph_in, int pw_in, int cb16_total,
-                                     int cb16_off, int pd, void* stream) {
+                                     int cb16_off, int pd, uint32_t* ovf, void* stream) {
     if (!xb || !y16) return -1;
     if (N < 0 || C <= 0 || (C & 31) || D <= 0 || H <= 0 || W <= 0 || pd < 0 || pd > 1 || pd_in < 0 || ph_in < 0 || pw_in < 0 || cb16_off < 0 ||
         cb16_off + C / 16 > cb16_total)
         return -2;
     if (N == 0) return 0;
     hipLaunchKernelGGL(rs16_from_blocked_kernel, dim3(grid_for((long)N * (C / 32) * D * H * 4 * W)), dim3(256), 0, (hipStream_t)stream, xb, (_Float16*)y16, N, C, D,
-                       H, W, pd_in, ph_in, pw_in, cb16_total, cb16_off, pd);
+                       H, W, pd_in, ph_in, pw_in, cb16_total, cb16_off, pd, ovf);
     return (int)hipGetLastError();
 }
 

@@ -89,18 +89,6 @@ class Blocked:
         _lib.check(st, "drc_dense_to_blocked")
         return self
 
-    def to_blocked(self, blk, first_unit=0):
-        """interior -> units [first_unit, first_unit + N) of a blocked fp32 tensor (or channel slice) of the same logical shape."""
-        base = getattr(blk, "base", blk)
-        if (blk.C, blk.D, blk.H, blk.W) != (self.C, self.D, self.H, self.W) or base.N < first_unit + self.N:
-            raise ValueError("RS16.to_blocked: shapes differ")
-        if self.N:
-            dst = C.c_void_p(base.storage.data_ptr() + 4 * first_unit * base.n_stride)
-            st = _lib.lib().drc_rs16_to_blocked(_ptr(self.storage), dst, self.N, self.C, self.D, self.H, self.W, base.pd, base.ph, base.pw, base.cb,
-                                                getattr(blk, "cb_off", 0), self.pd, _stream_ptr(self.device))
-            _lib.check(st, "drc_rs16_to_blocked")
-        return blk
-
     def to_dense(self):
         shape = (self.N, self.C, self.D, self.H, self.W)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -660,7 +648,7 @@ class ConvPlan:
             st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
             _lib.check(st, "drc_conv3d_k3s2_fwd")
         elif self.deconv_direct and y16 is not None:
-            st = _lib.lib().drc_deconv3d_k3s2_direct_s16_fwd(C.byref(p), _ptr(y16.storage), _stream_ptr(self.device))
+            st = _lib.lib().drc_deconv3d_k3s2_direct_s16_fwd(C.byref(p), _ptr(y16.storage), _ovf_ptr(), _stream_ptr(self.device))
             _lib.check(st, "drc_deconv3d_k3s2_direct_s16_fwd")
         elif self.deconv_direct:
             st = _lib.lib().drc_deconv3d_k3s2_direct_fwd(C.byref(p), self.deconv_ct, _stream_ptr(self.device))
@@ -1009,6 +997,8 @@ class BridgedConv2dS16:
     def worth(N, cin, cout, H, W):
         """Large maps only: a column of the kernel is 28 rows x 28 columns x 32 couts, and the converters at both ends are extra launches."""
         if not TRUNK_S16["enabled"] or BridgedConv2dS16.slices(cin) is None or cout not in (32, 64, 128, 256, 512) or not S16["enabled"]:
+            return False
+        if not s16_allowed():               # a guarded pass is being repeated on the fp32 kernels (OverflowGuard)
             return False
         tiles = N * -(-H // 28) * -(-W // 28) * (cout // 32)
         return H >= TRUNK_S16["min_rows"] and tiles >= TRUNK_S16["min_tiles"]
@@ -1425,6 +1415,111 @@ LASTCONV_S16 = {"enabled": True}     # eval, split-f16 2D schedule: lastconv[0] 
 S16 = {"enabled": True}       # eval: the stride-1 3x3x3 layers at full resolution on the f16 matrix cores in split arithmetic (convs16.hip)
 
 
+
+# ---- range guard of the split-f16 path (round 6; csrc/s16_ovf.h, include/disprcnn_hip.h `drc_s16conv_params.ovf`)
+# The reference computes in fp32 (config/defaults.py:22; submodule.py:19-22) and has no activation range limit; an RS16 value must stay
+# within +-65504.  Every kernel that writes split-f16 values ORs 1 into the device word of the OverflowGuard in scope when it had to clamp
+# (or met Inf / NaN); the component that opened the scope reads the word ONCE at the end of its forward pass (one stream synchronisation)
+# and -- "auto" -- runs the pass again with every split-f16 decision turned off (s16_allowed() False: the fp32 MFMA kernels), or --
+# math = "f16x2" -- raises.  Scopes nest: an inner component (PSMNet inside DispRCNN3D, the trunk inside DispRCNN) reports to the outermost
+# scope and leaves the check and the re-run to it.
+_GUARD = {"cur": None, "safe": False}
+
+
+class OverflowPolicy:
+    """Host side of the guard: after an overflow the next `2^level` passes go straight to the fp32 kernels (level grows with every further
+    overflow up to `cap` passes, a clean split-f16 pass resets it) -- a model whose activations are out of range pays the double pass at
+    passes 1, 3, 7, 15, ... instead of at every one, a single outlier input costs two fp32 passes."""
+
+    def __init__(self, cap=256):
+        self.cap, self.level, self.skip, self.overflows, self.checks = cap, 0, 0, 0, 0
+
+    def want_fast(self):
+        if self.skip > 0:
+            self.skip -= 1
+            return False
+        return True
+
+    def report(self, overflowed):
+        self.checks += 1
+        if overflowed:
+            self.overflows += 1
+            self.skip = min(1 << self.level, self.cap)
+            self.level = min(self.level + 1, 30)
+        else:
+            self.level = 0
+
+
+class OverflowGuard:
+    """One int32 device word + its policy.  `used` is set when a launch picked the word up during the scope (no split-f16 launch: no
+    synchronisation at the end)."""
+
+    def __init__(self, device):
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.policy = OverflowPolicy()
+        self.used = False
+        self.warned = False
+
+    def ptr(self):
+        self.used = True
+        return C.c_void_p(self.word.data_ptr())
+
+    def tripped(self):
+        """Read (one device synchronisation) and clear the word."""
+        v = int(self.word.item())
+        if v:
+            self.word.zero_()
+        return bool(v)
+
+
+def s16_allowed():
+    """False while a guarded pass is being repeated on the fp32 kernels (or its back-off runs): every split-f16 decision consults this."""
+    return not _GUARD["safe"]
+
+
+def _ovf_ptr():
+    g = _GUARD["cur"]
+    return g.ptr() if g is not None else None
+
+
+def guard_in_scope():
+    return _GUARD["cur"]
+
+
+def guarded(guard, fn, strict=False, what="split-f16 path", enabled=True):
+    """Run fn() under `guard` (see above).  strict: the caller asked for split-f16 arithmetic explicitly ("f16x2"): an overflow raises.
+    A scope that is already open, a stream capture in progress (the word cannot be read inside one) or enabled = False: plain fn()."""
+    if _GUARD["cur"] is not None or guard is None or not enabled or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return fn()
+    import warnings
+    pol = guard.policy
+    _GUARD["cur"], _GUARD["safe"] = guard, (False if strict else not pol.want_fast())
+    guard.used = False
+    try:
+        out = fn()
+        if not guard.used:
+            return out
+        over = guard.tripped()
+        pol.report(over)
+        if not over:
+            return out
+        if strict:
+            raise RuntimeError(f"{what}: a value left the split-f16 range (|v| > 65504, Inf or NaN) and math = 'f16x2' was requested; use "
+                               f"'auto' (re-runs on the fp32 kernels) or 'f32'")
+        if not guard.warned:
+            guard.warned = True
+            warnings.warn(f"{what}: a value left the split-f16 range (|v| > 65504, Inf or NaN); this pass and the next {pol.skip} run on the "
+                          f"fp32 kernels (reference arithmetic, config/defaults.py:22).  Reported once per model.", RuntimeWarning, stacklevel=3)
+        _GUARD["safe"] = True
+        guard.used = False
+        out = fn()
+        if guard.used and guard.tripped():      # (a component that ignored s16_allowed(): a bug, not an input property)
+            raise RuntimeError(f"{what}: the fp32 re-run still issued split-f16 launches that overflowed")
+        return out
+    finally:
+        _GUARD["cur"], _GUARD["safe"] = None, False
+
+
 class RS16:
     """Split-f16 tensor halfs [N][C/32][D+2pd][H+2][8 chunks][W+2][8], zero halo (include/disprcnn_hip.h, drc_s16conv_params)."""
 
@@ -1451,7 +1546,7 @@ class RS16:
         require_gpu(dense, "RS16.from_dense")
         dense = dense.contiguous()
         if self.N:
-            st = _lib.lib().drc_rs16_from_dense(_ptr(dense), _ptr(self.storage), self.N, self.C, self.D, self.H, self.W, self.pd, _stream_ptr(self.device))
+            st = _lib.lib().drc_rs16_from_dense(_ptr(dense), _ptr(self.storage), self.N, self.C, self.D, self.H, self.W, self.pd, _ovf_ptr(), _stream_ptr(self.device))
             _lib.check(st, "drc_rs16_from_dense")
         return self
 
@@ -1463,7 +1558,7 @@ class RS16:
         if self.N:
             src = C.c_void_p(base.storage.data_ptr() + 4 * first_unit * base.n_stride)
             st = _lib.lib().drc_rs16_from_blocked(src, _ptr(self.storage), self.N, self.C, self.D, self.H, self.W, base.pd, base.ph, base.pw, base.cb,
-                                                  getattr(blk, "cb_off", 0), self.pd, _stream_ptr(self.device))
+                                                  getattr(blk, "cb_off", 0), self.pd, _ovf_ptr(), _stream_ptr(self.device))
             _lib.check(st, "drc_rs16_from_blocked")
         return self
 
@@ -1564,7 +1659,7 @@ class ConvPlanS16:
                              _ptr(res.storage) if res is not None else None, _ptr(y16.storage) if y16 is not None else None,
                              _ptr(y32.storage) if y32 is not None else None, _ptr(left.storage) if self.cv else None,
                              _ptr(right.storage) if self.cv else None, self.N, self.D, self.H, self.W, self.cin, self.cout, int(self.relu), int(lo4), int(self.dil),
-                             _ptr(head[1]) if head is not None else None, _ptr(head[0]) if head is not None else None)
+                             _ptr(head[1]) if head is not None else None, _ptr(head[0]) if head is not None else None, _ovf_ptr())
         dev = self.device
         if TIMING is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -167,9 +167,18 @@ class BackboneRuntime:
         return ws
 
     def forward(self, x):
+        """The pyramid of backbone/resnet.py:81-146 + fpn.py:44-77.  The 3x3 layers on the largest maps run in split-f16 arithmetic
+        (engine.BridgedConv2dS16) under the range guard of engine.guarded: a value beyond +-65504 there (the fp32 reference has no limit)
+        repeats the pass on the fp32 kernels.  model.overflow_check = False skips the check."""
         E.require_gpu(x, "backbone input")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [N,3,H,W], got {tuple(x.shape)}")
+        if getattr(self, "_guard", None) is None:
+            self._guard = E.OverflowGuard(self.device)
+        return E.guarded(self._guard, lambda: self._forward_once(x), what="ResNet-FPN trunk (split-f16 3x3 layers)",
+                         enabled=bool(getattr(self.model, "overflow_check", True)))
+
+    def _forward_once(self, x):
         N, _, H, W_ = x.shape
         Wt = self._compile()
         ws = self._workspace(N, H, W_)
@@ -178,7 +187,7 @@ class BackboneRuntime:
 
         def conv(plan, x_, y_, res=None):
             c = Wt[plan]
-            br = ws["s16"].get(plan)
+            br = ws["s16"].get(plan) if E.s16_allowed() else None
             if br is not None and res is None:
                 packs, zero = _s16_slices(c, br.bounds)
                 br.run(t[x_], packs, c.shift, zero, t[y_])

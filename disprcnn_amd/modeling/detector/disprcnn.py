@@ -54,6 +54,17 @@ class DispRCNN(nn.Module):
         if self.training:
             raise NotImplementedError("training the 2D stage is not built (the shipped disparity / 3D configs freeze it)")
         left_images, right_images = to_image_list(lrimages["left"]), to_image_list(lrimages["right"])
+        # the split-f16 layers of the trunk and of the RPN head report to ONE range guard, read once at the end of the stage; an overflow
+        # (|v| > 65504: the fp32 reference has no such limit) repeats the stage on the fp32 kernels (engine.guarded)
+        from ... import engine as E
+        if left_images.tensors.is_cuda:
+            if getattr(self, "_guard", None) is None:
+                self._guard = E.OverflowGuard(left_images.tensors.device)
+            return E.guarded(self._guard, lambda: self._forward_once(left_images, right_images), what="DispRCNN 2D stage (split-f16 3x3 layers)",
+                             enabled=bool(getattr(self, "overflow_check", True)))
+        return self._forward_once(left_images, right_images)
+
+    def _forward_once(self, left_images, right_images):
         n = left_images.tensors.shape[0]
         feats = self.backbone(torch.cat((left_images.tensors, right_images.tensors), dim=0))
         left_features, right_features = [f[:n] for f in feats], [f[n:] for f in feats]

@@ -140,10 +140,21 @@ class BlockedConv2d:
         if br is None:
             br = self._s16["bridges"][key] = E.BridgedConv2dS16(xb.N, xb.C, self.cout, xb.H, xb.W, self.relu, xb.device, self._s16["cache"])
             while len(self._s16["bridges"]) > self.MAX_PLANS:
-                self._s16["bridges"].popitem(last=False)
+                (n_, c_, h_, w_), _ = self._s16["bridges"].popitem(last=False)
+                for k in [k for k in self._s16["cache"] if (k[1], k[3], k[4]) == (n_, h_, w_)]:      # its RS16 maps (keyed (tag, N, ch, H, W)) go with it
+                    del self._s16["cache"][k]
         return br
 
     def __call__(self, xb, yb):
+        """(The split-f16 bridge reports to the range guard in scope -- the detector's, engine.guarded -- or, called on its own, to a guard
+        of this layer: a value beyond +-65504 repeats the call on the fp32 kernel.)"""
+        if E.guard_in_scope() is None and xb.device.type == "cuda":
+            if getattr(self, "_guard", None) is None:
+                self._guard = E.OverflowGuard(xb.device)
+            return E.guarded(self._guard, lambda: self._call_once(xb, yb), what="BlockedConv2d (split-f16 3x3 layer)")
+        return self._call_once(xb, yb)
+
+    def _call_once(self, xb, yb):
         wp, sc, sh = self._weights(xb.device)
         br = self._bridge(xb, yb)
         if br is not None:

@@ -14,7 +14,8 @@ from ... import engine as E
 from .submodule import SPP_BRANCHES, TRUNK_STAGES
 
 GRAPH_MAX_UNITS = 96     # eval: batches up to this many ROI pairs replay a captured HIP graph (PSMNet.graph_eval = "auto")
-GRAPH_MAX_ENTRIES = 12   # captured graphs kept per runtime (one per exact input shape), least recently used dropped
+GRAPH_MAX_ENTRIES = 16   # captured graphs kept per runtime (one per unit-count bucket and input geometry), least recently used dropped
+GRAPH_CAPTURE_AFTER = 2  # a bucket is captured when it is seen for the second time (a count that never comes back costs one eager pass, not a capture)
 MAX_SLOTS = 4            # train-mode forward passes of one geometry that may await their backward at once (each owns a workspace pool)
 WS_MAX_PLANS = 48        # launch-plan sets kept per runtime (one per exact unit count; they hold views, not memory)
 
@@ -148,8 +149,11 @@ class PSMNetRuntime:
         self._tape = None       # list of recorded ops while a differentiable train-mode forward runs
         self._held = {}         # workspace slot -> token of the differentiable forward whose saved activations live there
         self._slot = 0          # slot the running forward uses
-        self._graphs = OrderedDict()    # eval HIP graphs: key -> (epoch, static inputs, GraphedStep)
+        self._graphs = OrderedDict()    # eval HIP graphs: (unit-count bucket, key) -> dict(epoch, static inputs, GraphedStep, ...)
+        self._graph_seen = {}           # key -> times seen before its capture
         self._epoch = 0         # advanced whenever what a captured graph points at is replaced (packed weights, BN folds, a workspace pool)
+        self._guard = None      # engine.OverflowGuard of this model's split-f16 passes (built on the first eval forward)
+        self._s16_used = False  # a split-f16 schedule was chosen during the running forward
 
     # ------------------------------------------------------------------ workspace slots (forwards awaiting their backward)
     def _pick_slot(self):
@@ -451,7 +455,18 @@ class PSMNetRuntime:
               all(E.s16_supported(ci, co, *dims, kind=kind) for kind, ci, co, dims in self._s16_layers(Dp, Hp, Wp)))
         if mode == "f16x2" and not ok:
             raise RuntimeError("PSMNet.regressor_math = 'f16x2': eval only; volume dims D' % 12 == 0, W' = 28 or a multiple of 56, H' % 4 == 0")
-        return ok and mode != "f32"
+        return self._s16_choice(ok and mode != "f32", mode, "regressor_math")
+
+    def _s16_choice(self, use, mode, what):
+        """A split-f16 schedule is taken only while the range guard allows it (engine.guarded: the repeat of a pass that overflowed runs on
+        the fp32 kernels); an explicit "f16x2" cannot be repeated in fp32 -- it raises."""
+        if use and not E.s16_allowed():
+            if mode == "f16x2":
+                raise RuntimeError(f"PSMNet.{what} = 'f16x2': a value left the split-f16 range (|v| > 65504) in an enclosing guarded pass")
+            return False
+        if use:
+            self._s16_used = True
+        return use
 
     def _ws3d_s16(self, N, Dp, Hp, Wp):
         key = self._slotted(("3ds16", N, Dp, Hp, Wp))
@@ -695,36 +710,87 @@ class PSMNetRuntime:
         return mode is True or n_units <= GRAPH_MAX_UNITS
 
     def _replay(self, key, inputs, fn):
-        """inputs: the caller's tensors; fn(*static_inputs) -> output tensor.  The graph is captured on first use of `key` (after an eager
-        warm-up that builds plans / workspaces), re-captured when what it points at was replaced (epoch), and replayed otherwise."""
+        """inputs: the caller's tensors (units along dim 0); fn(*static_inputs) -> output tensor (units along dim 0); key: everything the
+        pass depends on but the unit count.  ROI pairs are independent units, so a batch is padded to its capacity bucket
+        (engine.bucket_units: {2^k, 3*2^(k-1)}) and ONE graph per bucket serves every count in it -- the ROI count changes from image to image
+        (disprcnn3d.py:272-275), a graph per exact count would be captured over and over.  A bucket is captured when it is seen for
+        the GRAPH_CAPTURE_AFTER-th time (until then: eager, exact count), after an eager warm-up that builds plans / workspaces; re-captured
+        when what it points at was replaced (epoch); replayed otherwise."""
         from ...utils.graph import GraphedStep
         self._compile()                                   # a parameter / buffer change advances the epoch BEFORE the lookup
+        n = inputs[0].shape[0]
+        nb = E.bucket_units(n)
+        key = (nb,) + tuple(key)
         ent = self._graphs.get(key)
-        if ent is not None and ent[0] != self._epoch:
+        if ent is not None and ent["epoch"] != self._epoch:
             del self._graphs[key]
             ent = None
         if ent is None:
-            static = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in inputs]
+            seen = self._graph_seen.get(key, 0) + 1
+            if len(self._graph_seen) > 256:
+                self._graph_seen.clear()
+            self._graph_seen[key] = seen
+            if seen < GRAPH_CAPTURE_AFTER:
+                return fn(*inputs)
+            static = [torch.zeros((nb,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in inputs]
             for s_, t in zip(static, inputs):
-                s_.copy_(t)
+                s_[:n].copy_(t)
+            self._s16_used = False
             fn(*static)                                    # eager once: plans, workspaces, pools (may advance the epoch)
             step = GraphedStep(lambda: fn(*static), warmup=1)
-            ent = (self._epoch, static, step)
+            ent = dict(epoch=self._epoch, static=static, step=step, filled=n, s16=self._s16_used, guard=E.guard_in_scope())
             self._graphs[key] = ent
+            self._graph_seen.pop(key, None)
             while len(self._graphs) > GRAPH_MAX_ENTRIES:
                 self._graphs.popitem(last=False)
-            return step().clone()                          # (a capture records the launches, it does not run them: replay once)
-        self._graphs.move_to_end(key)
-        for s_, t in zip(ent[1], inputs):
-            s_.copy_(t)
-        return ent[2]().clone()
+        else:
+            self._graphs.move_to_end(key)
+            for s_, t in zip(ent["static"], inputs):
+                s_[:n].copy_(t)
+                if ent["filled"] > n:                      # rows of an earlier, larger batch: units of their own, but keep the padding inert
+                    s_[n:ent["filled"]].zero_()
+            ent["filled"] = n
+        if ent["s16"]:
+            self._s16_used = True
+            g = E.guard_in_scope()
+            if g is not None:
+                g.used = True                              # the replayed launches report to the guard word captured with them (key: its id)
+        return ent["step"]()[:n].clone()                   # (a capture records the launches, it does not run them: replay also after capturing)
+
+    # ------------------------------------------------------------------ range guard of the split-f16 schedules (engine.guarded)
+    def _guarded(self, training, fn):
+        """Eval passes run under this model's OverflowGuard: when a split-f16 kernel had to clamp a value (|v| > 65504, Inf, NaN -- the fp32
+        reference has no such limit, config/defaults.py:22) the pass is repeated on the fp32 MFMA kernels ("auto") or raises ("f16x2").
+        PSMNet.overflow_check = False skips the check (and its one stream synchronisation per forward)."""
+        if training or self.device.type != "cuda":
+            return fn()
+        if self._guard is None:
+            self._guard = E.OverflowGuard(self.device)
+        m = self.model
+        strict = "f16x2" in (getattr(m, "regressor_math", "auto"), getattr(m, "feature_math", "auto"))
+        return E.guarded(self._guard, fn, strict=strict, what="PSMNet (split-f16 regressor / feature CNN)",
+                         enabled=bool(getattr(m, "overflow_check", True)))
+
+    def _graph_key_tail(self):
+        """What a captured eval graph depends on besides its input shape: the module's arithmetic switches, the engine's schedule switches,
+        the range-guard word its launches report to and whether split-f16 schedules are allowed right now."""
+        m = self.model
+        return (m.maxdisp, m.mindisp, getattr(m, "regressor_math", "auto"), getattr(m, "regressor_storage", "f32"),
+                getattr(m, "feature_storage", "f32"), getattr(m, "feature_math", "auto"),
+                E.S16["enabled"], E.HEAD_FUSED["enabled"], E.LASTCONV_S16["enabled"], E.TRUNK_S16["enabled"], E.s16_allowed(),
+                id(E.guard_in_scope()))
 
     def forward_features(self, fl, fr, out_hw, training=False):
+        return self._guarded(training, lambda: self._forward_features_once(fl, fr, out_hw, training))
+
+    def forward_images(self, left, right, training=False):
+        return self._guarded(training, lambda: self._forward_images_once(left, right, training))
+
+    def _forward_features_once(self, fl, fr, out_hw, training=False):
         self._training = bool(training)
         self._slot = self._pick_slot()
         if fl.is_cuda and fl.shape == fr.shape and fl.dim() == 4 and self._graph_mode(fl.shape[0], training):
-            key = ("feat", tuple(fl.shape), tuple(out_hw), self.model.maxdisp, self.model.mindisp, getattr(self.model, "regressor_math", "auto"),
-                   getattr(self.model, "regressor_storage", "f32"))
+            key = ("feat", tuple(fl.shape[1:]), tuple(out_hw)) + self._graph_key_tail()
             return self._replay(key, (fl, fr), lambda a, b: self._forward_features_impl(a, b, out_hw, False))
         if training and torch.is_grad_enabled():
             params = [p for _, _, p in self._slots("p") if p.requires_grad and not self._is_fe_param(p)]
@@ -858,7 +924,7 @@ class PSMNetRuntime:
               E.s16_supported(64, 128, 1, H // 4, W // 4, "2d") and E.s16_supported(128, 128, 1, H // 4, W // 4, "2d"))
         if mode == "f16x2" and not ok:
             raise RuntimeError("PSMNet.feature_math = 'f16x2': eval only; H/4 a multiple of 28 and W/4 a multiple of 56")
-        return ok and mode != "f32"
+        return self._s16_choice(ok and mode != "f32", mode, "feature_math")
 
     def _ws2d_eval(self, N, H, W):
         return self._ws2d_s16(N, H, W) if self._use_s16_2d(False, H, W) else self._ws2d(N, H, W)
@@ -1173,12 +1239,11 @@ class PSMNetRuntime:
         return lib.drc_avgpool2d_blocked_slice(E._ptr(base.storage), E._ptr(pool.storage), base.N, skip.cb, base.H, base.W, base.ph, k, oh, ow, 0,
                                                base.cb, skip.cb_off, sp)
 
-    def forward_images(self, left, right, training=False):
+    def _forward_images_once(self, left, right, training=False):
         self._training = bool(training)
         self._slot = self._pick_slot()
         if left.is_cuda and left.dim() == 4 and self._graph_mode(left.shape[0], training):
-            key = ("img", tuple(left.shape), self.model.maxdisp, self.model.mindisp, getattr(self.model, "regressor_math", "auto"),
-                   getattr(self.model, "regressor_storage", "f32"), getattr(self.model, "feature_storage", "f32"), getattr(self.model, "feature_math", "auto"))
+            key = ("img", tuple(left.shape[1:])) + self._graph_key_tail()
             return self._replay(key, (left, right), lambda a, b: self._forward_images_impl(a, b, False))
         if training and torch.is_grad_enabled():
             params = [p for _, _, p in self._slots("p") if p.requires_grad]

@@ -155,8 +155,8 @@ int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_w
 int drc_deconv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 /* The same launch writing its result (also) as an RS16 tensor halfs [N][cout/32][2*OD+2][2*OH+2][8][2*OW+2][8] (round 5: the
  * consumer is the split-f16 convolution drc_conv3d_k3_s16_fwd); p->y may be NULL (RS16 output only); cout_pad % 32 == 0, two cout
- * tiles per wave. */
-int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* p, void* y16, void* stream);
+ * tiles per wave.  ovf: the range-guard word of drc_s16conv_params.ovf (may be NULL). */
+int drc_deconv3d_k3s2_direct_s16_fwd(const drc_tapconv_params* p, void* y16, uint32_t* ovf, void* stream);
 
 /* The stride-1 3x3x3 convolution of drc_tapconv3d_direct_fwd (same parameter block; R, WT and lds_bytes_per_wave ignored) as
  * Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores: 64 instead of 216 multiplies per (cin, cout) pair and 2x2x2 output tile.
@@ -382,6 +382,9 @@ typedef struct drc_s16conv_params {
                             stackhourglass.py:78-88) are: float [N][D][H][W][12], S[kh*3+kw] of the SOURCE voxel summed over the depth taps
                             (j 0..4 at floats 0..4, j 5..8 at 8..11), scaled by 2^wexp of w1.  drc_head_gather_fwd finishes the layer. */
     const void* w1;      /* with head: the 32 -> 1 weights as the MFMA A operand, halfs [2 K slices][hi, lo][64][8] (4 KiB) */
+    uint32_t* ovf;       /* optional device word (round 6): OR-ed with 1 when a value this launch stores (or, with head, multiplies) left the
+                            split-f16 range before the clamp -- |v| > 65504, Inf or NaN.  The reference is fp32 (config/defaults.py:22) and has no
+                            such limit: the caller reads the word once per forward and re-runs on the fp32 kernels or raises.  NULL: no report. */
 } drc_s16conv_params;
 int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
@@ -411,10 +414,12 @@ int drc_conv2d_k3_s16_supported(int cin, int cout, int H, int W, int dil);
 int drc_conv2d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
 /* RS16 converters (s16_ops.hip): interior only, the zero halo is the allocator's.  dense = NCDHW fp32 (D = 1, pd = 0 for 2D maps);
  * blocked = the engine's fp32 blocked tensor, channel blocks [cb16_off, cb16_off + C/16) of a tensor with cb16_total blocks and halos
- * (pd_in, ph_in, pw_in).  They stand where the reference hands fp32 NCHW features to the concat loop, stackhourglass.py:112-128. */
-int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, int W, int pd, void* stream);
+ * (pd_in, ph_in, pw_in).  They stand where the reference hands fp32 NCHW features to the concat loop, stackhourglass.py:112-128.
+ * ovf (the two fp32 -> RS16 converters; may be NULL): the range-guard word of drc_s16conv_params.ovf -- set when an input value is outside
+ * [-65504, 65504] (it is stored clamped), Inf or NaN. */
+int drc_rs16_from_dense(const float* x, void* y16, int N, int C, int D, int H, int W, int pd, uint32_t* ovf, void* stream);
 int drc_rs16_from_blocked(const float* xb, void* y16, int N, int C, int D, int H, int W, int pd_in, int ph_in, int pw_in, int cb16_total,
-                          int cb16_off, int pd, void* stream);
+                          int cb16_off, int pd, uint32_t* ovf, void* stream);
 int drc_rs16_to_dense(const void* y16, float* x, int N, int C, int D, int H, int W, int pd, void* stream);
 int drc_rs16_to_blocked(const void* y16, float* xb, int N, int C, int D, int H, int W, int pd_out, int ph_out, int pw_out, int cb16_total,
                         int cb16_off, int pd, void* stream);

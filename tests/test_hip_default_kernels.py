@@ -74,6 +74,37 @@ def _assert_bench_kernels(ws):
     return {n: pl.kname for n, pl in p.items()}
 
 
+def test_bench_batch_executes_the_fused_head_and_residual_instantiations_by_name(dev):
+    """a plan's `kname` carries the template flags of a plain call; the flags of the launch that actually ran (residual,
+    blocked-fp32 output, fused cout-1 head) follow the call's arguments.  At the bench's batch, the names the engine records per executed
+    launch (engine.TIMING, what bench.py's roofline reads) must be exactly the bench's: three fused-head launches -- the dominant kernel of
+    BENCH_r05 -- one residual form (dres1[2] + cost0a), the cost-volume form, and the hourglass set."""
+    import bench
+    from collections import Counter
+    m = _model(dev, "A", 48, 0, "auto")
+    N = bench.DEFAULT_ROIS
+    fl, fr = synth.synth_features(2, 32, 28, 28, tag="caseA")
+    fl, fr = fl.repeat(N // 2, 1, 1, 1).to(dev), fr.repeat(N // 2, 1, 1, 1).to(dev)
+    with torch.no_grad():
+        m.forward_from_features(fl, fr, (112, 112))
+        E.TIMING = []
+        try:
+            m.forward_from_features(fl, fr, (112, 112))
+        finally:
+            tim, E.TIMING = E.TIMING, None
+    torch.cuda.synchronize()
+    c = Counter(t[0] for t in tim)
+    want = {"convs16_kernel<2,false,1,28,false,false,true>": 3,        # classif1..3[0] + the 32 -> 1 layer behind it
+            "convs16_kernel<2,false,1,28,true,false,false>": 1,        # dres1[2] + cost0a
+            "convs16_kernel<2,false,1,28,false,false,false>": 2,       # dres0[2], dres1[0]
+            "convs16_kernel<4,true,1,28,false,false,false>": 1,        # dres0[0] on the virtual cost volume
+            "convs16d_kernel<2,2,14,3,true,true>": 3, "convs16d_kernel<4,4,7,2,true,false>": 3,
+            "convs16_kernel<4,false,2,14,false,false,false>": 1, "convs16_kernel<4,false,2,14,true,false,false>": 2,     # conv2 (+ postsqu in dres3 / dres4)
+            "convs16_kernel<4,false,4,7,false,false,false>": 3, "convs16u_kernel<4,7>": 3, "convs16u_kernel<2,14>": 3}
+    got = {k: v for k, v in c.items() if k.startswith("convs16")}
+    assert got == want, got
+
+
 @pytest.mark.parametrize("math", ["f32", "auto"])
 @pytest.mark.parametrize("case,mx,mn", [("A", 48, 0), ("At", 48, 0), ("A2", 24, -24)])
 def test_config_a_golden_replicated_to_bench_batch(dev, case, mx, mn, math):

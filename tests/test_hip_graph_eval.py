@@ -25,14 +25,18 @@ def _model(dev, case, mode, mx=48, mn=0):
 
 
 def test_graph_replay_equals_eager_from_features(dev):
+    """One graph per unit-count BUCKET (the ROI count changes from image to image): a count is padded to its bucket and sliced, a
+    bucket is captured the second time it is seen; ROI pairs are independent units, so the padded replay equals the eager pass bit for bit."""
     me, mg = _model(dev, "A", False), _model(dev, "A", "auto")
+    seq = ((16, "g0", 0), (16, "g1", 1), (16, "g2", 1), (5, "g3", 1), (6, "g4", 2), (5, "g5", 2), (4, "g6", 2), (1, "g7", 2), (1, "g8", 3), (6, "g9", 3))
     with torch.no_grad():
-        for n, tag in ((16, "g0"), (16, "g1"), (5, "g2"), (16, "g3"), (1, "g4")):            # replays, another count in between, a single ROI
+        for n, tag, graphs in seq:          # eager first sighting, capture, replay; 5 and 6 share a bucket (5 replays the graph captured for 6)
             fl, fr = synth.synth_features(n, 32, 28, 28, tag=tag)
             fl, fr = fl.to(dev), fr.to(dev)
             want = me.forward_from_features(fl, fr, (112, 112))
             got = mg.forward_from_features(fl, fr, (112, 112))
-            assert torch.equal(got, want), (n, tag)
+            assert got.shape == want.shape and torch.equal(got, want), (n, tag)
+            assert len(mg._rt._graphs) == graphs, (n, tag, len(mg._rt._graphs))
     assert len(mg._rt._graphs) == 3 and not me._rt._graphs
     # above GRAPH_MAX_UNITS "auto" stays eager; True always replays
     from disprcnn_amd.modeling.psmnet import runtime as R
@@ -41,6 +45,7 @@ def test_graph_replay_equals_eager_from_features(dev):
         a = mg.forward_from_features(fl.to(dev), fr.to(dev), (112, 112))
         assert len(mg._rt._graphs) == 3
         mg.graph_eval = True
+        mg.forward_from_features(fl.to(dev), fr.to(dev), (112, 112))           # (first sighting of the bucket under graph_eval = True: eager)
         b = mg.forward_from_features(fl.to(dev), fr.to(dev), (112, 112))
         assert len(mg._rt._graphs) == 4 and torch.equal(a, b)
     mg.graph_eval = "sometimes"

@@ -68,17 +68,18 @@ def test_params_struct_matches_header_size():
     """sizeof(drc_tapconv_params) computed by gcc must equal the ctypes mirror."""
     import subprocess, tempfile
     from disprcnn_amd import _lib
-    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(int32_t), sizeof(drc_costvol_src), sizeof(drc_wgrad_params));return 0;}'
+    src = '#include <stdio.h>\n#include "disprcnn_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu", sizeof(drc_tapconv_params), sizeof(drc_tap_class), sizeof(int32_t), sizeof(drc_costvol_src), sizeof(drc_wgrad_params), sizeof(drc_s16conv_params));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        a, b, t, cvs, wg = map(int, subprocess.check_output([exe]).split())
+        a, b, t, cvs, wg, s16p = map(int, subprocess.check_output([exe]).split())
     assert a == ctypes.sizeof(_lib.DrcTapconvParams)
     assert b == ctypes.sizeof(_lib.DrcTapClass) and t == 4
     assert cvs == ctypes.sizeof(_lib.DrcCostvolSrc)
     assert wg == ctypes.sizeof(_lib.DrcWgradParams)
+    assert s16p == ctypes.sizeof(_lib.DrcS16ConvParams)            # (round 6: + the range-guard word `ovf`)
 
 
 def test_state_dict_layout():
@@ -430,6 +431,80 @@ def test_bridged_conv_slices_and_threshold():
         assert not B.worth(2, 256, 256, 94, 310)
     finally:
         E.TRUNK_S16.update(saved)
+
+
+def test_overflow_policy_backs_off_exponentially_and_recovers():
+    """engine.OverflowPolicy: after an overflow the next 2^level passes skip the split-f16 kernels (capped), a clean fast pass resets."""
+    from disprcnn_amd import engine as E
+    pol = E.OverflowPolicy(cap=8)
+    assert pol.want_fast()
+    pol.report(True)                                   # first overflow: skip 1
+    assert [pol.want_fast() for _ in range(3)] == [False, True, True]
+    pol.report(True)                                   # second in a row: skip 2
+    assert [pol.want_fast() for _ in range(3)] == [False, False, True]
+    for _ in range(6):
+        pol.report(True)
+    assert pol.skip == 8 and pol.overflows == 8        # capped
+    while not pol.want_fast():
+        pass
+    pol.report(False)                                  # a clean split-f16 pass: back to the start
+    pol.report(True)
+    assert pol.skip == 1
+
+
+def test_guarded_control_flow_without_a_gpu():
+    """engine.guarded with a stand-in guard: clean pass -> one call; overflow -> the pass is repeated with s16_allowed() False ("auto") or
+    raises (strict); nested scopes leave the check to the outermost; the back-off passes run with s16_allowed() False from the start."""
+    import warnings
+    from disprcnn_amd import engine as E
+
+    class FakeGuard:
+        def __init__(self, trips):
+            self.policy, self.used, self.warned, self.trips, self.reads = E.OverflowPolicy(), False, False, list(trips), 0
+
+        def tripped(self):
+            self.reads += 1
+            return self.trips.pop(0) if self.trips else False
+
+    calls = []
+
+    def fn(g):
+        def run():
+            calls.append(E.s16_allowed())
+            if E.s16_allowed():
+                g.used = True                           # (a split-f16 launch picked the word up)
+            return len(calls)
+        return run
+
+    g = FakeGuard([False])
+    assert E.guarded(g, fn(g)) == 1 and calls == [True] and g.reads == 1 and E.guard_in_scope() is None
+    calls.clear()
+    g = FakeGuard([True])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert E.guarded(g, fn(g), what="unit") == 2
+    assert calls == [True, False] and len(w) == 1 and "unit" in str(w[0].message) and E.s16_allowed()
+    calls.clear()
+    assert E.guarded(g, fn(g)) == 1 and calls == [False] and g.reads == 1          # back-off pass: fp32 from the start, no read
+    assert E.guarded(g, fn(g)) == 2 and calls == [False, True]                       # then split-f16 again
+    g = FakeGuard([True])
+    with pytest.raises(RuntimeError, match="f16x2"):
+        E.guarded(g, fn(g), strict=True)
+    assert E.guard_in_scope() is None and E.s16_allowed()
+    # nested: the inner component reports to the outer guard and does not check
+    outer, inner = FakeGuard([False]), FakeGuard([True])
+    seen = []
+
+    def outer_fn():
+        seen.append(E.guard_in_scope() is outer)
+        outer.used = True
+        return E.guarded(inner, lambda: seen.append(E.guard_in_scope() is outer) or 7)
+    assert E.guarded(outer, outer_fn) == 7 and seen == [True, True] and inner.reads == 0 and outer.reads == 1
+    # disabled / no guard: plain call, no scope
+    assert E.guarded(None, lambda: E.guard_in_scope()) is None and E.guarded(FakeGuard([]), lambda: E.guard_in_scope(), enabled=False) is None
+    # a pass without split-f16 launches is not read back
+    g = FakeGuard([True])
+    assert E.guarded(g, lambda: 3) == 3 and g.reads == 0
 
 
 def test_newest_profile_set_is_complete_and_from_one_commit():
