@@ -135,6 +135,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
     const float relu_lo = p.relu ? 0.f : -65504.f;
     S16Ovf og;                                        // range guard (s16_ovf.h)
+#pragma unroll
+    for (int e = 0; e < OWN; ++e) { og.see_raw(sc[e], 3.0e38f); og.see_raw(sh[e], 3.0e38f); }      // a NaN / Inf folded BN parameter
 
     for (unsigned it = 0;; ++it) {
         const unsigned j = it * per_xcd + qx;
@@ -218,10 +220,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     float s_;
                     if constexpr (KW == 2) s_ = part[(e >> 2) * 2][e & 3] + part[(e >> 2) * 2 + 1][e & 3];
                     else s_ = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-                    float x_ = s_ * sc[e] + sh[e];
-                    og.see(x_, og_keep);
-                    x_ = fmaxf(x_, relu_lo);
+                    float x_ = fmaxf(s_ * sc[e] + sh[e], relu_lo);
                     x_ = fminf(x_, 65504.f);
+                    og.see(x_, og_keep);
                     vh[e] = (_Float16)x_;
                     vl[e] = (_Float16)(x_ - (float)vh[e]);
                 };

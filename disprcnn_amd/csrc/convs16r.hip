@@ -175,6 +175,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
     Col ccur = col_of(0);
     if (!ccur.valid) return;
     S16Ovf og;                                              // range guard (s16_ovf.h)
+#pragma unroll
+    for (int e = 0; e < OWN; ++e) { og.see_raw(sc[e], 3.0e38f); og.see_raw(sh[e], 3.0e38f); }      // a NaN / Inf folded BN parameter
     Src s_cur = src_of(ccur), s_next = s_cur;
     Ctx cx_cur = ctx_of(ccur), cx_prev = cx_cur;
     cx_prev.ok = false;
@@ -260,8 +262,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KS == 1 
                 const _Float16 rh = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][0])[e], rl_ = __builtin_bit_cast(f16x8, resv[(J + 2) % 3][1])[e];
                 x_ += (float)rh + (float)rl_;
             }
-            og.see(x_, og_keep);
             x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);
+            og.see(x_, og_keep);
             vh[e] = (_Float16)x_;
             vl[e] = (_Float16)(x_ - (float)vh[e]);
         };

@@ -107,6 +107,12 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
         bnlds[gg * 32 + e] = p.scale[co];
         bnlds[gg * 32 + 16 + e] = p.shift[co];
     }
+    S16Ovf og;                                        // range guard (s16_ovf.h)
+    if (wave == 0) {                                  // a NaN / Inf folded BN parameter (lanes 0..31 cover the tile's 32 couts)
+        const int co = ct * 32 + (lane & 31);
+        og.see_raw(p.scale[co], 3.0e38f);
+        og.see_raw(p.shift[co], 3.0e38f);
+    }
     unsigned srcoff;
     {
         const bool ok = lane < (RT + 1) * SXI;
@@ -124,7 +130,6 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
     const float relu_lo = p.relu ? 0.f : -65504.f;
-    S16Ovf og;                                        // range guard (s16_ovf.h)
 
     for (unsigned it = 0;; ++it) {
         const unsigned j = it * per_xcd + qx;
@@ -243,6 +248,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
                 const f32x16 a = acc[ci][ai];
                 const unsigned long long og_keep = S16Ovf::lanes(fo[ci] != 0x80000000u);      // dropped lanes / planes hold over-read data
                 f16x8 hi[2], lo[2];
+                float og_mx = 0.f;                                   // largest |stored value| of this accumulator (one compare per accumulator)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const f32x4 sc0 = *(lds_f4*)(bnl + g * 32 + s * 8), sc1 = *(lds_f4*)(bnl + g * 32 + s * 8 + 4);
@@ -253,12 +259,13 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
                         const float sc_ = e < 4 ? sc0[e & 3] : sc1[e & 3], sh_ = e < 4 ? sh0[e & 3] : sh1[e & 3];
                         float x_ = a[s * 8 + e] * sc_ + sh_;
                         x_ += (float)rh[e] + (float)rl_[e];
-                        og.see(x_, og_keep);
                         x_ = __builtin_amdgcn_fmed3f(x_, relu_lo, 65504.f);
+                        og_mx = fmaxf(og_mx, __builtin_fabsf(x_));
                         hi[s][e] = (_Float16)x_;
                         lo[s][e] = (_Float16)(x_ - (float)hi[s][e]);
                     }
                 }
+                og.see_max(og_mx, og_keep);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi[s]), y16r, fo[ci] + (unsigned)((s * 2) * o_chunkB), 0, 0);

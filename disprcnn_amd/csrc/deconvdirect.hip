@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * DD_WAVES) void deconvdirect_kernel(const drc_t
                                 f16x4 hi, lo;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    og.see(v_[e]);
+                                    og.see_raw(v_[e]);
                                     const float x_ = fminf(fmaxf(v_[e], -65504.f), 65504.f);
                                     hi[e] = (_Float16)x_;
                                     lo[e] = (_Float16)(x_ - (float)hi[e]);

@@ -19,7 +19,7 @@ namespace {
 __device__ inline void split8(const float (&v)[8], f16x8& hi, f16x8& lo, S16Ovf& og) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        og.see(v[e]);
+        og.see_raw(v[e]);
         float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
         hi[e] = (_Float16)x;
         lo[e] = (_Float16)(x - (float)hi[e]);

@@ -48,7 +48,7 @@ def test_C_roi_align_backward_as_the_reference_autograd_function_calls_it(dev):
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (lhs, rhs)
     xr = x.clone().requires_grad_(True)
     roi_align(xr, rois, (5, 6), 0.5, 2).backward(g)
-    assert torch.equal(xr.grad, gx)
+    assert torch.allclose(xr.grad, gx, rtol=1e-5, atol=1e-6)          # (the scatter is float atomics: the order of the adds is not fixed)
 
 
 def test_C_nms_vs_reference_kernel_golden_and_oracle(dev):

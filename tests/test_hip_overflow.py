@@ -101,6 +101,8 @@ def _run_layer(dev, kind, N, cin, cout, D, H, W, relu, boost, form="y16", with_r
     res = torch.randn(N, cout, *od, generator=g) if with_res else None
     if with_res:
         y = y + res
+    if relu:
+        y = y.clamp_min(0)                   # (a negative pre-activation the ReLU zeroes is not a range violation)
     pd = 0 if kind == "2d" else 1
     with _Scope(dev) as gd:
         plan = E.ConvPlanS16(N, cin, cout, 1 if kind == "2d" else D, H, W, relu, cv=(kind == "cv"), device=dev, kind="s1" if kind == "cv" else kind, dil=dil)
@@ -153,6 +155,29 @@ def test_conv_kernels_report_exactly_when_the_map_leaves_the_range(dev, kind, N,
     assert not hit and m < 65504.0, (hit, m)
     hit, m = _run_layer(dev, kind, N, cin, cout, D, H, W, relu, inside * 1.5, form, with_res)
     assert hit and m > 65504.0, (hit, m)
+
+
+def test_nan_or_inf_in_a_folded_bn_parameter_is_reported(dev):
+    """NaN cannot survive a clamp (v_med3 returns a finite operand), so the kernels test the folded BN scale / shift they load: a model with
+    a NaN / Inf parameter must not answer silently (the fp32 reference would propagate it)."""
+    g = torch.Generator().manual_seed(5)
+    for kind, (N, cin, cout, D, H, W) in (("s1", (2, 32, 32, 6, 28, 28)), ("s2", (2, 32, 64, 6, 14, 14)), ("up", (2, 64, 32, 3, 7, 7)), ("2d", (2, 64, 64, 1, 28, 28))):
+        shape_w = (cout, cin, 3, 3) if kind == "2d" else (cout, cin, 3, 3, 3)
+        wp, wexp = s16.pack_weight_s16((torch.randn(shape_w, generator=g) * 0.05).to(dev))
+        od = {"s1": (D, H, W), "s2": (D // 2, H // 2, W // 2), "up": (2 * D, 2 * H, 2 * W), "2d": (1, H, W)}[kind]
+        pd = 0 if kind == "2d" else 1
+        x16 = E.RS16(N, cin, D, H, W, pd, dev).from_dense(torch.randn(N, cin, D, H, W, generator=g).to(dev) if kind != "2d" else torch.randn(N, cin, H, W, generator=g).to(dev))
+        plan = E.ConvPlanS16(N, cin, cout, D, H, W, True, device=dev, kind=kind)
+        for which, bad in (("scale", float("nan")), ("shift", float("inf")), (None, 0.0)):
+            sc = torch.full((cout,), 2.0 ** -wexp, device=dev)
+            sh = torch.zeros(cout, device=dev)
+            if which == "scale":
+                sc[cout - 3] = bad
+            elif which == "shift":
+                sh[5] = bad
+            with _Scope(dev) as gd:
+                plan.run(x16, wp, sc, sh, y16=E.RS16(N, cout, *od, pd, dev))
+                assert gd.tripped() == (which is not None), (kind, which)
 
 
 def test_dilated_2d_kernel_reports(dev):
@@ -239,7 +264,8 @@ def test_overflow_is_seen_through_a_replayed_graph(dev):
         w = want.forward_from_features(fl, fr, (112, 112))
         outs = []
         for i in range(6):
-            m._rt._guard and setattr(m._rt._guard.policy, "skip", 0)     # no back-off: every pass tries the split-f16 graph first
+            if m._rt is not None and m._rt._guard is not None:
+                m._rt._guard.policy.skip = 0                               # no back-off: every pass tries the split-f16 graph first
             outs.append(m.forward_from_features(fl, fr, (112, 112)))
     assert all(torch.equal(o, w) for o in outs)
     pol = m._rt._guard.policy
