@@ -24,6 +24,17 @@ def _headers():
         [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(".h")]
 
 
+def source_digest():
+    """sha256 over the kernel sources and headers (names + contents): what a committed PMC profile is valid for (profiles/summarize.py stores it,
+    bench.py nulls `roofline.traffic` when it differs -- the GPU box has no .git to diff against)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_sources() + _headers(), key=os.path.basename):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

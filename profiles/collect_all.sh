@@ -38,7 +38,7 @@ run() {   # name, suffix of the summary files, description, full (1: also LDS + 
   PROF_CMD="$desc" python profiles/summarize.py "$OUT" "${TAG}${sfx}"
   echo "[$name] $((SECONDS - t0)) s"
 }
-run headline "" "python bench.py --steps 10 --warmup 3 --no-cpu --no-extra  (Config A headline, 1024 ROI pairs per step; plus the instrumented repeat of the same 10 steps)" 1 python bench.py --steps 10 --warmup 3 --no-cpu --no-extra
+run headline "" "python bench.py --steps 10 --warmup 3 --no-cpu --no-extra --sustain-seconds 0  (Config A headline, 1024 ROI pairs per step; plus the instrumented repeat of the same 10 steps)" 1 python bench.py --steps 10 --warmup 3 --no-cpu --no-extra --sustain-seconds 0
 run configB _configB "WHAT=psm python tools/prof_pair.py  (Config B: full PSMNet on 16 ROI crops 224x224, D=96; 2 warm-up + 5 timed passes)" 1 env WHAT=psm python tools/prof_pair.py
 run pair_backbone _pair_backbone "WHAT=bb python tools/prof_pair.py  (R-50-FPN trunk on one stereo pair 2x3x375x1242 = 250.3 GFLOP; 2 warm-up + 5 timed passes)" 0 env WHAT=bb python tools/prof_pair.py
 run stage2d _stage2d "python tools/prof_2d.py  (2D stage: DispRCNN = R-50-FPN trunk + Stereo RPN + stereo box head + mask head on one 2x3x375x1242 pair, synthetic weights; 2 warm-up + 5 timed passes)" 0 python tools/prof_2d.py

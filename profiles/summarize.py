@@ -90,6 +90,12 @@ def main(out, tag):
             a, rq, h, m = (mean(c.get(n, [])) / 1e6 for n in ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"))
             lines.append(f"| `{k}` | {a:.2f} | {rq:.2f} | {h:.2f} | {m:.2f} | {100 * h / (h + m) if h + m else float('nan'):.1f} |")
     open(os.path.join(here, f"{tag}_pmc.md"), "w").write("\n".join(lines) + "\n")
+    try:        # what the numbers are valid for: bench.py compares the digest with the sources it runs and nulls roofline.traffic when they differ
+        sys.path.insert(0, os.path.dirname(here))
+        from disprcnn_amd.csrc.build import source_digest
+        traffic["__meta__"] = {"commit": commit, "csrc_sha": source_digest(), "command": cmd}
+    except Exception as ex:  # noqa: BLE001
+        traffic["__meta__"] = {"commit": commit, "csrc_sha": None, "error": repr(ex)}
     json.dump(traffic, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1)
     print("wrote", f"profiles/{tag}_kernel_stats.md", f"profiles/{tag}_pmc.md", f"profiles/{tag}_traffic.json")
 
