@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __attribute__((address_space(3))) char* ringl = (const __attribute__((address_space(3))) char*)ring;
     typedef const __attribute__((address_space(3))) f16x8 lds_frag;
 
-    const int n_xt = Wo / WT, n_yt = (Ho + RPW * RT - 1) / (RPW * RT);
+    const int n_xt = (Wo + WT - 1) / WT, n_yt = (Ho + RPW * RT - 1) / (RPW * RT);       // ragged last tiles: lanes outside the map are masked (lane_ok)
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
     const float relu_lo = p.relu ? 0.f : -65504.f;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         };
         const __amdgpu_buffer_rsrc_t y16r = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y16 + (long)n * o_nB), 0, 0x7FFFFF00, 0x00020000);
         const int yl = y0 + rs * RT + rl;
-        const bool lane_ok = tln.ok && yl < Ho;
+        const bool lane_ok = tln.ok && yl < Ho && x0 + xl < Wo;
         unsigned o16;
         if constexpr (KW == 2)
             o16 = (unsigned)((long)ct * o_cbB + o_planeB + (long)(yl + 1) * o_rowB + (long)(k * 2 + g) * (Wpo * 16) + (long)(x0 + xl + 1) * 16);
@@ -333,7 +333,7 @@ int launch2(const drc_s16conv_params& p, hipStream_t stream) {
         attr_done = true;
     }
     const int Ho = p.H / 2, Wo = p.W / 2;
-    const long columns = (long)p.N * ((Ho + RPW * RT - 1) / (RPW * RT)) * (Wo / WT);
+    const long columns = (long)p.N * ((Ho + RPW * RT - 1) / (RPW * RT)) * ((Wo + WT - 1) / WT);
     const int n_ct = CS ? 1 : p.cout / 32;
     long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
     while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
@@ -365,8 +365,7 @@ extern "C" int drc_conv3d_k3s2_s16_supported(int cin, int cout, int D, int H, in
     if (cin != 32 && cin != 64) return 0;
     if (cout != 32 && cout != 64) return 0;
     if (D <= 0 || H <= 0 || W <= 0 || (D & 1) || (H & 1) || (W & 1)) return 0;
-    const int Wo = W / 2;
-    return Wo == 14 || Wo == 7 || Wo % 28 == 0;
+    return 1;       // round 6: any even dims (output width <= 7: 4 x 7 tiles, <= 14: 2 x 14, else 1 x 28; the last tiles masked)
 }
 
 extern "C" int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* pp, void* stream) {
@@ -382,7 +381,7 @@ extern "C" int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* pp, void* strea
     hipStream_t s = (hipStream_t)stream;
     const int Wo = p.W / 2;
     // (ring depth by what fits the 160 KiB LDS next to the 32 KiB exchange buffers)
-    if (Wo == 14) return p.cin == 32 ? launch<2, 2, 14, 3, 3>(p, s) : launch<4, 2, 14, 2, 2>(p, s);
-    if (Wo == 7) return p.cin == 32 ? launch<2, 4, 7, 3, 3>(p, s) : launch<4, 4, 7, 2, 2>(p, s);
+    if (Wo <= 7) return p.cin == 32 ? launch<2, 4, 7, 3, 3>(p, s) : launch<4, 4, 7, 2, 2>(p, s);
+    if (Wo <= 14) return p.cin == 32 ? launch<2, 2, 14, 3, 3>(p, s) : launch<4, 2, 14, 2, 2>(p, s);
     return p.cin == 32 ? launch<2, 1, 28, 2, 3>(p, s) : launch<4, 1, 28, 2, 2>(p, s);
 }

@@ -126,7 +126,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
     typedef const __attribute__((address_space(3))) f16x8 lds_frag;
     typedef const __attribute__((address_space(3))) f32x4 lds_f4;
 
-    const int n_xt = Wi / WT, n_yt = (Hi + RT - 1) / RT;
+    const int n_xt = (Wi + WT - 1) / WT, n_yt = (Hi + RT - 1) / RT;          // ragged last tiles: lanes outside the map are masked (lane_ok)
     const unsigned xcd = blockIdx.x & 7, qx = (blockIdx.x >> 3) / n_ct, per_xcd = (gridDim.x >> 3) / n_ct;
     const unsigned cols_unit = (unsigned)n_yt * n_xt;
     const float relu_lo = p.relu ? 0.f : -65504.f;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void body(const drc_s16conv_params& p, char* lds, int
         const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(p.res ? (void*)((const char*)p.res + (long)n * o_nB + (long)ct * o_cbB) : (void*)p.w, 0,
                                                                               p.res ? 0x7FFFFF00 : 0, 0x00020000);
         const int yl = y0 + rl;
-        const bool lane_ok = tln.ok && yl < Hi;
+        const bool lane_ok = tln.ok && yl < Hi && x0 + xl < Wi;
         // this lane's even-corner output voxel (2 yl, 2 (x0 + xl)), chunk (s = 0, g), hi, in output plane 0 (padded + 1)
         const unsigned o_lane = (unsigned)(o_planeB + (long)(2 * yl + 1) * o_rowB + (long)g * o_chunkB + (long)(2 * (x0 + xl) + 1) * 16);
 
@@ -320,7 +320,7 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)convs16u_kernel<RT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const long columns = (long)p.N * ((p.H + RT - 1) / RT) * (p.W / WT);
+    const long columns = (long)p.N * ((p.H + RT - 1) / RT) * ((p.W + WT - 1) / WT);
     const int n_ct = p.cout / 32;
     long blocks = 256;                                   // column workers x cout tiles (the tiles of a worker side by side on its XCD)
     while (blocks > 8 * n_ct && blocks / (2 * n_ct) >= columns) blocks /= 2;
@@ -334,7 +334,7 @@ int launch(const drc_s16conv_params& p, hipStream_t stream) {
 extern "C" int drc_deconv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W) {
     if (cin != 64 || (cout != 32 && cout != 64)) return 0;
     if (D <= 0 || H <= 0 || W <= 0) return 0;
-    return W == 14 || W == 7 || W % 28 == 0;
+    return 1;       // round 6: any input dims (W <= 7: 4 x 7 input tiles, <= 14: 2 x 14, else 1 x 28; the last tiles masked)
 }
 
 extern "C" int drc_deconv3d_k3s2_s16_fwd(const drc_s16conv_params* pp, void* stream) {
@@ -348,7 +348,7 @@ extern "C" int drc_deconv3d_k3s2_s16_fwd(const drc_s16conv_params* pp, void* str
     const long unit_out = (long)(2 * p.D + 2) * (2 * p.H + 2) * (2 * p.W + 2) * 128;      // one 32-channel block
     if (unit_out >= 0x7FFFFF00L / 2) return -5;
     hipStream_t s = (hipStream_t)stream;
-    if (p.W == 14) return launch<2, 14>(p, s);
-    if (p.W == 7) return launch<4, 7>(p, s);
+    if (p.W <= 7) return launch<4, 7>(p, s);
+    if (p.W <= 14) return launch<2, 14>(p, s);
     return launch<1, 28>(p, s);
 }

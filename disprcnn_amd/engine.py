@@ -1530,12 +1530,15 @@ class RS16:
         self.cb = C_ // 32
         self.unit = self.cb * (D + 2 * pd) * (H + 2) * 8 * (W + 2) * 8          # halfs per unit
         self.numel = N * self.unit
+        # slack behind the last unit: a masked (ragged) last tile of the kernels stages whole slabs -- up to a tile's rows below the bottom halo
+        # and a tile's columns to the right of it; what it over-reads only reaches output lanes that are not stored, but it must be mapped memory
+        slack = self.slack = max(4096, 8 * 8 * (W + 2) * 8)
         if storage is None:
-            self.storage = torch.zeros(self.numel + 4096, dtype=torch.float16, device=device)
+            self.storage = torch.zeros(self.numel + slack, dtype=torch.float16, device=device)
         else:
-            if storage.numel() < self.numel + 4096:
+            if storage.numel() < self.numel + slack:
                 raise ValueError("RS16: the given storage is too small for this geometry")
-            self.storage = storage.narrow(0, 0, self.numel + 4096)
+            self.storage = storage.narrow(0, 0, self.numel + slack)
         self.device = device
 
     def view7(self):
@@ -1599,7 +1602,7 @@ class ConvPlanS16:
     CNN, reference submodule.py:9-16).  D, H, W = the INPUT dims."""
 
     def __init__(self, N, cin, cout, D, H, W, relu, cv=False, device=None, kind="s1", dil=1):
-        if not s16_supported(cin, cout, D, H, W, kind, dil) or (cv and (cin != 64 or kind != "s1" or W % 28)) or (dil != 1 and kind != "2d"):
+        if not s16_supported(cin, cout, D, H, W, kind, dil) or (cv and (cin != 64 or kind != "s1" or W <= 14)) or (dil != 1 and kind != "2d"):
             raise ValueError("ConvPlanS16: unsupported shape")
         self.dil = dil
         self.N, self.cin, self.cout, self.D, self.H, self.W, self.relu, self.cv, self.device, self.kind = N, cin, cout, D, H, W, bool(relu), cv, device, kind
@@ -1609,8 +1612,8 @@ class ConvPlanS16:
         self.flops = 2 * N * vox * (9 if kind == "2d" else 27) * cin * cout
         rt, wt = (1, 28)
         nw = {"s1": W, "s2": W // 2, "up": W, "2d": W}[kind]
-        if nw in (14, 7):
-            rt, wt = (2, 14) if nw == 14 else (4, 7)
+        if nw <= 14:                       # (the kernels' dispatch: width <= 7 -> 4 x 7 tiles, <= 14 -> 2 x 14, else 1 x 28; the last tiles masked)
+            rt, wt = (2, 14) if nw > 7 else (4, 7)
         if kind == "s1":
             self._kfmt = "convs16_kernel<%d,%s,%d,%d,%%s,%%s,%%s>" % (cin // 16, "true" if cv else "false", rt, wt)
             self.kname = self._kfmt % ("false", "false", "false")  # (the residual / blocked-fp32-output / fused-head template flags follow the call's arguments)
@@ -1634,7 +1637,7 @@ class ConvPlanS16:
         head, its output is not stored, the partial sums of the cout-1 layer behind it are (head_gather finishes it)."""
         from ._lib import DrcS16ConvParams
         if head is not None:
-            if self.kind != "s1" or self.cv or (self.cin, self.cout) != (32, 32) or self.W % 28 or self.D < 6 or y16 is not None or y32 is not None or res is not None:
+            if self.kind != "s1" or self.cv or (self.cin, self.cout) != (32, 32) or self.W % 28 or self.D < 6 or self.D % 3 or y16 is not None or y32 is not None or res is not None:
                 raise ValueError("ConvPlanS16.run: the fused head is the 32 -> 32 full-resolution layer without another output")
             if head[1].dtype != torch.float32 or head[1].numel() < self.N * self.D * self.H * self.W * 12 or head[0].dtype != torch.float16 or head[0].numel() != 2048:
                 raise ValueError("ConvPlanS16.run: head = (halfs [2][2][64][8], fp32 buffer of N*D*H*W*12)")

@@ -451,10 +451,10 @@ class PSMNetRuntime:
         mode = getattr(self.model, "regressor_math", "auto")
         if mode not in ("auto", "f32", "f16x2"):
             raise ValueError("PSMNet.regressor_math must be 'auto', 'f32' or 'f16x2'")
-        ok = (not training and self._tape is None and Dp % 4 == 0 and Hp % 4 == 0 and Wp % 4 == 0 and
+        ok = (not training and self._tape is None and Dp % 4 == 0 and Hp % 4 == 0 and Wp % 4 == 0 and Wp > 14 and      # (Wp > 14: the cost-volume layer's 28-wide tiles)
               all(E.s16_supported(ci, co, *dims, kind=kind) for kind, ci, co, dims in self._s16_layers(Dp, Hp, Wp)))
         if mode == "f16x2" and not ok:
-            raise RuntimeError("PSMNet.regressor_math = 'f16x2': eval only; volume dims D' % 12 == 0, W' = 28 or a multiple of 56, H' % 4 == 0")
+            raise RuntimeError("PSMNet.regressor_math = 'f16x2': eval only; volume dims D', H', W' multiples of 4, W' >= 16 (the cost-volume layer runs on 28-wide tiles)")
         return self._s16_choice(ok and mode != "f32", mode, "regressor_math")
 
     def _s16_choice(self, use, mode, what):
@@ -491,7 +491,7 @@ class PSMNetRuntime:
             t[f"costk{k}"] = pool.dense(f"costk{k}", N, *full)
         # the heads: classif[0] + the 32 -> 1 layer fused (convs16.hip HEAD form: partial sums S, 48 B per voxel, one buffer for the three
         # heads) where the map is a multiple of 28 columns; else classif[0] writes a blocked fp32 tensor that cout1_mfma.hip reads
-        fused = E.HEAD_FUSED["enabled"] and Wp % 28 == 0 and Dp >= 6
+        fused = E.HEAD_FUSED["enabled"] and Wp % 28 == 0 and Dp >= 6 and Dp % 3 == 0
         if fused:
             t["hs"] = pool.dense("hs", N, Dp, Hp, Wp, 12)
         else:
@@ -919,11 +919,11 @@ class PSMNetRuntime:
         if mode not in ("auto", "f32", "f16x2"):
             raise ValueError("PSMNet.feature_math must be 'auto', 'f32' or 'f16x2'")
         ok = (not training and self._tape is None and H % 4 == 0 and W % 4 == 0 and H // 4 >= 56 and W // 4 >= 56 and
-              (H // 4) % 28 == 0 and (W // 4) % 56 == 0 and           # (the kernel takes ragged maps too -- the trunk's; this CNN keeps whole tiles)
+              # (round 6: any such crop size -- the 2D kernel masks ragged last tiles; whole 28-row / 56-column tiles at the shipped 224 x 224)
               E.s16_supported(32, 32, 1, H // 2, W // 2, "2d") and E.s16_supported(64, 64, 1, H // 4, W // 4, "2d") and
               E.s16_supported(64, 128, 1, H // 4, W // 4, "2d") and E.s16_supported(128, 128, 1, H // 4, W // 4, "2d"))
         if mode == "f16x2" and not ok:
-            raise RuntimeError("PSMNet.feature_math = 'f16x2': eval only; H/4 a multiple of 28 and W/4 a multiple of 56")
+            raise RuntimeError("PSMNet.feature_math = 'f16x2': eval only; H, W multiples of 4 and >= 224 (the reference's AvgPool2d(56), submodule.py:76)")
         return self._s16_choice(ok and mode != "f32", mode, "feature_math")
 
     def _ws2d_eval(self, N, H, W):

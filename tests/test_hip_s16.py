@@ -87,6 +87,17 @@ CASES = [
     (2, 64, 32, 12, 28, 28, True, False, True, -6, 1.0),
     (2, 64, 32, 6, 28, 28, False, False, True, 3, 1.0),
     (1, 64, 32, 24, 56, 56, True, False, True, -12, 1.0),
+    # round 6: shapes beyond BASELINE's (VERDICT r5 missing #2; the reference takes any D, H, W = 0 mod 4 here, stackhourglass.py:115-128):
+    # depths that are not multiples of 3 (phantom zero planes behind the last one), widths that mask their last 28-wide tile, odd row counts
+    (2, 32, 32, 4, 8, 32, True, False, False, 0, 1.0),
+    (2, 32, 32, 8, 7, 16, False, True, False, 0, 1.0),
+    (9, 32, 32, 16, 5, 40, True, True, False, 0, 1.0),
+    (2, 32, 32, 1, 3, 20, True, False, False, 0, 1.0),
+    (2, 32, 32, 2, 4, 64, False, False, False, 0, 1.0),
+    (2, 64, 64, 20, 6, 36, True, True, False, 0, 1.0),
+    (2, 64, 32, 8, 32, 32, True, False, True, 0, 1.0),
+    (2, 64, 32, 16, 12, 40, True, False, True, -8, 1.0),
+    (3, 64, 32, 4, 16, 16, False, False, True, 2, 1.0),
 ]
 
 
@@ -123,7 +134,7 @@ def test_conv3d_s16_vs_fp64_next_to_the_fp32_chain(dev, N, cin, cout, D, H, W, r
     else:
         x16 = E.RS16(N, cin, D, H, W, 1, dev).from_dense(x.to(dev))
         plan.run(x16, wp, sc, shift.to(dev), y16=y16, res=r16)
-        if cin == 32 and not with_res and W % 28 == 0:
+        if cin == 32 and not with_res and W > 14:
             # the blocked fp32 output form (the cout-1 head's input): instead of RS16
             y32 = E.Blocked(N, cout, D, H, W, 1, 1, 1, dev)
             plan.run(x16, wp, sc, shift.to(dev), y32=y32)
@@ -207,6 +218,20 @@ def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed, lo4=0):
     ("up", 2, 64, 64, 6, 14, 14, True, False),       # hourglass conv5, Config B
     ("up", 2, 64, 64, 1, 3, 7, False, False),
     ("up", 2, 64, 32, 2, 5, 56, True, True),
+    # round 6: masked last tiles / any depth
+    ("s1", 3, 64, 64, 4, 8, 8, True, True),          # 2 x 14 tiles, 8 of 14 columns
+    ("s1", 3, 64, 64, 2, 4, 4, True, False),         # 4 x 7 tiles, 4 of 7 columns, two phantom planes... (D = 2 -> walk of 3)
+    ("s1", 2, 32, 32, 5, 9, 12, False, True),
+    ("s1", 2, 64, 64, 10, 16, 16, True, True),       # 1 x 28 tiles, 16 of 28 columns
+    ("s2", 3, 32, 64, 8, 16, 32, True, False),       # -> 4 x 8 x 16 (cout split, 1 x 28 tile masked)
+    ("s2", 3, 64, 64, 4, 8, 16, True, False),        # -> 2 x 4 x 8 (2 x 14 tile masked)
+    ("s2", 2, 64, 64, 2, 6, 8, True, False),         # -> 1 x 3 x 4 (4 x 7 tile masked)
+    ("s2", 2, 32, 64, 16, 20, 40, True, False),      # -> 8 x 10 x 20
+    ("s2", 2, 32, 32, 4, 10, 72, False, False),      # -> 36 wide: 28 + 8
+    ("up", 3, 64, 64, 2, 4, 4, True, True),          # -> 4 x 8 x 8
+    ("up", 3, 64, 32, 4, 8, 8, False, True),         # -> 8 x 16 x 16
+    ("up", 2, 64, 32, 8, 10, 20, False, True),       # -> 16 x 20 x 40
+    ("up", 2, 64, 64, 3, 5, 36, True, False),
 ])
 def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, cout, D, H, W, relu, with_res):
     _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
@@ -476,18 +501,42 @@ def test_lastconv_as_chained_split_f16_launches(dev):
 def test_feature_math_validation(dev):
     from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
     m = PSMNet(48, -48).to(dev).eval()
-    left, right = synth.synth_images(1, 256, 256, tag="v2d")             # 64 x 64 maps: not a multiple of 28
+    left, right = synth.synth_images(1, 224, 224, tag="v2d")
     m.feature_math = "bf16"
     with pytest.raises(ValueError):
         m((left.to(dev), right.to(dev)))
     m.feature_math = "f16x2"
-    with pytest.raises(RuntimeError):
+    left, right = synth.synth_images(1, 220, 224, tag="v2e")             # below the reference's own minimum (fixed AvgPool2d(56), submodule.py:76)
+    with pytest.raises((RuntimeError, ValueError)):
         m((left.to(dev), right.to(dev)))
-    m.feature_math = "auto"                                              # falls back to the fp32 kernels
-    with torch.no_grad():
-        out = m((left.to(dev), right.to(dev)))
-    assert out.shape == (1, 256, 256) and torch.isfinite(out).all()
-    assert "2d" in [k[0] for k in m._rt._ws]
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (224, 320)])
+def test_full_psmnet_other_crop_sizes_f16x2_vs_f32_path(dev, H, W):
+    """Round 6: the split-f16 2D CNN and regressor on crops beyond 224 x 224 (64 x 64 and 56 x 80 feature maps: ragged last tiles in the 2D
+    kernel, masked last tiles / phantom planes in the 3D ones) against the all-fp32 HIP path: features to fp32 rounding, disparities at the
+    bounds of the 224 x 224 test."""
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    sd = state_for("B")
+    left, right = synth.synth_images(2, H, W, tag=f"crop{H}x{W}")
+    outs, feats = {}, {}
+    for math in ("f16x2", "f32"):
+        m = PSMNet(48, -48)
+        m.load_state_dict(sd, strict=True)
+        m.feature_math = m.regressor_math = math
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            outs[math] = m((left.to(dev), right.to(dev))).cpu()
+        keys = [k[0] for k in m._rt._ws]
+        assert ("2ds16" in keys and "3ds16" in keys) == (math == "f16x2"), keys
+        feats[math] = m._rt._ws[("2ds16" if math == "f16x2" else "2d", 4, H, W)]["t"]["feat"].to_dense().cpu()
+    fd = (feats["f16x2"] - feats["f32"]).abs().max().item()
+    fm = feats["f32"].abs().max().item()
+    d = (outs["f16x2"] - outs["f32"]).abs()
+    print(f"{H}x{W}: features max diff {fd:.3e} (max {fm:.3f}); disparity: mean {d.mean().item():.3e} max {d.max().item():.3e} px")
+    assert outs["f16x2"].shape == (2, H, W)
+    assert fd <= 1e-4 * max(1.0, fm)
+    assert d.mean().item() < 1e-3 and d.max().item() < 2e-2
 
 
 def test_conv3d_s16_small_activations_keep_an_absolute_error_floor(dev):
@@ -535,6 +584,38 @@ def test_deconv_direct_writes_rs16_identical_to_its_fp32_output(dev):
     assert torch.equal(s_only.view7().cpu(), want)
 
 
+@pytest.mark.parametrize("mx,mn,N,Hp,Wp", [(64, 0, 3, 32, 32), (16, -16, 2, 20, 40), (32, 0, 2, 16, 64), (80, 0, 2, 28, 28)])
+def test_regressor_f16x2_other_volume_shapes_vs_f32_path_and_oracle(dev, mx, mn, N, Hp, Wp):
+    """VERDICT r5 missing #2: the reference takes any D, H, W = 0 mod 16 (stackhourglass.py:115-174); the split-f16 schedule now takes every
+    such volume of at least 16 columns (masked last tiles, phantom depth planes; the heads fall back to the stand-alone cout-1 kernel where the
+    fused form's shape rule does not hold).  128 x 128 / 64 disparities, 80 x 160 / 32, 64 x 256 / 32, 112 x 112 / 80: against the fp32 HIP path and
+    the CPU oracle at the bounds of test_hip_parity.py."""
+    from disprcnn_amd.modeling.psmnet.stackhourglass import PSMNet
+    sd = state_for("A")
+    fl, fr = synth.synth_features(N, 32, Hp, Wp, tag=f"shape_{Hp}_{Wp}")
+    outs = {}
+    for math in ("f16x2", "f32"):
+        m = PSMNet(mx, mn)
+        m.load_state_dict(sd, strict=True)
+        m.regressor_math = math
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            outs[math] = m.forward_from_features(fl.to(dev), fr.to(dev), (4 * Hp, 4 * Wp)).cpu()
+        keys = [k[0] for k in m._rt._ws]
+        assert ("3ds16" in keys) == (math == "f16x2"), keys
+        if math == "f16x2":
+            assert m._rt._guard.policy.overflows == 0
+    with torch.no_grad():
+        ref = O.psmnet_from_features(sd, fl, fr, mx, mn, 4 * Hp, 4 * Wp)
+    for math, got in outs.items():
+        err = (got - ref).abs()
+        print(f"{math} D'={(mx - mn) // 4} {Hp}x{Wp}: mean/max err px vs oracle {err.mean().item():.3e} {err.max().item():.3e}")
+        assert err.mean().item() < 1e-3 and err.max().item() < 2e-2
+    d = (outs["f16x2"] - outs["f32"]).abs()
+    print(f"f16x2 vs f32 HIP paths: mean {d.mean().item():.3e} max {d.max().item():.3e} px")
+    assert d.max().item() < 3e-3 and d.mean().item() < 1e-4          # two fp32-class paths (measured 1.2e-3 max at 64 / 80 disparities: the soft-argmin's range scales it)
+
+
 @pytest.mark.parametrize("mx,mn,N", [(48, 0, 16), (24, -24, 5), (48, 0, 1)])
 def test_regressor_f16x2_vs_f32_path_and_oracle(dev, mx, mn, N):
     """Config A from the feature boundary: the default (split-f16) path against the all-fp32-MFMA path of rounds 1-4 and against the CPU
@@ -571,10 +652,10 @@ def test_regressor_math_validation(dev):
     with pytest.raises(ValueError):
         m.forward_from_features(fl.to(dev), fr.to(dev), (112, 112))
     m.regressor_math = "f16x2"
-    fl, fr = synth.synth_features(2, 32, 16, 16, tag="v2")          # 16-wide maps: not a shape the split-f16 kernel takes
+    fl, fr = synth.synth_features(2, 32, 12, 12, tag="v2")          # 12-wide maps: below the cost-volume layer's 28-wide tiles
     with pytest.raises(RuntimeError):
-        m.forward_from_features(fl.to(dev), fr.to(dev), (64, 64))
+        m.forward_from_features(fl.to(dev), fr.to(dev), (48, 48))
     m.regressor_math = "auto"                                      # ... "auto" falls back to the fp32 kernels
     with torch.no_grad():
-        out = m.forward_from_features(fl.to(dev), fr.to(dev), (64, 64))
-    assert out.shape == (2, 64, 64) and torch.isfinite(out).all()
+        out = m.forward_from_features(fl.to(dev), fr.to(dev), (48, 48))
+    assert out.shape == (2, 48, 48) and torch.isfinite(out).all() and "3ds16" not in [k[0] for k in m._rt._ws]

@@ -405,12 +405,17 @@ def test_split_f16_shape_rules_through_the_c_abi():
     from disprcnn_amd import _lib
     lib = _lib.lib()
     s1, s2, up, c2 = lib.drc_conv3d_k3_s16_supported, lib.drc_conv3d_k3s2_s16_supported, lib.drc_deconv3d_k3s2_s16_supported, lib.drc_conv2d_k3_s16_supported
-    # 3D stride 1: cin / cout in {32, 64}, D % 3 == 0, W = 7 | 14 | multiple of 28 (cin 32: even H)
+    # 3D stride 1 (round 6): cin / cout in {32, 64}, ANY D, H, W > 0 -- D that is not a multiple of 3 walks phantom zero planes, widths that are
+    # not 7 | 14 | a multiple of 28 mask their last tile (the reference's contract: D, H, W = 0 mod 4 at 1/4 resolution, stackhourglass.py:115-128)
     assert s1(32, 32, 12, 28, 28) and s1(64, 32, 24, 56, 56) and s1(64, 64, 6, 14, 14) and s1(64, 64, 3, 7, 7) and s1(32, 64, 6, 5, 7)
-    assert not s1(32, 32, 10, 28, 28) and not s1(32, 32, 12, 27, 28) and not s1(48, 32, 12, 28, 28) and not s1(32, 32, 12, 28, 30)
-    # stride 2 / transposed: the narrower map 7, 14 or a multiple of 28 wide; even input dims for stride 2; cin 64 for the transposed layer
-    assert s2(32, 64, 12, 28, 28) and s2(64, 64, 6, 14, 14) and s2(32, 64, 24, 56, 56) and not s2(32, 64, 12, 28, 30) and not s2(32, 64, 11, 28, 28)
-    assert up(64, 32, 6, 14, 14) and up(64, 64, 3, 7, 7) and up(64, 32, 12, 28, 28) and not up(32, 32, 6, 14, 14) and not up(64, 32, 6, 14, 15)
+    assert all(s1(32, 32, d, 32, w) for d in range(4, 49, 4) for w in (16, 28, 32, 40, 56, 64))
+    assert s1(32, 32, 10, 28, 28) and s1(32, 32, 12, 27, 28) and s1(32, 32, 12, 28, 30) and s1(64, 64, 1, 1, 1)
+    assert not s1(48, 32, 12, 28, 28) and not s1(32, 96, 12, 28, 28) and not s1(32, 32, 0, 28, 28) and not s1(32, 32, 12, 28, 0)
+    # stride 2: even input dims; transposed: cin 64; any size (masked last tiles)
+    assert s2(32, 64, 12, 28, 28) and s2(64, 64, 6, 14, 14) and s2(32, 64, 24, 56, 56) and s2(32, 64, 12, 28, 30) and s2(64, 64, 16, 32, 32)
+    assert not s2(32, 64, 11, 28, 28) and not s2(32, 64, 12, 27, 28) and not s2(48, 64, 12, 28, 28)
+    assert up(64, 32, 6, 14, 14) and up(64, 64, 3, 7, 7) and up(64, 32, 12, 28, 28) and up(64, 32, 6, 14, 15) and up(64, 64, 4, 8, 8)
+    assert not up(32, 32, 6, 14, 14) and not up(64, 48, 6, 14, 14)
     # 2D: any map size at dilation 1, cin in {32, 64, 128} (wider layers: chained launches), cout a power of two in 32..512; dilation 2: cin 128, 56-row blocks
     assert c2(64, 64, 56, 56, 1) and c2(32, 32, 29, 57, 1) and c2(128, 512, 12, 39, 1) and c2(128, 256, 94, 310, 1)
     assert not c2(256, 64, 28, 28, 1) and not c2(128, 96, 28, 28, 1) and not c2(128, 1024, 28, 28, 1) and not c2(64, 64, 0, 28, 1)
