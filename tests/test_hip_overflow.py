@@ -69,7 +69,7 @@ def _run_layer(dev, kind, N, cin, cout, D, H, W, relu, boost, form="y16", with_r
     """One launch of a kernel family on O(1) inputs with the epilogue scale multiplied by `boost`; -> (guard tripped, max |pre-clamp value|
     of the map according to an fp32 torch convolution)."""
     import torch.nn.functional as F
-    g = torch.Generator().manual_seed(hash((kind, N, cin, cout, D, H, W, form)) % 997)
+    g = torch.Generator().manual_seed(("s1", "cv", "s2", "up", "2d").index(kind) * 101 + N + cin + 3 * cout + 7 * D + 11 * H + 13 * W + len(form))
     if kind == "2d":
         x = torch.randn(N, cin, H, W, generator=g)
         w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
@@ -151,7 +151,11 @@ def test_conv_kernels_report_exactly_when_the_map_leaves_the_range(dev, kind, N,
     assert not hit and m1 < 100.0, (hit, m1)                          # O(1) activations: silent (also: over-read idle lanes / planes do not report)
     # a boost that puts the largest value just INSIDE the range, then one just outside
     inside = 0.9 * 65504.0 / m1
-    hit, m = _run_layer(dev, kind, N, cin, cout, D, H, W, relu, inside, form, with_res)
+    for _ in range(4):                          # (shift and residual do not scale with the boost: settle on a boost whose maximum is ~0.9 of the limit)
+        hit, m = _run_layer(dev, kind, N, cin, cout, D, H, W, relu, inside, form, with_res)
+        if 0.8 * 65504.0 < m < 0.97 * 65504.0:
+            break
+        inside *= 0.9 * 65504.0 / m
     assert not hit and m < 65504.0, (hit, m)
     hit, m = _run_layer(dev, kind, N, cin, cout, D, H, W, relu, inside * 1.5, form, with_res)
     assert hit and m > 65504.0, (hit, m)

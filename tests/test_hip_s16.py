@@ -234,7 +234,7 @@ def _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed, lo4=0):
     ("up", 2, 64, 64, 3, 5, 36, True, False),
 ])
 def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, cout, D, H, W, relu, with_res):
-    _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000)
+    _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=("s1", "s2", "up").index(kind) * 331 + N + cin + 3 * cout + 7 * D + 11 * H + 13 * W)
 
 
 @pytest.mark.parametrize("N,D,H,W,with_prev", [
@@ -330,7 +330,7 @@ def test_fused_head_validation(dev):
     ("up", 3, 64, 64, 3, 7, 7, True, True, 0x100), ("up", 3, 64, 32, 6, 14, 14, False, True, 0x100),
 ])
 def test_hourglass_layers_s16_experiment_forms(dev, kind, N, cin, cout, D, H, W, relu, with_res, lo4):
-    _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=hash((kind, N, cin, cout, D, H, W)) % 1000, lo4=lo4)
+    _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=("s1", "s2", "up").index(kind) * 331 + N + cin + 3 * cout + 7 * D + 11 * H + 13 * W, lo4=lo4)
 
 
 @pytest.mark.parametrize("N,cin,cout,H,W,relu,with_res,form", [
