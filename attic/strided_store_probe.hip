@@ -2,7 +2,7 @@
 // DIFFERENT waves) cost HBM bandwidth against contiguous 16-B-per-lane accesses?  Copy kernel: each workgroup streams a private 56 KB region
 // per step (read 28 KB "residual", write 28 KB "output"), 4 waves.  mode 0: lane l of wave w moves bytes [w][l*16 ..] contiguous (1 KB per
 // instruction).  mode 1: wave w moves the even (w & 1 == 0) or odd 16-byte slots of a 2 KB span: the same bytes per instruction, half-dense.
-//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/exp_libs/libprobe.so tools/experiments/strided_store_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/exp_libs/libprobe.so attic/strided_store_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

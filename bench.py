@@ -576,7 +576,7 @@ def rank0_extras(dev, extra):
         with torch.no_grad():
             fn()
         torch.cuda.synchronize()
-        is2d = lambda k: k.startswith(("convs16r", "wino2d", "conv2d", "pointwise", "stemconv", "tap2d"))      # noqa: E731 -- (convs16r: the split-f16 2D kernel)
+        is2d = lambda k: k.startswith(("convs16r", "wino2d", "conv2d", "pointwise", "stemconv"))      # noqa: E731 -- (convs16r: the split-f16 2D kernel)
         reg = [(f, a.elapsed_time(b) * 1e-3) for k, f, a, b in E.TIMING
                if not is2d(k) and k.startswith(("convs16", "conv16", "wino3d", "tapdirect", "downdirect_kernel<7", "downdirect_kernel<4", "deconv"))]
         cnn = [(f, a.elapsed_time(b) * 1e-3) for k, f, a, b in E.TIMING if is2d(k)]

@@ -88,11 +88,9 @@ _SIGS = {
     "drc_dense_to_blocked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_blocked_to_dense": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_tapconv_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
-    "drc_tapconv3d_slide_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_tapconv3d_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_deconv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
     "drc_deconv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
-    "drc_conv3d_k3s2_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3s2_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_k3_wino_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_linear_scratch_floats": (C.c_int64, [_I, _I, _I]),
@@ -116,7 +114,6 @@ _SIGS = {
     "drc_pack_weights_wino2d": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_pack_weights_wino": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "drc_conv2d_k1_fwd": (_I, [C.POINTER(DrcTapconvParams), _P]),
-    "drc_conv2d_k3_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv2d_k3_direct_fwd": (_I, [C.POINTER(DrcTapconvParams), _I, _P]),
     "drc_conv3d_cout1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "drc_upsample_softargmin_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -16,7 +16,7 @@ SLACK_FLOATS = 1 << 16          # over-read room behind every blocked tensor (ra
 LDS_PER_WAVE_MAX = 38 * 1024    # 4 waves/block -> 152 KiB of the 160 KiB LDS
 MAX_SLOTS = 112                 # 7 voxel tiles of 16
 TIMING = None                   # bench.py sets this to a list to collect (kernel name, flops, start_evt, end_evt)
-SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1, "min_units": 700, "min_units_ct1": 150}   # sliding-depth-window kernel for stride-1 3x3x3 convs (tapslide.hip)
+SLIDE = {"enabled": True, "max_slots": 112, "ct": 2, "min_od": 3, "min_share": 1, "min_units": 700, "min_units_ct1": 150}   # sliding-depth-window plans for stride-1 3x3x3 convs (tapdirect.hip and the Winograd kernels; thresholds measured with tools/experiments/exp_conv.py)
 
 
 def _stream_ptr(device):
@@ -504,7 +504,6 @@ class ConvPlan:
         self.fused_deconv = False
         self.down = False
         self.pointwise = False
-        self.tap2d = False
         self.direct = False
         self.wino = False
         self.rb = False            # wino3d_rb.hip (two waves per SIMD, row brick) instead of wino3d.hip
@@ -543,7 +542,7 @@ class ConvPlan:
         CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
         while CT > 1 and (groups * (ct // CT) < 2048 or nvt * CT > 16):      # mirrors drc_tapconv_fwd's choice
             CT //= 2
-        self.kname = "tapconv_kernel<%d,%d>" % (nvt, CT)
+        self.kname = self._generic_kname = "tapconv_kernel<%d,%d>" % (nvt, CT)
         if slide:
             # the sliding-window kernel gives every resident wave an equal share (>= 3 output slices) of the
             # (cout group, column, slice) units: use it only when that still yields enough waves to fill the 1024 SIMDs
@@ -641,12 +640,6 @@ class ConvPlan:
         elif self.pointwise:
             st = _lib.lib().drc_conv2d_k1_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_conv2d_k1_fwd")
-        elif self.tap2d:
-            st = _lib.lib().drc_conv2d_k3_fwd(C.byref(p), self.tap2d_ct, _stream_ptr(self.device))
-            _lib.check(st, "drc_conv2d_k3_fwd")
-        elif self.down:
-            st = _lib.lib().drc_conv3d_k3s2_fwd(C.byref(p), self.down_ct, _stream_ptr(self.device))
-            _lib.check(st, "drc_conv3d_k3s2_fwd")
         elif self.deconv_direct and y16 is not None:
             st = _lib.lib().drc_deconv3d_k3s2_direct_s16_fwd(C.byref(p), _ptr(y16.storage), _ovf_ptr(), _stream_ptr(self.device))
             _lib.check(st, "drc_deconv3d_k3s2_direct_s16_fwd")
@@ -656,9 +649,6 @@ class ConvPlan:
         elif self.fused_deconv:
             st = _lib.lib().drc_deconv3d_k3s2_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_deconv3d_k3s2_fwd")
-        elif self.slide:
-            st = _lib.lib().drc_tapconv3d_slide_fwd(C.byref(p), self.slide_ct, _stream_ptr(self.device))
-            _lib.check(st, "drc_tapconv3d_slide_fwd")
         else:
             st = _lib.lib().drc_tapconv_fwd(C.byref(p), _stream_ptr(self.device))
             _lib.check(st, "drc_tapconv_fwd")
@@ -730,7 +720,7 @@ WINO2D = {"enabled": True,    # the same for Conv2d 3x3 stride 1 on even maps (w
           "min_chunks": 4}    # ... with at least this many rounds-of-four tile groups per cout group (else the direct kernel;
                               #     measured on the R-50-FPN trunk: 64 and 16 give 2.02 ms of 3x3 convs per pair, 4 gives 1.76)
 CONV2D_FILL = {"enabled": True}   # 3x3 Conv2d tile choice: trade MFMA padding for waves when a layer cannot fill the 1024 SIMDs
-DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip) instead of the LDS-staged tapslide / tapdown / tap2d
+DIRECT = {"enabled": True}    # LDS-free kernels (tapdirect.hip, downdirect.hip, conv2ddirect) and the Winograd kernels built on their plans; False: the generic kernel (tapconv.hip) for every layer
 DOWN = {"enabled": True, "tile": None,     # stride-2 Conv3d kernels; "tile" = development override (tools/experiments/exp_conv.py)
         "min_groups": 700}                 # cout tiles per wave grow while >= ~0.7 groups per SIMD remain (measured)
 
@@ -785,10 +775,12 @@ def plan_conv3d(x, y, stride, cout, relu):
             # odd maps (no Winograd) at small batch: the direct kernel with one cout tile per wave
             pl.slide, pl.direct, pl.slide_ct = True, True, 1
             pl.kname = "tapdirect_kernel<%d,1>" % (-(-(pl.p.R * pl.p.WT) // 16))
-    elif pl.slide and (pl.p.R + 2) * (-(-(2 * (pl.p.WT + 2)) // 64)) > 18:
-        pl.slide = False                     # the LDS-staged kernel stages at most two pieces per tap step: tall narrow tiles go generic
-        pl.kname = pl.kname.replace("tapslide", "tapconv")
-    if stride == 2 and DOWN["enabled"]:
+    elif pl.slide:
+        # DIRECT off: the generic kernel (tapconv.hip).  (Rounds 1-2 had an LDS-staged sliding-window kernel here -- tapslide.hip -- which no
+        # default plan selected any more; it left the library in round 6, attic/.)
+        pl.slide = False
+        pl.kname = pl._generic_kname
+    if stride == 2 and DOWN["enabled"] and DIRECT["enabled"] and DIRECT.get("down", True):      # (else: the generic kernel)
         pl.down = True
         pl.p.R, pl.p.WT = choose_tile_down(y.H, y.W)
         nvt = -(-(pl.p.R * pl.p.WT) // 16)
@@ -798,10 +790,8 @@ def plan_conv3d(x, y, stride, cout, relu):
         while CT > 1 and (nvt * CT > 28 or tiles * (ct // CT) < DOWN["min_groups"]):
             CT //= 2
         pl.down_ct = CT
-        pl.kname = "tapdown_kernel<%d,%d>" % (nvt, CT)
-        if DIRECT["enabled"] and DIRECT.get("down", True):
-            pl.direct = True
-            pl.kname = "downdirect_kernel<%d,%d>" % (nvt, CT)
+        pl.direct = True
+        pl.kname = "downdirect_kernel<%d,%d>" % (nvt, CT)
     return pl
 
 
@@ -851,28 +841,6 @@ def plan_deconv3d(x, y, cout, relu):
     return pl
 
 
-TAP2D = {"enabled": True, "tile": None}     # LDS-staged 3x3 stride-1 Conv2d kernel (tap2d.hip), used when DIRECT is off
-
-
-def choose_tile_2d(OH, OW, dil):
-    """Output tile (R, WT) of the 3x3 Conv2d kernel: least MFMA padding, then the largest tile, then the widest rows; the
-    (R+2d) x (WT+2d) input tile must fit 18 LDS-DMA pieces."""
-    if TAP2D["tile"]:
-        return TAP2D["tile"]
-    best = None
-    for r in range(1, min(OH, MAX_SLOTS) + 1):
-        for wt in range(1, min(OW, MAX_SLOTS // r) + 1):
-            if -(-((r + 2 * dil) * (wt + 2 * dil) * 2) // 64) > 18:
-                continue
-            nvt = -(-(r * wt) // 16)
-            waste = (-(-OH // r)) * (-(-OW // wt)) * nvt * 16 / (OH * OW)
-            halo = (r + 2 * dil) * (wt + 2 * dil) / (r * wt)          # staged voxels per output voxel
-            key = (-round(waste + 0.15 * halo, 1), r * wt, wt)
-            if best is None or key > best[0]:
-                best = (key, r, wt)
-    return (best[1], best[2]) if best else None
-
-
 def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
     """Conv2d(k,stride,pad,dilation) on blocked 2D tensors (D=1, pd=0)."""
     assert x.pd == 0 and x.D == 1
@@ -919,19 +887,6 @@ def plan_conv2d(x, y, k, stride, pad, dilation, cout, relu):
                     and _lib.lib().drc_conv2d_k3_wino_rb_supported(pl.p.cout_pad, y.H, y.W)):
                 pl.rb = True
                 pl.kname = "wino2d_rb_kernel<%d>" % (7 if y.W == 14 else 14)
-    elif k == 3 and stride == 1 and pad == dilation and TAP2D["enabled"]:
-        tile = choose_tile_2d(y.H, y.W, dilation)
-        if tile is not None:
-            pl.tap2d = True
-            pl.p.R, pl.p.WT = tile
-            nvt = -(-(tile[0] * tile[1]) // 16)
-            ct = pl.p.cout_pad // 16
-            tiles = x.N * (-(-y.H // tile[0])) * (-(-y.W // tile[1]))
-            CT = 4 if ct % 4 == 0 else (2 if ct % 2 == 0 else 1)
-            while CT > 1 and (nvt * CT > 20 or tiles * (ct // CT) < 2048):      # no spills; keep >= 2 groups per SIMD
-                CT //= 2
-            pl.tap2d_ct = CT
-            pl.kname = "tap2d_kernel<%d,%d>" % (nvt, CT)
     if k == 1 and POINTWISE["enabled"]:
         pl.pointwise = True
         ct = pl.p.cout_pad // 16

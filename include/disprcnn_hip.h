@@ -114,16 +114,12 @@ typedef struct drc_tapconv_params {
 /* Validates, picks the (voxel-tiles, cout-tiles) instantiation and launches. */
 int drc_tapconv_fwd(const drc_tapconv_params* p, void* stream);
 
-/* Same operation as drc_tapconv_fwd for the stride-1 3x3x3 class only (one class, nd=nh=nw=3, unit spacing,
- * in_mul=out_mul=1), executed with a sliding depth window: a wave owns R x WT voxels of ALL depth slices of a ROI and
- * applies every staged input tile to the three output slices it touches (3x fewer staged bytes per MFMA).
- * lds_bytes_per_wave >= 2*(R+2)*(WT+2)*32.  cout_tiles_per_wave in {1,2} must divide cout_pad/16. */
-int drc_tapconv3d_slide_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
-
-/* The same stride-1 3x3x3 convolution with the same sliding depth window, but with both MFMA operands read straight from
- * global memory (no LDS): the B fragment of tap (kh,kw) is one coalesced float4 per lane (16 channels = four MFMA k-steps).
- * Weights are packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16), NOT in the tap layout of drc_tapconv_fwd;
- * R, WT as for drc_tapconv3d_slide_fwd (lds_bytes_per_wave is ignored). */
+/* The stride-1 3x3x3 class (one class, nd=nh=nw=3, unit spacing, in_mul=out_mul=1) with a sliding depth window -- a wave owns R x WT
+ * voxels of ALL depth slices of a unit and applies every input slice to the three output slices it touches -- and both MFMA operands read
+ * straight from global memory (no LDS): the B fragment of tap (kh,kw) is one coalesced float4 per lane (16 channels = four MFMA k-steps).
+ * Weights are packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16), NOT in the tap layout of drc_tapconv_fwd; cout_tiles_per_wave in
+ * {1,2} must divide cout_pad/16; lds_bytes_per_wave is ignored.  (The LDS-staged predecessors of this and of the two kernels below --
+ * tapslide.hip, tapdown.hip, tap2d.hip, rounds 1-2 -- left the library in round 6: no default plan selected them; attic/.) */
 int drc_tapconv3d_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
 /* ConvTranspose3d(k3, s2, p1, op1) (+BN, +residual, +ReLU) -- hourglass.conv5/conv6 (stackhourglass.py:22-30) and the data
@@ -134,15 +130,10 @@ int drc_tapconv3d_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wav
  * Needs R*WT <= 112 and ceil((R+1)*(WT+1)*2/64) <= 9.  Results equal drc_tapconv_fwd's up to the fp32 summation order. */
 int drc_deconv3d_k3s2_fwd(const drc_tapconv_params* p, void* stream);
 
-/* Conv3d(k3, stride 2, pad 1) (+BN, +residual, +ReLU) -- hourglass.conv1/conv3 (stackhourglass.py:9-16) and the data gradient
- * of the transposed convolutions -- on parity-split LDS tiles: per phase the four (row parity, column parity) planes of the
- * needed input rows are staged as dense unit-stride tiles, so every tap is a conflict-free B fragment.  Takes the parameter
- * block of drc_tapconv_fwd for the single 3x3x3 class with in_mul = 2.  cout_tiles_per_wave in {1,2,4} must divide
- * cout_pad/16; ceil(R*WT/16) * cout_tiles_per_wave <= 28; the tile's four planes must fit 18 LDS-DMA pieces. */
-int drc_conv3d_k3s2_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
-
-/* drc_conv3d_k3s2_fwd with both MFMA operands read straight from global memory (no LDS): the stride only changes the
- * per-lane address of the float4 B fragment.  Weights packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16). */
+/* Conv3d(k3, stride 2, pad 1) (+BN, +residual, +ReLU) -- hourglass.conv1/conv3 (stackhourglass.py:9-16) and the data gradient of the
+ * transposed convolutions -- with both MFMA operands read straight from global memory (no LDS): the stride only changes the per-lane address
+ * of the float4 B fragment.  Parameter block of drc_tapconv_fwd for the single 3x3x3 class with in_mul = 2; cout_tiles_per_wave in {1,2,4}
+ * must divide cout_pad/16; weights packed [27][cb_in][cout_pad][16] (engine.pack_weight_t16). */
 int drc_conv3d_k3s2_direct_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
 /* ConvTranspose3d(k3, s2, p1, output_padding 1) with all 8 output-parity classes from one register-resident set of B
@@ -213,12 +204,6 @@ int drc_pack_weights_wino2d(const float* w, int cout, int cin, int transposed, i
  * w [Cout][Cin][27] (transposed: [Cin][Cout][27]; flip reverses the taps -- data gradients) ->
  * out [64 = (xd*4+xh)*4+xw][ceil(Cin/16)][cout_pad][16], zero-padded. */
 int drc_pack_weights_wino(const float* w, int cout, int cin, int transposed, int flip, float* out, void* stream);
-
-/* Conv2d(k3, stride 1, dilation d, pad d) (+BN/bias, +residual, +ReLU): the 3x3 convolutions of the PSMNet feature CNN
- * (submodule.py:60-139) and of ResNet-50-FPN, with the wait protocol of drc_conv3d_k3s2_fwd (dense LDS-DMA tile, static piece
- * count, uncounted weight loads, two waves per SIMD).  Parameter block of drc_tapconv_fwd for the single 1x3x3 class
- * (OD = 1, tap spacing = dilation); cout_tiles_per_wave in {1,2,4}; (R+2d)*(WT+2d) voxels must fit 18 LDS-DMA pieces. */
-int drc_conv2d_k3_fwd(const drc_tapconv_params* p, int cout_tiles_per_wave, void* stream);
 
 /* Conv2d(k3, stride 1 or 2, dilation d) (+BN/bias, +residual, +ReLU) with both MFMA operands read straight from global memory
  * (the 2D instantiation of drc_conv3d_k3s2_direct_fwd; stride = in_mul, dilation = tap spacing of the class).  Weights packed
@@ -554,7 +539,7 @@ int drc_bn_apply_blocked(const float* x, const int* geom_x, float* y, const int*
 
 /* ---------------------------------------------------------------------------------------
  * Backward kernels (autograd of stackhourglass.py:130-174 in the reference).  Data gradients of the MFMA convolutions
- * reuse drc_tapconv_fwd / drc_tapconv3d_slide_fwd / drc_deconv3d_k3s2_fwd with transformed weights
+ * reuse drc_tapconv_fwd / drc_tapconv3d_direct_fwd / drc_deconv3d_k3s2_direct_fwd with transformed weights
  * (disprcnn_amd/modeling/psmnet/train.py).
  *   drc_upsample_softargmin_bwd : grad_cost [N,Dp,Hp,Wp] = d disp / d cost * grad_disp [N,H,W]  (overwritten).  scratch:
  *        drc_upsample_softargmin_bwd_scratch_floats(...) floats -- every 8 x 16 pixel tile stores the gradient of its coarse

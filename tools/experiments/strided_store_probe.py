@@ -1,4 +1,4 @@
-"""Times tools/experiments/strided_store_probe.hip on an MI355X: GB/s of a read + write stream, contiguous against 16-B slots at a 32-B stride."""
+"""Times attic/strided_store_probe.hip on an MI355X: GB/s of a read + write stream, contiguous against 16-B slots at a 32-B stride."""
 import ctypes as C
 import os
 import torch

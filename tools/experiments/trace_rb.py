@@ -1,4 +1,4 @@
-"""Development tool: per-step s_memtime timeline of the two waves of one SIMD in the rb kernel (needs a -DRB_TRACE variant lib built from tools/experiments/wino3d_rb_abl.hip)."""
+"""Development tool: per-step s_memtime timeline of the two waves of one SIMD in the rb kernel (needs a -DRB_TRACE variant lib built from attic/wino3d_rb_abl.hip)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

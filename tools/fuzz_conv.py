@@ -7,7 +7,7 @@ from disprcnn_amd import ops, engine as E
 
 dev = torch.device("cuda:0")
 if os.environ.get("DIRECT") == "0":
-    E.DIRECT["enabled"] = False          # sweep the LDS-staged variants instead
+    E.DIRECT["enabled"] = False          # sweep the generic kernel (tapconv.hip) instead
 WINO_ONLY = os.environ.get("WINO") == "1"
 if WINO_ONLY:
     E.SLIDE["min_od"] = 2
