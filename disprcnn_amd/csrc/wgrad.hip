@@ -126,11 +126,16 @@ __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_kernel(const drc_wgrad_pa
             sc += 4;
             while (sc >= p.WT) { sc -= p.WT; ++sr; }
         };
-        auto mfmas = [&](const float (&av)[NT], float bv, float okf, int wait_imm) __attribute__((always_inline)) {
+        auto mfmas = [&](float (&av)[NT], float bv, float okf, int wait_imm) __attribute__((always_inline)) {
             if constexpr (COUNTED) {
                 if (wait_imm == WAIT_ALL) __builtin_amdgcn_s_waitcnt(WAIT_ALL); else __builtin_amdgcn_s_waitcnt(WAIT_FETCHED);
                 __builtin_amdgcn_sched_barrier(0);
-                bv *= okf;
+                // the operands were written by `asm volatile` LDS reads the compiler's wait-count pass does not see: tie every use to this point
+                // (an empty asm with the register as in/out operand), so that no later pass can hoist a use above the hand-placed wait
+                asm volatile("" : "+v"(bv));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(av[t]));
+                bv = okf != 0.f ? bv : 0.f;        // a select, not a multiply: an Inf / NaN read from a ragged (over-read) slot must not become NaN * 0
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[t], 0, 0, 0);

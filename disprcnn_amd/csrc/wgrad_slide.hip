@@ -189,8 +189,12 @@ __global__ __launch_bounds__(64 * WS_WAVES) void wgrad_slide_kernel(const drc_wg
                             if (fetched) __builtin_amdgcn_s_waitcnt(0xC07F | (7 << 8));
                             else __builtin_amdgcn_s_waitcnt(0xC07F);
                             __builtin_amdgcn_sched_barrier(0);
+                            // (operands of `asm volatile` LDS reads: every use is tied behind the hand-placed wait)
+                            asm volatile("" : "+v"(bvs[cur]));
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(avs[cur][t]));
                         }
-                        const float bm = NK > 0 ? bvs[cur] * okf[m] : bvs[cur];
+                        const float bm = NK > 0 ? (okf[m] != 0.f ? bvs[cur] : 0.f) : bvs[cur];      // select, not multiply (Inf / NaN in a ragged slot)
 #pragma unroll
                         for (int t = 0; t < 9; ++t)
                             acc[kd * 9 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[cur][t], bm, acc[kd * 9 + t], 0, 0, 0);

@@ -345,8 +345,11 @@ int drc_conv16_k3_costvol_fwd(const drc_tapconv_params* p, int mindisp4, void* s
  * chunk q = p*4 + s*2 + g (p = 0 hi / 1 lo), element e of chunk (s, g) = channel 4g + 8(2s + (e>>2)) + (e&3) of the 32-channel block.
  * value = (float)hi + (float)lo, hi = fp16(value) (round to nearest), lo = fp16(value - hi); |value| <= 65504.
  * Weights: drc_s16_pack_weights layout [cout/32][cin/16][27 taps kd*9+kh*3+kw][hi, lo][64 lanes][8 halfs], pre-scaled by 2^wexp
- * (the caller folds 2^-wexp into scale).  cin, cout in {32, 64}; D % 3 == 0; W % 28 == 0 (1x28 MFMA tiles; H even for cin 32), or W = 14 /
- * W = 7 (2x14 / 4x7 tiles: the hourglass' half- and quarter-resolution maps). */
+ * (the caller folds 2^-wexp into scale).  cin, cout in {32, 64}; any D, H, W > 0 (round 6; the reference's contract at this resolution is
+ * D, H, W = 0 mod 4, stackhourglass.py:115-128): W <= 7 runs on 4x7 MFMA tiles, W <= 14 on 2x14, wider maps on 1x28 -- the last x tile and
+ * the last row tile are masked -- and a D that is not a multiple of 3 walks phantom zero planes behind the last one.  All 32 MFMA columns of a
+ * tile and no phantom work at W = 7 | 14 | 0 mod 28, D = 0 mod 3 (BASELINE's configs).  Range: a stored value is clamped to +-65504 and
+ * reported through `ovf` (below). */
 typedef struct drc_s16conv_params {
     const void* x;       /* RS16 input [N][cin/32][D+2][H+2][8][W+2][8]; ignored when left/right are given */
     const void* w;       /* packed split weights */
@@ -384,7 +387,7 @@ int drc_head_gather_fwd(const float* S, const float* res, float* cost, int N, in
  *                                conv5 / conv6, stackhourglass.py:22-30,44-49).  D, H, W = the INPUT dims; y16 and res have (2D, 2H, 2W);
  *                                cin = 64; weights: drc_s16 packing of the ConvTranspose weight with its first two axes swapped
  *                                ([Cout, Cin, 3,3,3], tap kd*9+kh*3+kw of o = 2i - 1 + k, no flip).
- * Shapes: the narrower map of the layer is 7, 14 or a multiple of 28 voxels wide (4x7, 2x14, 1x28 MFMA tiles). */
+ * Shapes: any (stride 2: even input dims); the narrower map of the layer picks the tile -- <= 7 voxels wide: 4x7, <= 14: 2x14, else 1x28 -- last tiles masked. */
 int drc_conv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3s2_s16_fwd(const drc_s16conv_params* p, void* stream);
 int drc_deconv3d_k3s2_s16_supported(int cin, int cout, int D, int H, int W);
@@ -393,8 +396,11 @@ int drc_deconv3d_k3s2_s16_fwd(const drc_s16conv_params* p, void* stream);
  * halfs [N][C/32][H+2][8][W+2][8] -- reference convbn of disprcnn/modeling/psmnet/submodule.py:9-16 at firstconv[2], firstconv[4] and the
  * BasicBlocks of layer1 / layer2 / layer3 (submodule.py:40-60, 68-95).  Uses the fields x, w, scale, shift, res, y16, N, H, W, cin, cout,
  * relu of the drc_s16conv_params block -- D is ignored, y32 / left / right must be NULL, lo4 = 0.  Weights: the drc_s16 packing with 9 taps kh*3+kw:
- * [cout/32][cin/16][9][hi, lo][64][8].  cin, cout in {32, 64, 128}; H % 28 == 0; W % 28 == 0 (W % 56 == 0 for cin = 32).  dil = 2
- * (padding 2; layer4, submodule.py:73): cin = 128, H % 56 == 0. */
+ * [cout/32][cin/16][9][hi, lo][64][8].  cin in {32, 64, 128} (wider layers: the caller chains launches over 128-channel slices, each adding
+ * the previous partial sum as its residual), cout a power of two in 32..512, any H, W > 0 (ragged last x group / row block masked).  dil = 2
+ * (padding 2; layer4, submodule.py:73): cin = 128, H % 56 == 0.  Range: as for the 3D kernels, a stored value is clamped to +-65504 and
+ * reported through p->ovf -- the callers (PSMNet's 2D CNN, the ResNet-FPN trunk and the RPN head under `auto`) run inside engine.guarded, which
+ * reads the word once per forward pass and repeats the pass on the fp32 kernels when it is set. */
 int drc_conv2d_k3_s16_supported(int cin, int cout, int H, int W, int dil);
 int drc_conv2d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
 /* RS16 converters (s16_ops.hip): interior only, the zero halo is the allocator's.  dense = NCDHW fp32 (D = 1, pd = 0 for 2D maps);
