@@ -522,3 +522,19 @@ def test_newest_profile_set_is_complete_and_from_one_commit():
     spec.loader.exec_module(mod)
     assert mod.check("r4") == []
     assert mod.check("r5c") == []                # the final set of round 5 (seven workloads, one commit)
+    assert mod.check("r6") == []                 # round 6 (the same seven workloads; its traffic files carry the digest of the kernel sources)
+
+
+def test_roofline_traffic_is_tied_to_the_kernel_sources():
+    """bench.py reads roofline.traffic from a committed PMC pass; the pass records a digest of the kernel sources
+    (profiles/summarize.py) and bench.py nulls the figure when the sources it runs differ.  Held here: the newest headline traffic file
+    carries a digest, and it is the digest of the sources in this tree (a kernel edit without a re-collected profile fails this test --
+    or must lower the claim by deleting the stale file)."""
+    import json
+    import os
+    from disprcnn_amd.csrc.build import source_digest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = json.load(open(os.path.join(root, "profiles", "r6_traffic.json"))).get("__meta__") or {}
+    assert meta.get("csrc_sha") and len(meta.get("commit", "")) >= 7
+    assert meta["csrc_sha"] == source_digest(), "kernel sources changed since profiles/r6_* were collected: re-run profiles/collect_all.sh r6"
+

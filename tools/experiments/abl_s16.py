@@ -13,18 +13,10 @@ VARIANTS = {
     "base": [],
     "nofin": [("            float s_;\n            if constexpr (KW == 2) s_ = part", "            float s_; v[e] = 0.f; vh[e] = vl[e] = (_Float16)0.f; return;\n            if constexpr (KW == 2) s_ = part")],
     "nopub": [("            for (int q = 0; q < 4; ++q) *(f32x4*)(xb + q * 1024) = (f32x4){a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};", "            for (int q = 0; q < 4; ++q) asm volatile(\"\" :: \"v\"(a[q * 4]), \"v\"(xb));")],
-    "nobar": [("        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        {   // slab t+2", "        asm volatile(\"\" ::: \"memory\");\n        {   // slab t+2")],
+    "nobar": [("        __builtin_amdgcn_s_barrier();\n        asm volatile(\"\" ::: \"memory\");\n        // contexts of the planes finalized", "        asm volatile(\"\" ::: \"memory\");\n        // contexts of the planes finalized")],
     "nostage": [("                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, LDS_PTR(dst + (cb * 8 + c) * CPB + h * 1024), 16, va[h], so, 0, 0);\n            }", "                asm volatile(\"\" :: \"v\"(va[h]), \"s\"(so), \"s\"(dst));\n            }")],
     "nostore": [("        auto stores = [&]() __attribute__((always_inline)) {\n", "        auto stores = [&]() __attribute__((always_inline)) {\n            return;\n")],
 }
-# idle lanes (28..31 of a 28-voxel row) read a zeroed LDS region instead of their neighbours' voxels: MFMA array toggling (DVFS) test
-VARIANTS["zidle"] = [
-    ("    const unsigned bfrag = (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + ((r * RT + rl) * SX + xl) * 16);",
-     "    for (int i_ = threadIdx.x; i_ < RING * SLAB / 16; i_ += 256) ((f32x4*)(lds + RING * SLAB + 2 * 4 * XW))[i_] = (f32x4){0.f, 0.f, 0.f, 0.f};\n"
-     "    __syncthreads();\n"
-     "    const unsigned bfrag = (n_ >= RT * WT ? (unsigned)(RING * SLAB + 2 * 4 * XW) : 0u) + (unsigned)(((k >> 1) * 8 + (k & 1) * 2 + g) * CPB + ((r * RT + rl) * SX + xl) * 16);"),
-    ("    constexpr size_t lds = RING * SLAB + 2 * 4 * XW;", "    constexpr size_t lds = RING * SLAB + 2 * 4 * XW + (KW == 2 ? RING * SLAB : 0);"),
-]
 VARIANTS["nofin_nopub"] = VARIANTS["nofin"] + VARIANTS["nopub"]
 VARIANTS["nofin_nopub_nobar"] = VARIANTS["nofin"] + VARIANTS["nopub"] + VARIANTS["nobar"]
 VARIANTS["mfma_only"] = VARIANTS["nofin"] + VARIANTS["nopub"] + VARIANTS["nobar"] + VARIANTS["nostage"] + VARIANTS["nostore"]
@@ -72,7 +64,7 @@ def build():
         f = os.path.join(OUT, f"s16_{name}.hip")
         open(f, "w").write(s)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-pass-failed", "-shared",
-                               "-o", os.path.join(OUT, f"libs16_{name}.so"), f])
+                               "-I", os.path.dirname(SRC), "-o", os.path.join(OUT, f"libs16_{name}.so"), f])
         os.remove(f)
         print("built", name, flush=True)
 
@@ -134,6 +126,16 @@ def run():
     zero = os.environ.get("ZERO") == "1"
     if zero:
         x.zero_()
+    if os.environ.get("CV") == "1":         # the cost-volume form (dres0[0]: 64 -> 32, the volume built from two 2D maps)
+        cin = 64
+        w = torch.randn(cout, cin, 3, 3, 3) * 0.05
+        wp, wexp = s16.pack_weight_s16(w.to(dev))
+        sc = torch.full((cout,), 2.0 ** -wexp, device=dev)
+        L = torch.zeros(N, 1, 1, H + 2, 8, W + 2, 8, dtype=torch.float16, device=dev)
+        L[:, :, :, 1:H + 1, :, 1:W + 1].normal_()
+        L[:, :, :, 1:H + 1, 4:, 1:W + 1] *= 2.0 ** -11
+        R = L.flip(0).contiguous()
+        p = DrcS16ConvParams(None, P(wp), P(sc), P(sh), None, P(y), None, P(L), P(R), N, D, H, W, cin, cout, 1, 0)
     only = os.environ.get("ONLY")
     for name in (only.split(",") if only else (["base", "mfma_only"] if zero else VARIANTS)):
         lib = C.CDLL(os.path.join(OUT, f"libs16_{name}.so"))
