@@ -1427,6 +1427,20 @@ class OverflowGuard:
         return bool(v)
 
 
+_SHARED_GUARDS = {}
+
+
+def one_guard(fn, device, what="guarded call", enabled=True):
+    """Run fn() -- several components in a row, e.g. the ResNet-FPN trunk and then DispRCNN3D on the same stereo pair -- under ONE range
+    guard of `device`: the components' own scopes nest into it, so the pass costs one read of the guard word (one stream synchronisation)
+    instead of one per component, and an overflow anywhere repeats all of fn() on the fp32 kernels."""
+    dev = torch.device(device)
+    g = _SHARED_GUARDS.get(dev)
+    if g is None:
+        g = _SHARED_GUARDS[dev] = OverflowGuard(dev)
+    return guarded(g, fn, what=what, enabled=enabled)
+
+
 def s16_allowed():
     """False while a guarded pass is being repeated on the fp32 kernels (or its back-off runs): every split-f16 decision consults this."""
     return not _GUARD["safe"]
