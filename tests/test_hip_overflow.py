@@ -357,3 +357,33 @@ def test_trunk_overflow_repeats_on_fp32(dev):
     assert over == 1
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+def test_2d_stage_reads_one_guard_for_trunk_and_rpn_head(dev):
+    """DispRCNN.forward: the trunk's bridged 3x3 layers and the RPN head's 256 -> 512 convolution report to ONE guard, read once at the end
+    of the stage; an input that leaves the range repeats the whole stage on the fp32 kernels and equals the TRUNK_S16-off result."""
+    from disprcnn_amd.modeling.detector import DispRCNN, default_cfg_2d
+    torch.manual_seed(1)
+    m = DispRCNN(default_cfg_2d("R-50-FPN", post_nms_top_n_test=40)).to(dev).eval()
+    pair = torch.rand(2, 3, 375, 1242, device=dev)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m({"left": pair[:1], "right": pair[1:]})
+        g = m._guard
+        assert g.policy.checks == 1 and g.policy.overflows == 0              # split-f16 layers ran, one read, in range
+        assert m.backbone._rt._guard.policy.checks == 0                       # the trunk's own guard stayed idle: it reported to the detector's
+        big = pair * 1.0e6
+        got = m({"left": big[:1], "right": big[1:]})
+        assert g.policy.checks == 2 and g.policy.overflows == 1
+        saved = dict(E.TRUNK_S16)
+        try:
+            E.TRUNK_S16["enabled"] = False
+            m.backbone._rt._ws.clear()
+            m.overflow_check = False
+            want = m({"left": big[:1], "right": big[1:]})
+        finally:
+            E.TRUNK_S16.update(saved)
+            m.overflow_check = True
+    for side in ("left", "right"):
+        for a, b in zip(got[side], want[side]):
+            assert len(a) == len(b) and torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("scores"), b.get_field("scores"))
