@@ -144,6 +144,8 @@ _SIGS = {
     "drc_cost_volume16_blocked_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "drc_conv3d_k3_s16_supported": (_I, [_I, _I, _I, _I, _I]),
     "drc_conv3d_k3_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
+    "drc_conv3d_k3_s16_wide": (_I, [C.POINTER(DrcS16ConvParams)]),
+    "drc_conv3d_k3_s16_wide_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
     "drc_conv3d_k3s2_s16_supported": (_I, [_I, _I, _I, _I, _I]),
     "drc_conv3d_k3s2_s16_fwd": (_I, [C.POINTER(DrcS16ConvParams), _P]),
     "drc_deconv3d_k3s2_s16_supported": (_I, [_I, _I, _I, _I, _I]),

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["tapconv.hip", "tapdirect.hip", "wino3d.hip", "wino3d_rb.hip", "wino2d.hip", "tapdeconv.hip", "deconvdirect.hip", "downdirect.hip", "stemconv.hip", "pointwise.hip", "linear.hip", "volume_ops.hip", "cout1_mfma.hip", "roi_ops.hip", "nms_ops.hip", "det_ops.hip", "post_ops.hip", "train_ops.hip", "bwd_ops.hip", "wgrad.hip", "wgrad_slide.hip", "conv16.hip", "conv16t.hip", "conv16x.hip", "ops16.hip", "convs16.hip", "convs16d.hip", "convs16u.hip", "convs16r.hip", "s16_ops.hip"]
+SOURCES = ["tapconv.hip", "tapdirect.hip", "wino3d.hip", "wino3d_rb.hip", "wino2d.hip", "tapdeconv.hip", "deconvdirect.hip", "downdirect.hip", "stemconv.hip", "pointwise.hip", "linear.hip", "volume_ops.hip", "cout1_mfma.hip", "roi_ops.hip", "nms_ops.hip", "det_ops.hip", "post_ops.hip", "train_ops.hip", "bwd_ops.hip", "wgrad.hip", "wgrad_slide.hip", "conv16.hip", "conv16t.hip", "conv16x.hip", "ops16.hip", "convs16.hip", "convs16w.hip", "convs16d.hip", "convs16u.hip", "convs16r.hip", "s16_ops.hip"]
 LIB = os.path.join(HERE, "libdisprcnn_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

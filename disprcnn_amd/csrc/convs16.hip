@@ -642,6 +642,7 @@ extern "C" int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* pp, void* stream)
     const long unit16 = (long)(p.cout / 32) * (p.D + 2) * (p.H + 2) * (p.W + 2) * 128;
     if (unit16 >= 0x7FFFFF00L / 2) return -5;
     hipStream_t s = (hipStream_t)stream;
+    if (drc_conv3d_k3_s16_wide(pp)) return drc_conv3d_k3_s16_wide_fwd(pp, stream);      // the cost-volume form at large batches: two tiles per wave (convs16w.hip)
     if (cv) return launch<4, true>(p, s);
     if (p.W <= 7) return p.cin == 32 ? launch<2, false, 4, 7>(p, s) : launch<4, false, 4, 7>(p, s);
     if (p.W <= 14) return p.cin == 32 ? launch<2, false, 2, 14>(p, s) : launch<4, false, 2, 14>(p, s);

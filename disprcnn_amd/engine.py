@@ -1586,6 +1586,14 @@ class ConvPlanS16:
         if kind == "s1":
             self._kfmt = "convs16_kernel<%d,%s,%d,%d,%%s,%%s,%%s>" % (cin // 16, "true" if cv else "false", rt, wt)
             self.kname = self._kfmt % ("false", "false", "false")  # (the residual / blocked-fp32-output / fused-head template flags follow the call's arguments)
+            # round 6: the cost-volume form runs two tiles per wave (convs16w.hip) where the launch has enough whole two-row blocks: the
+            # library decides (drc_conv3d_k3_s16_wide), asked here with stand-in pointers
+            from ._lib import DrcS16ConvParams
+            probe = DrcS16ConvParams(None if cv else 1, 1, 1, 1, None, 1, None, 1 if cv else None, 1 if cv else None, N, D, H, W, cin, cout, int(bool(relu)), 0, 1)
+            self._wide = bool(_lib.lib().drc_conv3d_k3_s16_wide(C.byref(probe)))
+            self._wname = "convs16w_kernel<%d,%s>" % (cin // 16, "true" if cv else "false")
+            if self._wide:
+                self.kname = self._wname
         elif kind == "2d":
             # convs16r.hip's dispatch: (waves over K, K slices per wave)
             wide = cin == 64 and W % 56 == 0 and cout == 128 and N * (H // 28) * (W // 56) * (cout // 32) >= 256
@@ -1641,7 +1649,9 @@ class ConvPlanS16:
         _lib.check(st, fn)
         if TIMING is not None:
             e1.record(torch.cuda.current_stream(dev))
-            if self.kind == "s1":
+            if self.kind == "s1" and self._wide and res is None and y32 is None and head is None:
+                kn = self._wname
+            elif self.kind == "s1":
                 kn = self._kfmt % ("true" if res is not None else "false", "true" if y32 is not None else "false", "true" if head is not None else "false")
             elif self.kind == "2d":
                 kn = self._kfmt % ("true" if res is not None else "false")

@@ -376,6 +376,14 @@ typedef struct drc_s16conv_params {
 } drc_s16conv_params;
 int drc_conv3d_k3_s16_supported(int cin, int cout, int D, int H, int W);
 int drc_conv3d_k3_s16_fwd(const drc_s16conv_params* p, void* stream);
+/* Round 6 (convs16w.hip): the cost-volume form (left / right set) with TWO MFMA tiles per wave -- a workgroup owns two rows of a column
+ * instead of one: 2.0 instead of 3.0 staged rows per output row, half the barriers per MFMA; 6-8 % faster, bit-identical results.  (Measured
+ * for the plain 32 -> 32 layer too: no gain; the residual and fused-head forms have no registers for a second accumulator set.)
+ * drc_conv3d_k3_s16_wide (host code, no launch) says whether drc_conv3d_k3_s16_fwd sends a parameter block there: the cost-volume form,
+ * W > 14, H even, at least 1024 two-row columns (smaller launches keep the finer columns); drc_conv3d_k3_s16_wide_fwd launches it for any
+ * cost-volume block. */
+int drc_conv3d_k3_s16_wide(const drc_s16conv_params* p);
+int drc_conv3d_k3_s16_wide_fwd(const drc_s16conv_params* p, void* stream);
 /* The second half of a fused head (p->head above): cost[n][z][y][x] = (res ? res[..] : 0) + scale * sum_{kh,kw} S[n][z][y+kh-1][x+kw-1][kh*3+kw]
  * (sources outside the volume contribute zero: the convolution's zero padding); cost, res: dense float [N][D][H][W] (res = the previous
  * head's cost, stackhourglass.py:142-144, or NULL); scale = 2^-wexp of the packed 32 -> 1 weights. */

@@ -38,7 +38,7 @@ def _model(dev, case, mx, mn, math="f32"):
 
 
 # (plan names: the last two template flags -- residual, blocked fp32 output -- follow the call's arguments and read false,false here)
-S16_LAYERS = {"dres0.0": "convs16_kernel<4,true,1,28,false,false,false>", "dres0.2": "convs16_kernel<2,false,1,28,false,false,false>",
+S16_LAYERS = {"dres0.0": "convs16w_kernel<4,true>",          # (round 6: the cost-volume layer runs two tiles per wave at the bench's batch, convs16w.hip) "dres0.2": "convs16_kernel<2,false,1,28,false,false,false>",
               "dres1.0": "convs16_kernel<2,false,1,28,false,false,false>", "dres1.2": "convs16_kernel<2,false,1,28,false,false,false>",
               "classif1.0": "convs16_kernel<2,false,1,28,false,false,false>", "classif2.0": "convs16_kernel<2,false,1,28,false,false,false>",
               "classif3.0": "convs16_kernel<2,false,1,28,false,false,false>"}
@@ -60,7 +60,7 @@ def _assert_bench_kernels_s16_b(ws):
     """Config B's volume (24 x 56 x 56): every layer of the regressor on the split-f16 kernels (1 x 28 tiles at full resolution and in the
     hourglass' half-resolution maps, 2 x 14 in its quarter-resolution ones)."""
     for name, pl in ws["p"].items():
-        assert pl.kname.startswith(("convs16_kernel", "convs16d_kernel", "convs16u_kernel")), (name, pl.kname)
+        assert pl.kname.startswith(("convs16_kernel", "convs16w_kernel", "convs16d_kernel", "convs16u_kernel")), (name, pl.kname)
 
 
 def _assert_bench_kernels(ws):
@@ -97,7 +97,7 @@ def test_bench_batch_executes_the_fused_head_and_residual_instantiations_by_name
     want = {"convs16_kernel<2,false,1,28,false,false,true>": 3,        # classif1..3[0] + the 32 -> 1 layer behind it
             "convs16_kernel<2,false,1,28,true,false,false>": 1,        # dres1[2] + cost0a
             "convs16_kernel<2,false,1,28,false,false,false>": 2,       # dres0[2], dres1[0]
-            "convs16_kernel<4,true,1,28,false,false,false>": 1,        # dres0[0] on the virtual cost volume
+            "convs16w_kernel<4,true>": 1,                              # dres0[0] on the virtual cost volume (two tiles per wave, convs16w.hip)
             "convs16d_kernel<2,2,14,3,true,true>": 3, "convs16d_kernel<4,4,7,2,true,false>": 3,
             "convs16_kernel<4,false,2,14,false,false,false>": 1, "convs16_kernel<4,false,2,14,true,false,false>": 2,     # conv2 (+ postsqu in dres3 / dres4)
             "convs16_kernel<4,false,4,7,false,false,false>": 3, "convs16u_kernel<4,7>": 3, "convs16u_kernel<2,14>": 3}

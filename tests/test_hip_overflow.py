@@ -136,6 +136,7 @@ LAYERS = [
     ("s1", 2, 64, 64, 6, 14, 14, True, "y16", True),        # 2x14 tiles, K over four waves
     ("s1", 3, 64, 64, 3, 7, 7, True, "y16", False),         # 4x7 tiles, ragged last row tile (idle rows must not report)
     ("cv", 2, 64, 32, 6, 28, 28, True, "y16", False),       # cost-volume form
+    ("cv", 80, 64, 32, 3, 28, 28, True, "y16", False),      # ... at a batch the two-tiles-per-wave kernel takes (convs16w.hip)
     ("s2", 2, 32, 64, 12, 28, 28, True, "y16", False),      # stride 2, cout split
     ("s2", 2, 64, 64, 6, 14, 14, True, "y16", False),       # stride 2, 4x7 tiles (ragged)
     ("up", 2, 64, 64, 3, 7, 7, True, "y16", True),          # transposed, 4x7 input tiles

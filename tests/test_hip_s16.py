@@ -237,6 +237,53 @@ def test_hourglass_layers_s16_vs_fp64_next_to_the_fp32_chain(dev, kind, N, cin, 
     _layer_case(dev, kind, N, cin, cout, D, H, W, relu, with_res, seed=("s1", "s2", "up").index(kind) * 331 + N + cin + 3 * cout + 7 * D + 11 * H + 13 * W)
 
 
+@pytest.mark.parametrize("N,D,H,W,lo4", [(80, 6, 28, 28, 0), (3, 12, 28, 28, -5), (2, 8, 12, 40, 2), (5, 4, 6, 64, -1), (2, 1, 2, 16, 0)])
+def test_costvol_layer_two_tiles_per_wave_is_bit_identical_and_vs_fp64(dev, N, D, H, W, lo4):
+    """convs16w.hip (round 6): the cost-volume layer with two MFMA tiles per wave -- through drc_conv3d_k3_s16_wide_fwd directly (any batch;
+    masked last x tile at W = 40 / 16, phantom depth planes at D = 8 / 4 / 1) and through the library's own dispatch (80 units of 28 rows:
+    1120 two-row columns -> picked) -- against the one-tile kernel BIT FOR BIT (same products, same summation order) and against the fp64
+    convolution of the materialised volume next to the fp32 chain."""
+    import ctypes as C
+    from disprcnn_amd import _lib
+    from disprcnn_amd._lib import DrcS16ConvParams
+    g = torch.Generator().manual_seed(N * 100 + D + W + lo4)
+    w = torch.randn(32, 64, 3, 3, 3, generator=g) * (2.0 / (27 * 64)) ** 0.5
+    scale = torch.rand(32, generator=g) + 0.5
+    shift = torch.randn(32, generator=g) * 0.1
+    L, R = torch.randn(N, 32, H, W, generator=g), torch.randn(N, 32, H, W, generator=g)
+    x = _ref_costvol(L, R, lo4, D)
+
+    def chain(dt):
+        return (F.conv3d(x.to(dt), w.to(dt), padding=1) * scale.to(dt).view(1, -1, 1, 1, 1) + shift.to(dt).view(1, -1, 1, 1, 1)).clamp_min(0)
+    ref = chain(torch.float64)
+    e32 = (chain(torch.float32).double() - ref).abs().max().item()
+    wp, wexp = s16.pack_weight_s16(w.to(dev))
+    sc = (scale * (2.0 ** -wexp)).to(dev).contiguous()
+    sh = shift.to(dev)
+    l16, r16 = E.RS16(N, 32, 1, H, W, 0, dev).from_dense(L.to(dev)), E.RS16(N, 32, 1, H, W, 0, dev).from_dense(R.to(dev))
+    lib = _lib.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    outs = {}
+    for name, fn, dil in (("wide", lib.drc_conv3d_k3_s16_wide_fwd, 1), ("dispatch", lib.drc_conv3d_k3_s16_fwd, 1), ("one tile", lib.drc_conv3d_k3_s16_fwd, 0x800)):
+        y = E.RS16(N, 32, D, H, W, 1, dev)
+        prm = DrcS16ConvParams(None, P(wp), P(sc), P(sh), None, P(y.storage), None, P(l16.storage), P(r16.storage), N, D, H, W, 64, 32, 1, lo4, dil)
+        _lib.check(fn(C.byref(prm), st), name)
+        if name == "dispatch":
+            assert bool(lib.drc_conv3d_k3_s16_wide(C.byref(prm))) == (N * (H // 2) * -(-W // 28) >= 1024 and H % 2 == 0 and W > 14)
+        outs[name] = y
+    torch.cuda.synchronize()
+    assert torch.equal(outs["wide"].storage, outs["one tile"].storage) and torch.equal(outs["dispatch"].storage, outs["one tile"].storage)
+    got = outs["wide"].to_dense().cpu()
+    m = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item()
+    print(f"convs16w N={N} {D}x{H}x{W} lo4={lo4}: max|err| {err:.3e} (fp32 chain {e32:.3e}), max|ref| {m:.3f}")
+    assert err <= 2e-5 * m + 1e-5 and err <= 2.0 * e32 + 1e-6 * m
+    v = outs["wide"].view7().clone()
+    v[:, :, 1:D + 1, 1:H + 1, :, 1:W + 1] = 0
+    assert not v.any()                   # the halo stays zero
+
+
 @pytest.mark.parametrize("N,D,H,W,with_prev", [
     (3, 12, 28, 28, True),          # Config A volume
     (18, 6, 28, 28, False),         # some workgroups walk two columns (units 0, 8, 16 share an XCD's 32 workers): the depth sums cross column boundaries
