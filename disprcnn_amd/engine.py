@@ -1368,6 +1368,7 @@ def cost_volume16_blocked(left, right, out, lo4, hi4, in_blocked_pad=-1):
 HEAD_FUSED = {"enabled": True}       # eval, split-f16 regressor: classif[0] + the 32 -> 1 layer as one fused launch + a gather (convs16.hip HEAD form) instead of a blocked fp32 tensor + cout1_mfma.hip
 LASTCONV_S16 = {"enabled": True}     # eval, split-f16 2D schedule: lastconv[0] (320 -> 128) as three chained split-f16 launches over the concat's parts (runtime._ws2d_s16)
 S16 = {"enabled": True}       # eval: the stride-1 3x3x3 layers at full resolution on the f16 matrix cores in split arithmetic (convs16.hip)
+CV_WIDE = {"enabled": True}   # eval, large batches: the cost-volume layer on the two-tiles-per-wave kernel (convs16w.hip); False: convs16.hip's one-tile form (A/B switch)
 
 
 
@@ -1590,7 +1591,9 @@ class ConvPlanS16:
             # library decides (drc_conv3d_k3_s16_wide), asked here with stand-in pointers
             from ._lib import DrcS16ConvParams
             probe = DrcS16ConvParams(None if cv else 1, 1, 1, 1, None, 1, None, 1 if cv else None, 1 if cv else None, N, D, H, W, cin, cout, int(bool(relu)), 0, 1)
-            self._wide = bool(_lib.lib().drc_conv3d_k3_s16_wide(C.byref(probe)))
+            self._wide = bool(CV_WIDE["enabled"] and _lib.lib().drc_conv3d_k3_s16_wide(C.byref(probe)))
+            if cv and not CV_WIDE["enabled"]:
+                self.dil = 0x800               # (the library's experiment bit of the 3D layers' unused `dil` field: keep the one-tile kernel)
             self._wname = "convs16w_kernel<%d,%s>" % (cin // 16, "true" if cv else "false")
             if self._wide:
                 self.kname = self._wname
