@@ -950,7 +950,9 @@ class BridgedConv2dS16:
 
     @staticmethod
     def worth(N, cin, cout, H, W):
-        """Large maps only: a column of the kernel is 28 rows x 28 columns x 32 couts, and the converters at both ends are extra launches."""
+        """Large maps only: a column of the kernel is 28 rows x 28 columns x 32 couts, and the converters at both ends are extra launches.
+        (No eval gate of its own: its callers -- the ResNet-FPN trunk, the RPN head, the heads of the 2D stage -- are inference-only on this
+        engine and raise NotImplementedError in train mode before they get here.)"""
         if not TRUNK_S16["enabled"] or BridgedConv2dS16.slices(cin) is None or cout not in (32, 64, 128, 256, 512) or not S16["enabled"]:
             return False
         if not s16_allowed():               # a guarded pass is being repeated on the fp32 kernels (OverflowGuard)
