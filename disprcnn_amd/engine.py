@@ -1417,6 +1417,7 @@ class OverflowGuard:
         self.policy = OverflowPolicy()
         self.used = False
         self.warned = False
+        self.dirty = False          # launches of a scope that ended in an exception may have set the word without anyone reading it
 
     def ptr(self):
         self.used = True
@@ -1465,10 +1466,18 @@ def guarded(guard, fn, strict=False, what="split-f16 path", enabled=True):
         return fn()
     import warnings
     pol = guard.policy
+    if getattr(guard, "dirty", False):          # a previous scope ended in an exception with launches in flight: its word was never read
+        guard.word.zero_()
+        guard.dirty = False
     _GUARD["cur"], _GUARD["safe"] = guard, (False if strict else not pol.want_fast())
     guard.used = False
     try:
-        out = fn()
+        try:
+            out = fn()
+        except BaseException:
+            if guard.used:
+                guard.dirty = True
+            raise
         if not guard.used:
             return out
         over = guard.tripped()

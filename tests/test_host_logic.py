@@ -510,6 +510,15 @@ def test_guarded_control_flow_without_a_gpu():
     # a pass without split-f16 launches is not read back
     g = FakeGuard([True])
     assert E.guarded(g, lambda: 3) == 3 and g.reads == 0
+    # an exception inside the pass: the scope closes, and the guard remembers that its word may hold a flag nobody read
+    g = FakeGuard([])
+
+    def boom():
+        g.used = True
+        raise KeyError("x")
+    with pytest.raises(KeyError):
+        E.guarded(g, boom)
+    assert E.guard_in_scope() is None and E.s16_allowed() and g.dirty
 
 
 def test_newest_profile_set_is_complete_and_from_one_commit():
