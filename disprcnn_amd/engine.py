@@ -1380,7 +1380,9 @@ CV_WIDE = {"enabled": True}   # eval, large batches: the cost-volume layer on th
 # (or met Inf / NaN); the component that opened the scope reads the word ONCE at the end of its forward pass (one stream synchronisation)
 # and -- "auto" -- runs the pass again with every split-f16 decision turned off (s16_allowed() False: the fp32 MFMA kernels), or --
 # math = "f16x2" -- raises.  Scopes nest: an inner component (PSMNet inside DispRCNN3D, the trunk inside DispRCNN) reports to the outermost
-# scope and leaves the check and the re-run to it.
+# scope and leaves the check and the re-run to it.  The scope is process-global state of the HOST layer (the reference drives one Python
+# thread per process, engine/inference.py:24-50; autograd's worker threads only run backward passes, which launch no split-f16 kernel); the
+# C ABI underneath stays re-entrant -- the word is an explicit argument of every launch.
 _GUARD = {"cur": None, "safe": False}
 
 
